@@ -1,0 +1,101 @@
+"""Pin the CPU oracle (oracle/repet_oracle.py) against golden vectors produced by the unmodified
+reference (tests/golden/make_golden.py). CPU only; float64; tolerance 1e-10 max-abs on
+background_signal and exact equality on every integer intermediate."""
+import numpy as np
+import pytest
+
+from helpers import golden_input, load_golden
+from oracle import repet_oracle as orc
+
+FAST_CASES = ["small_mono", "small_stereo", "mid_stereo"]
+ALGOS = ["original", "extended", "adaptive", "sim", "simonline"]
+TOL = 1e-10
+
+
+def _run(case, algo):
+    x, fs = golden_input(case)
+    tr = orc.Trace()
+    y = orc.ALGORITHMS[algo](np.array(x), fs, orc.Params(), tr)
+    return y, tr.items, load_golden(case)
+
+
+@pytest.mark.parametrize("case", FAST_CASES)
+@pytest.mark.parametrize("algo", ALGOS)
+def test_background_matches_reference(case, algo):
+    y, _, g = _run(case, algo)
+    stride = int(g["sample_stride"])
+    assert y.dtype == np.float64 and y.shape[1] == int(g["channels"])
+    assert np.max(np.abs(y[::stride] - g[f"{algo}.samples"])) <= TOL
+    assert np.allclose(np.sum(y, axis=0), g[f"{algo}.sum"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", FAST_CASES + ["g44k_stereo"])
+def test_original_intermediates(case):
+    _, tr, g = _run(case, "original")
+    assert tr["repeating_period"] == int(g["original.period"])
+    assert np.max(np.abs(tr["beat_spectrum"] - g["original.beat_spectrum"])) <= 1e-9 * np.max(g["original.beat_spectrum"])
+    fstride = int(g["frame_stride"])
+    rows = tr["mask_c0"][[0, 1, 5, 6, -1]][:, ::fstride]
+    assert np.max(np.abs(rows - g["original.mask_c0_rows"])) <= 1e-9
+
+
+@pytest.mark.parametrize("case", FAST_CASES + ["g44k_stereo"])
+def test_sim_intermediates(case):
+    _, tr, g = _run(case, "sim")
+    s = tr["similarity_matrix"]
+    t = s.shape[0]
+    assert np.max(np.abs(s[:, [0, t // 2, t - 1]] - g["sim.similarity_columns"])) <= 1e-12
+    counts = np.array([len(ix) for ix in tr["similarity_indices"]])
+    assert np.array_equal(counts, g["sim.counts"])
+    for row, frame in zip(g["sim.indices"], g["sim.index_frames"]):
+        assert np.array_equal(tr["similarity_indices"][frame], row[row >= 0])
+
+
+@pytest.mark.parametrize("case", FAST_CASES)
+def test_adaptive_and_extended_periods(case):
+    _, tr, g = _run(case, "adaptive")
+    assert np.array_equal(tr["repeating_periods"], g["adaptive.periods"])
+    _, tr, g = _run(case, "extended")
+    if "segment_periods" in tr:
+        assert np.array_equal(tr["segment_periods"], g["extended.periods"])
+    else:
+        assert len(g["extended.periods"]) == 1
+
+
+@pytest.mark.parametrize("case", FAST_CASES)
+def test_simonline_indices(case):
+    _, tr, g = _run(case, "simonline")
+    b = tr["buffer_frames"]
+    counts = np.array([len(ix) for ix in tr["similarity_indices"]])
+    assert np.array_equal(counts, g["simonline.counts"])
+    fstride = int(g["frame_stride"])
+    for k, row in enumerate(g["simonline.buffer_indices"]):
+        j = b - 1 + k * fstride
+        cols = row[row >= 0]
+        assert np.array_equal(tr["similarity_indices"][k * fstride], j - np.mod(j - cols, b))
+
+
+def test_extended_has_two_segments_at_8k():
+    g = load_golden("small_stereo")
+    assert len(g["extended.periods"]) == 2
+    x, fs = golden_input("small_stereo")
+    segs, overlap = orc.extended_plan(len(x), fs, orc.Params())
+    assert segs == [(0, 80000), (40000, 88000)] and overlap == 40000
+
+
+def test_half_to_even_buffer_length():
+    # B = round(10*8000/256) = round(312.5) = 312 (banker's rounding, repet.py:787)
+    assert round((10 * 8000) / 256) == 312
+
+
+def test_localmaxima_matches_definition():
+    rs = np.random.RandomState(0)
+    for n, d, k in [(50, 3, 5), (200, 7, 100), (31, 40, 4), (1, 2, 3)]:
+        v = rs.rand(n)
+        v[rs.randint(0, n, size=max(1, n // 10))] = np.nan
+        want = [i for i in range(n)
+                if v[i] >= 0.2 and all(v[i] > v[max(i - d, 0):i]) and all(v[i] > v[i + 1:min(i + d + 1, n)])]
+        want = np.array(want, dtype=int)
+        order = np.argsort(v[want])[::-1][:k]
+        vals, idx = orc.localmaxima(v, 0.2, d, k)
+        assert np.array_equal(idx, want[order])
