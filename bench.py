@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: repet.sim throughput on the MI355X, in audio-seconds per second.
+
+A "step" is one full REPET-SIM separation (BASELINE.json config 2: one 180-s 44.1 kHz stereo synthetic
+clip) of a clip that is already resident in HBM: STFT -> cosine self-similarity GEMM -> peak picking ->
+median mask -> iSTFT, all on the engine's HIP stream (repet_ctx_execute). With N ranks every rank owns
+its own clip (seed = rank): independent units, no data-path collective, weak scaling.
+
+    python bench.py                       # 1 GPU, finishes in a few minutes (incl. the CPU baseline)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. `roofline` describes the stage with the largest device time, measured
+with HIP events recorded on the engine's stream during the timed steps; `cpu_baseline` is the NumPy
+oracle (a port of the reference, validated against it) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "repet-python_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def cpu_baseline(fs, channels, seconds):
+    """Time the float64 NumPy oracle (CPU port of the reference) on a bounded sample of the workload."""
+    import numpy as np
+    from oracle import repet_oracle as orc
+    from repet_synth import synth
+    x = synth(seconds, fs, channels, 0)
+    t0 = time.perf_counter()
+    orc.sim(x, fs)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        blas = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        blas = os.cpu_count() or 1
+    return {"value": round(seconds / dt, 4), "unit": "audio-seconds/sec", "cores": int(blas), "kind": "port",
+            "sample": f"oracle.sim (NumPy float64 port of repet.py) on one {seconds}-s {fs} Hz {channels}-ch synth clip, "
+                      f"{dt:.1f} s wall; single-threaded except the similarity matmul ({blas} BLAS threads); "
+                      f"host has {os.cpu_count()} logical cores. sim is O(T^2): the 180-s clip is slower per audio-second"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--duration", type=float, default=180.0, help="clip length in seconds (config 2: 180)")
+    ap.add_argument("--algo", default="sim")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="length of the CPU-baseline sample clip")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import repet
+    from repet_synth import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the REPET engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    fs, channels = 44100, 2
+    clip = synth(args.duration, fs, channels, seed=rank)
+    params = repet.derive_params(fs)
+    ctx = repet.Context(local_rank)
+    ctx.upload(clip)                      # input resident in HBM (fp32, interleaved) before timing starts
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.execute(args.algo, params)
+    stage_ms, stage_meta = {}, {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tm = ctx.execute(args.algo, params, timing=True)     # blocks until the stream is idle
+        for s in tm["stages"]:
+            stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
+            stage_meta[s["name"]] = s
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = ctx.download()
+    assert out.shape == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        stages = []
+        for name, total in stage_ms.items():
+            ms = total / steps
+            meta = stage_meta[name]
+            entry = {"name": name, "ms": round(ms, 4), "GB/s": round(meta["bytes"] / (ms * 1e-3) / 1e9, 1)}
+            if meta["flops"] > 0:
+                entry["TFLOP/s"] = round(meta["flops"] / (ms * 1e-3) / 1e12, 2)
+            stages.append(entry)
+        dom = max(stages, key=lambda s: s["ms"])
+        meta = stage_meta[dom["name"]]
+        if meta["flops"] > 0 and meta["flops"] / (MFMA_F32_PEAK_TF * 1e12) > meta["bytes"] / (HBM_PEAK_GBS * 1e9):
+            ach = meta["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None}
+        else:
+            ach = meta["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["ms_per_launch"] = dom["ms"]
+        roof["algorithmic_per_launch"] = meta["flops"] if roof["bound"] == "mfma" else meta["bytes"]
+        line = {
+            "metric": f"audio-seconds/sec (x real-time) for repet.{args.algo}, 44.1 kHz stereo",
+            "value": round(args.duration * args.steps * world / elapsed, 2),
+            "unit": "audio-seconds/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"repet.{args.algo} on one {args.duration:g}-s 44.1 kHz stereo synthetic clip per GPU "
+                                   f"(BASELINE.json configs[1]), clip resident in HBM",
+                       "clips_per_step": world, "samples_per_clip": int(clip.shape[0]), "channels": channels,
+                       "frames": int(ctx.last_frame_count()), "parallelism": f"clip-parallel x{world}, no collective"},
+            "roofline": roof,
+            "stages": stages,
+            "device_ms_per_step": round(sum(s["ms"] for s in stages), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * repet_hip.h -- C ABI of librepet_hip.so, the MI355X (gfx950) REPET separation engine.
+ *
+ * The reference (zafarrafii/REPET-Python, repet.py) has no FFI seam: its boundary is the Python call
+ *   repet.<original|extended|adaptive|sim|simonline>(audio_signal[N,C], sampling_frequency)
+ *     -> background_signal[N,C] float64                      (repet.py:67,205,422,571,712)
+ * This header is what a ctypes binding of that call binds instead. Plain C types
+ * only; the caller owns every buffer; the library keeps no caller pointer after a call returns.
+ *
+ * Every derived size (window length, period range in frames, cutoff bin, buffer length ...) crosses
+ * the ABI as an INTEGER already evaluated by the caller with the reference's own expressions
+ * (Python round()/np.round are half-to-even, C round() is not) -- the C side never converts
+ * seconds to frames.
+ *
+ * Return value: 0 on success, negative repet_status otherwise; text via repet_last_error().
+ * Thread-safety: a repet_ctx serialises its own calls on one HIP stream; different contexts may be
+ * used from different host threads concurrently.
+ */
+#ifndef REPET_HIP_H
+#define REPET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REPET_ABI_VERSION 1
+
+typedef enum repet_status {
+    REPET_OK = 0,
+    REPET_ERR_BAD_ARG = -1,   /* malformed argument: the Python shim raises ValueError            */
+    REPET_ERR_TOO_SHORT = -2, /* clip too short for the algorithm (repet.py:1263, :802): ValueError */
+    REPET_ERR_HIP = -3,       /* HIP runtime error: RuntimeError                                   */
+    REPET_ERR_OOM = -4,       /* device allocation failed                                          */
+    REPET_ERR_LIMIT = -5      /* size outside what the kernels support (documented in DESIGN.md)   */
+} repet_status;
+
+/* Which public function of the reference to run. */
+typedef enum repet_algo {
+    REPET_ORIGINAL = 0,  /* repet.py:67-202  */
+    REPET_EXTENDED = 1,  /* repet.py:205-419 */
+    REPET_ADAPTIVE = 2,  /* repet.py:422-568 */
+    REPET_SIM = 3,       /* repet.py:571-709 */
+    REPET_SIMONLINE = 4  /* repet.py:712-911 */
+} repet_algo;
+
+typedef enum repet_dtype { REPET_F32 = 0, REPET_F64 = 1, REPET_I16 = 2 } repet_dtype;
+
+/* The reference's nine module globals (repet.py:42-63), already converted to frames/bins/samples. */
+typedef struct repet_params {
+    int32_t window_length;       /* W = 2^ceil(log2(0.04 fs))                       repet.py:130 */
+    int32_t step_length;         /* H = W/2                                         repet.py:132 */
+    int32_t period_lo;           /* np.round(period_range[0]*fs/H)                  repet.py:165 */
+    int32_t period_hi;           /* np.round(period_range[1]*fs/H)                  repet.py:165 */
+    int32_t cutoff_bins;         /* round(cutoff_frequency*W/fs)                    repet.py:173 */
+    int32_t filter_order;        /* adaptive median order                           repet.py:54  */
+    int32_t seg_len_frames;      /* int(round(segment_length*fs/H))   (adaptive)    repet.py:519 */
+    int32_t seg_step_frames;     /* int(round(segment_step*fs/H))     (adaptive)    repet.py:520 */
+    int32_t sim_distance_frames; /* int(round(similarity_distance*fs/H))            repet.py:670 */
+    int32_t sim_number;          /* similarity_number                               repet.py:60  */
+    int32_t buffer_frames;       /* round(buffer_length*fs/H)         (simonline)   repet.py:787 */
+    int32_t reserved0;
+    int64_t seg_len_samples;     /* round(segment_length*fs)          (extended)    repet.py:266 */
+    int64_t seg_step_samples;    /* round(segment_step*fs)            (extended)    repet.py:267 */
+    double sim_threshold;        /* similarity_threshold                            repet.py:58  */
+} repet_params;
+
+/* Per-stage device time of the last repet_ctx_execute, from HIP events on the context's stream. */
+#define REPET_MAX_STAGES 16
+typedef struct repet_timing {
+    int32_t n_stages;
+    int32_t reserved0;
+    float total_ms;                       /* first event to last event                     */
+    float stage_ms[REPET_MAX_STAGES];     /* one entry per stage, in launch order          */
+    char stage_name[REPET_MAX_STAGES][24];
+    double stage_bytes[REPET_MAX_STAGES]; /* algorithmic HBM bytes of the stage */
+    double stage_flops[REPET_MAX_STAGES]; /* algorithmic flops of the stage                 */
+} repet_timing;
+
+typedef struct repet_ctx repet_ctx;
+
+/* ---- library --------------------------------------------------------------------------------- */
+int repet_abi_version(void);
+int repet_device_count(void);
+const char* repet_last_error(void); /* thread-local text of the last failure on this thread */
+
+/* ---- context: one per (host thread, device); owns a stream, workspaces, twiddle tables ------- */
+int repet_ctx_create(int device, repet_ctx** out);
+int repet_ctx_destroy(repet_ctx* ctx);
+
+/* Device-resident path (what bench.py times): upload once, execute any number of times, download.
+ * upload  : audio[n_samples*n_channels] in NumPy C order (audio[n*C + c]), converted to fp32 on device
+ * execute : runs the whole algorithm on the resident clip; blocks until the stream is idle
+ * download: background_signal as float64 [n_samples][n_channels]                                  */
+int repet_ctx_upload(repet_ctx* ctx, const void* audio, int dtype, int64_t n_samples, int32_t n_channels);
+int repet_ctx_execute(repet_ctx* ctx, int algo, const repet_params* p, repet_timing* timing /* nullable */);
+int repet_ctx_download(repet_ctx* ctx, double* out);
+
+/* ---- one-shot drop-in: replaces repet.<algo>(audio_signal, fs) (repet.py:67,205,422,571,712) -- */
+int repet_run(int algo, const void* audio, int dtype, int64_t n_samples, int32_t n_channels,
+              const repet_params* p, double* out, int device, repet_timing* timing /* nullable */);
+
+/* Batch of independent clips dealt round-robin (longest first) over n_devices GPUs of this process. */
+int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype,
+                    const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
+                    double* const* out, int32_t n_devices);
+
+/* ---- stage-level exports (parity tests; layouts follow the reference helper they replace) ---- */
+
+/* repet.py:1021-1028 (centred=1) / repet.py:781 (centred=0): number of frames for n samples. */
+int64_t repet_frame_count(int64_t n_samples, int32_t window_length, int32_t step_length, int32_t centred);
+
+/* _stft, repet.py:1001-1060. x[n] one channel -> spec[T][F] interleaved (re,im) fp32, F = W/2+1
+ * (frame-major; the reference's (W,T) array is its transpose plus the mirrored bins). */
+int repet_stft(repet_ctx* ctx, const float* x, int64_t n, const float* window, int32_t window_length,
+               int32_t step_length, int32_t centred, float* spec_out, int64_t n_frames);
+
+/* _istft, repet.py:1063-1105. spec[T][F] (re,im) -> y[(T-1)*H] (centred: trimmed W-H each end and
+ * divided by sum(window[0:W:H])). */
+int repet_istft(repet_ctx* ctx, const float* spec, int64_t n_frames, const float* window,
+                int32_t window_length, int32_t step_length, float* y_out, int64_t n_out);
+
+/* _selfsimilaritymatrix, repet.py:1209-1225. v[T][F] (frame-major magnitudes) -> s[T][T]. */
+int repet_selfsim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, float* s_out);
+
+/* _beatspectrum, repet.py:1142-1158 (input already squared by the caller, as in the reference):
+ * p[T][F] -> beat[n_lags], n_lags <= T. */
+int repet_beat_spectrum(repet_ctx* ctx, const float* p, int64_t n_frames, int32_t n_freq,
+                        float* beat_out, int32_t n_lags);
+
+/* _beatspectrogram, repet.py:1161-1206: p[T][F] -> beat[T][seg_len] (frame-major). */
+int repet_beat_spectrogram(repet_ctx* ctx, const float* p, int64_t n_frames, int32_t n_freq,
+                           int32_t seg_len, int32_t seg_step, float* beat_out);
+
+/* _periods, repet.py:1249-1291: beat[n_cols][n_lags] -> period[n_cols]. */
+int repet_periods(repet_ctx* ctx, const float* beat, int32_t n_cols, int32_t n_lags, int32_t period_lo,
+                  int32_t period_hi, int32_t* period_out);
+
+/* _localmaxima over every row of m[n_rows][n_cols], repet.py:1294-1383: idx[n_rows][number] (-1 padded,
+ * sorted by value descending) and count[n_rows]. */
+int repet_local_maxima(repet_ctx* ctx, const float* m, int32_t n_rows, int32_t n_cols, float min_value,
+                       int32_t min_distance, int32_t number, int32_t* idx_out, int32_t* count_out);
+
+/* _mask / _adaptivemask / _simmask, repet.py:1386-1545: v[T][F] -> mask[T][F] (no high-pass override). */
+int repet_mask_period(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, int32_t period,
+                      float* mask_out);
+int repet_mask_adaptive(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq,
+                        const int32_t* periods, int32_t filter_order, float* mask_out);
+int repet_mask_sim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, const int32_t* idx,
+                   const int32_t* count, int32_t number, float* mask_out);
+
+/* Integer intermediates of the last repet_ctx_execute (for index-set / period parity checks).
+ * periods: original -> 1 value; extended -> one per segment; adaptive -> one per frame.
+ * sim indices: idx[T][number] (-1 padded) + count[T]; simonline: rows for frames B-1..T-1, FRAME numbers. */
+int repet_ctx_last_periods(repet_ctx* ctx, int32_t* out, int32_t capacity, int32_t* n_written);
+int repet_ctx_last_sim_indices(repet_ctx* ctx, int32_t* idx_out, int32_t* count_out, int32_t n_rows,
+                               int32_t number);
+int repet_ctx_last_frame_count(repet_ctx* ctx, int64_t* n_frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REPET_HIP_H */

@@ -222,9 +222,12 @@ def localmaxima(v, min_value, d, number_values):
 
 def indices(sim, threshold, d, number):
     """Similar-frame index list of every frame: column i of ``sim`` is scanned (repet.py:1348-1383)."""
-    by_col = np.ascontiguousarray(sim.T)
-    keep = localmaxima_mask(by_col, threshold, d)
-    return [_top_indices(by_col[i], keep[i], number)[1] for i in range(sim.shape[0])]
+    out = []
+    for lo in range(0, sim.shape[0], 64):        # 64 columns at a time keeps the scan in cache
+        by_col = np.ascontiguousarray(sim[:, lo:lo + 64].T)
+        keep = localmaxima_mask(by_col, threshold, d)
+        out.extend(_top_indices(by_col[i], keep[i], number)[1] for i in range(by_col.shape[0]))
+    return out
 
 
 # ----------------------------------------------------------------------------- masks

@@ -1,0 +1,95 @@
+// Shared declarations for the gfx950 REPET engine (kernels + host orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace repet {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kFreqAlign = 32;     // spectrogram rows are padded to a multiple of 32 bins (GEMM K-step)
+constexpr int kTile = 128;         // Gram tile edge; frame-major matrices are padded to whole tiles
+constexpr float kMaskEps = 2.220446049250313e-16f;  // np.finfo(float).eps, repet.py:1446
+
+__host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// ---- kernel launchers (implemented in the .hip files; all asynchronous on `s`) -------------------
+
+// K1: frame + window + real FFT + magnitude (+ channel mean, unit-norm rows).
+//   audio[n][C] fp32 interleaved -> X[c][t][FS] (re,im), V[c][t][FS], Vm[t][FS] (mean magnitude),
+//   Vn[t][FS] (Vm / ||Vm||, the cosine-similarity operand), P[t][FS] (Vm^2, the beat-spectrum operand).
+//   Any of Vm/Vn/P may be null. Pad bins [F,FS) are written as zero. centred: repet.py:1031 vs :781.
+struct StftArgs {
+    const float* audio; int64_t n_samples; int32_t n_channels;
+    int64_t sample_offset;   // first sample of the clip inside `audio` (segments of `extended`)
+    const float* window; const float2* twiddle;   // twiddle[m] = exp(-2 pi i m / W), m < W
+    int32_t W, H; int64_t T; int32_t FS; int32_t centred;
+    float2* X; float* V; int64_t chan_stride;     // elements between channels in X and V (= Tpad*FS)
+    float* Vm; float* Vn; float* P;
+};
+hipError_t launch_stft(const StftArgs& a, hipStream_t s);
+
+// K9: masked spectrum -> inverse real FFT -> time frames yf[c][t][W] (scaled by 1/W like np.fft.ifft).
+struct IstftArgs {
+    const float2* Y; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t FS; int32_t W;
+    const float2* twiddle; float* frames;  // frames[c][t][W]
+};
+hipError_t launch_istft_frames(const IstftArgs& a, hipStream_t s);
+
+// Overlap-add of frames[c][t][W] at hop H into out[n][C] (interleaved), out sample n takes padded
+// position n + trim; multiplied by `scale` (1/sum(window[0:W:H])).
+struct OlaArgs {
+    const float* frames; int32_t n_channels; int64_t T; int32_t W, H; int64_t trim;
+    float* out; int64_t n_out; int64_t out_offset; float scale; int32_t accumulate_weighted;
+    // accumulate_weighted (extended, repet.py:380-414): out += w(n) * y instead of out = y, with the
+    // triangular fade-in over [0,fade_in) and fade-out over [n_out-fade_out, n_out)
+    int64_t fade_in, fade_out;
+};
+hipError_t launch_overlap_add(const OlaArgs& a, hipStream_t s);
+
+// K3: S[T][TS] = A A^T for A[Tpad][FS] fp32 (rows >= T are zero), MFMA fp32, upper tiles mirrored.
+hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, hipStream_t s);
+// K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
+hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags,
+                            int32_t LP, hipStream_t s);
+
+// Windowed diagonal sums of the band: beat[w][l] = sum_{t=lo_w}^{hi_w - l} band[t][l] / ((len - l) * F)
+//   window w covers frames [start0 + w*step, start0 + w*step + len) clipped to [0,T).
+hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,
+                                  int64_t start0, int64_t step, int64_t len, int32_t n_windows,
+                                  float* beat, int32_t beat_pitch, hipStream_t s);
+
+// K7: period[c] = argmax(beat[c][lo:hi]) + 1 + lo (first max wins), hi = min(period_hi, n_lags/3).
+hipError_t launch_periods(const float* beat, int32_t n_cols, int32_t pitch, int32_t n_lags, int32_t lo,
+                          int32_t hi, int32_t* period, hipStream_t s);
+// adaptive: expand per-window periods to per-frame periods with the reference's replicate-with-a-hole
+// rule (repet.py:1194-1204): frame i+step-1 of every window keeps the all-zero column => lo+1.
+hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, int32_t step, int64_t T,
+                                 int32_t lo, int32_t* frame_period, hipStream_t s);
+
+// K4: strict local maxima (+-d, clipped) of every row of M[n_rows][pitch], top `number` by value.
+//   mode 0: row r is M[r][0..n_cols); indices are column numbers.
+//   mode 1 (simonline): "row" j is the circular-buffer view of the band: element c is
+//           band[j-l][l], l = (j-c) mod B, for c < B = n_cols; indices are FRAME numbers j-l.
+hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
+                               int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
+                               int32_t idx_pitch, int32_t* count, hipStream_t s);
+
+// K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
+// multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).
+struct MaskArgs {
+    const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t F, FS;
+    float2* X; float* mask; int32_t cutoff;
+};
+hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
+                           int64_t first_frame, hipStream_t s);
+hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
+hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host, hipStream_t s);
+
+// elementwise helpers
+hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);
+hipError_t launch_convert_out(const float* src, double* dst, int64_t count, hipStream_t s);
+hipError_t launch_square(const float* src, float* dst, int64_t count, hipStream_t s);
+hipError_t launch_unit_rows(const float* src, float* dst, int64_t T, int32_t F, int32_t FS, hipStream_t s);
+
+}  // namespace repet

@@ -1,0 +1,820 @@
+// Host orchestration and C ABI (include/repet_hip.h) of the gfx950 REPET engine.
+//
+// A repet_ctx owns one HIP stream, grow-only device workspaces and the per-window-length tables
+// (periodic Hamming window, FFT twiddles). repet_ctx_execute chains the kernels of one variant on
+// that stream with no host round trip in between (periods and index lists stay on the device).
+#include "../../include/repet_hip.h"
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace repet;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? REPET_ERR_OOM : REPET_ERR_HIP,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+        }                                                                                          \
+    } while (0)
+
+#define RP_TRY(expr)                                                                               \
+    do {                                                                                           \
+        int rc_ = (expr);                                                                          \
+        if (rc_ != REPET_OK) return rc_;                                                           \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Tables {
+    DevBuf window, twiddle;
+    double cola = 1.0;   // sum(window[0:W:H]) for H = W/2 (repet.py:1103)
+};
+
+}  // namespace
+
+struct repet_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // resident clip
+    DevBuf staging, audio, out, out64;
+    int64_t n_samples = 0;
+    int32_t n_channels = 0;
+    // workspaces
+    DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
+    std::map<int, std::unique_ptr<Tables>> tables;
+    // last run
+    int last_algo = -1;
+    int64_t last_T = 0;
+    int32_t last_n_periods = 0;
+    int64_t last_idx_rows = 0;
+    int32_t last_idx_pitch = 0;
+    // timing
+    std::vector<hipEvent_t> events;
+    repet_timing* timing = nullptr;
+    int n_marks = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = 0;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() { if (ok) (void)hipSetDevice(prev); }
+};
+
+int get_tables(repet_ctx* c, int W, Tables** out) {
+    auto it = c->tables.find(W);
+    if (it != c->tables.end()) { *out = it->second.get(); return REPET_OK; }
+    if (W < 64 || W > 8192 || (W & (W - 1))) return fail(REPET_ERR_LIMIT, "window length must be a power of two in [64, 8192]");
+    auto t = std::make_unique<Tables>();
+    std::vector<float> win(W);
+    std::vector<float2> tw(W);
+    const double two_pi = 6.283185307179586476925286766559;
+    std::vector<double> wd(W);
+    for (int n = 0; n < W; ++n) {
+        wd[n] = 0.54 - 0.46 * std::cos(two_pi * n / W);   // scipy.signal.hamming(W, sym=False), repet.py:131
+        win[n] = (float)wd[n];
+        tw[n] = make_float2((float)std::cos(two_pi * n / W), (float)(-std::sin(two_pi * n / W)));
+    }
+    t->cola = wd[0] + wd[W / 2];
+    HIP_TRY(t->window.ensure(W * sizeof(float)));
+    HIP_TRY(t->twiddle.ensure(W * sizeof(float2)));
+    HIP_TRY(hipMemcpyAsync(t->window.p, win.data(), W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->twiddle.p, tw.data(), W * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = t.get();
+    c->tables[W] = std::move(t);
+    return REPET_OK;
+}
+
+int upload_twiddle_only(repet_ctx* c, int W, const float2** tw) {
+    Tables* t = nullptr;
+    RP_TRY(get_tables(c, W, &t));
+    *tw = t->twiddle.as<float2>();
+    return REPET_OK;
+}
+
+void mark(repet_ctx* c, const char* name, double bytes, double flops) {
+    if (!c->timing) return;
+    if (c->n_marks >= REPET_MAX_STAGES) return;
+    while ((int)c->events.size() < REPET_MAX_STAGES + 1) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->events.push_back(e);
+    }
+    (void)hipEventRecord(c->events[c->n_marks + 1], c->stream);
+    std::snprintf(c->timing->stage_name[c->n_marks], sizeof(c->timing->stage_name[0]), "%s", name);
+    c->timing->stage_bytes[c->n_marks] = bytes;
+    c->timing->stage_flops[c->n_marks] = flops;
+    c->n_marks++;
+}
+
+void begin_timing(repet_ctx* c, repet_timing* t) {
+    c->timing = t;
+    c->n_marks = 0;
+    if (!t) return;
+    std::memset(t, 0, sizeof(*t));
+    while ((int)c->events.size() < REPET_MAX_STAGES + 1) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { c->timing = nullptr; return; }
+        c->events.push_back(e);
+    }
+    (void)hipEventRecord(c->events[0], c->stream);
+}
+
+void end_timing(repet_ctx* c) {
+    if (!c->timing) return;
+    repet_timing* t = c->timing;
+    t->n_stages = c->n_marks;
+    for (int i = 0; i < c->n_marks; ++i) (void)hipEventElapsedTime(&t->stage_ms[i], c->events[i], c->events[i + 1]);
+    if (c->n_marks > 0) (void)hipEventElapsedTime(&t->total_ms, c->events[0], c->events[c->n_marks]);
+    c->timing = nullptr;
+}
+
+// Geometry shared by every variant.
+struct Geo {
+    int W, H, F, FS;
+    int64_t T, Tpad, chan_stride;
+    int C;
+};
+
+Geo make_geo(int W, int H, int64_t T, int C) {
+    Geo g;
+    g.W = W; g.H = H; g.F = W / 2 + 1; g.FS = (int)round_up(g.F, kFreqAlign);
+    g.T = T; g.Tpad = round_up(T > 0 ? T : 1, kTile); g.chan_stride = g.Tpad * g.FS; g.C = C;
+    return g;
+}
+
+int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p) {
+    HIP_TRY(c->X.ensure((size_t)g.C * g.chan_stride * sizeof(float2)));
+    HIP_TRY(c->V.ensure((size_t)g.C * g.chan_stride * sizeof(float)));
+    const size_t row_bytes = (size_t)g.FS * sizeof(float);
+    if (want_vn) {
+        HIP_TRY(c->Vn.ensure((size_t)g.chan_stride * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->Vn.as<float>() + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * row_bytes, c->stream));
+    }
+    if (want_p) {
+        HIP_TRY(c->P.ensure((size_t)g.chan_stride * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->P.as<float>() + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * row_bytes, c->stream));
+    }
+    return REPET_OK;
+}
+
+int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64_t n, int centred, bool vn, bool p) {
+    StftArgs a{};
+    a.audio = c->audio.as<float>(); a.n_samples = n; a.n_channels = g.C; a.sample_offset = offset;
+    a.window = tb->window.as<float>(); a.twiddle = tb->twiddle.as<float2>();
+    a.W = g.W; a.H = g.H; a.T = g.T; a.FS = g.FS; a.centred = centred;
+    a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
+    a.Vm = nullptr; a.Vn = vn ? c->Vn.as<float>() : nullptr; a.P = p ? c->P.as<float>() : nullptr;
+    HIP_TRY(launch_stft(a, c->stream));
+    const double in_b = 4.0 * n * g.C, spec_b = (8.0 + 4.0) * g.F * g.T * g.C, mean_b = 4.0 * g.F * g.T;
+    mark(c, "stft", in_b + spec_b + mean_b, 0);
+    return REPET_OK;
+}
+
+MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
+    MaskArgs m{};
+    m.V = c->V.as<float>(); m.chan_stride = g.chan_stride; m.n_channels = g.C; m.T = g.T; m.F = g.F; m.FS = g.FS;
+    m.X = c->X.as<float2>(); m.mask = nullptr; m.cutoff = cutoff;
+    return m;
+}
+
+// masked spectrum -> time frames -> overlap-add into c->out
+int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_t n_out, int64_t out_offset,
+              bool weighted, int64_t fade_in, int64_t fade_out) {
+    HIP_TRY(c->frames.ensure((size_t)g.C * g.T * g.W * sizeof(float)));
+    IstftArgs ia{};
+    ia.Y = c->X.as<float2>(); ia.chan_stride = g.chan_stride; ia.n_channels = g.C; ia.T = g.T; ia.FS = g.FS; ia.W = g.W;
+    ia.twiddle = tb->twiddle.as<float2>(); ia.frames = c->frames.as<float>();
+    HIP_TRY(launch_istft_frames(ia, c->stream));
+    mark(c, "istft_frames", 8.0 * g.F * g.T * g.C + 4.0 * g.W * g.T * g.C, 0);
+    OlaArgs oa{};
+    oa.frames = c->frames.as<float>(); oa.n_channels = g.C; oa.T = g.T; oa.W = g.W; oa.H = g.H; oa.trim = trim;
+    oa.out = c->out.as<float>(); oa.n_out = n_out; oa.out_offset = out_offset; oa.scale = (float)(1.0 / tb->cola);
+    oa.accumulate_weighted = weighted ? 1 : 0; oa.fade_in = fade_in; oa.fade_out = fade_out;
+    HIP_TRY(launch_overlap_add(oa, c->stream));
+    mark(c, "overlap_add", 4.0 * g.W * g.T * g.C + 4.0 * n_out * g.C, 0);
+    return REPET_OK;
+}
+
+// ---- original on samples [offset, offset+n) of the resident clip (also one segment of extended) ----
+int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n, int32_t* period_slot,
+                 bool weighted, int64_t fade_in, int64_t fade_out) {
+    Tables* tb = nullptr;
+    RP_TRY(get_tables(c, p->window_length, &tb));
+    const int64_t T = repet_frame_count(n, p->window_length, p->step_length, 1);
+    const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
+    const int hi = (int)std::min<int64_t>(p->period_hi, T / 3);
+    if (hi <= p->period_lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence (clip too short for the period range)");
+    RP_TRY(ensure_spectra(c, g, false, true));
+    RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true));
+    const int LP = (int)round_up(hi, 64);
+    HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
+    HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
+    HIP_TRY(launch_gram_band(c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, c->stream));
+    mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
+    HIP_TRY(launch_periods(c->beat.as<float>(), 1, LP, (int)T, p->period_lo, p->period_hi, period_slot, c->stream));
+    mark(c, "beat_period", 4.0 * T * hi, 0);
+    HIP_TRY(launch_mask_period(mask_args(c, g, p->cutoff_bins), period_slot, 0, c->stream));
+    mark(c, "mask_period", (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
+    RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, weighted, fade_in, fade_out));
+    c->last_T = T;
+    return REPET_OK;
+}
+
+int exec_original(repet_ctx* c, const repet_params* p) {
+    HIP_TRY(c->periods.ensure(sizeof(int32_t)));
+    RP_TRY(run_original(c, p, 0, c->n_samples, c->periods.as<int32_t>(), false, 0, 0));
+    c->last_n_periods = 1;
+    return REPET_OK;
+}
+
+int exec_extended(repet_ctx* c, const repet_params* p) {
+    const int64_t N = c->n_samples, L = p->seg_len_samples, Hs = p->seg_step_samples;
+    if (L <= 0 || Hs <= 0 || Hs > L) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step");
+    if (N < L + Hs) return exec_original(c, p);                    // repet.py:271
+    const int64_t count = 1 + (N - L) / Hs;                         // repet.py:279
+    const int64_t O = L - Hs;
+    HIP_TRY(c->periods.ensure((size_t)count * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
+    repet_timing* timing = c->timing;       // one "segments" stage instead of 5 marks per segment
+    c->timing = nullptr;
+    double bytes = 0, flops = 0;
+    for (int64_t j = 0; j < count; ++j) {
+        const int64_t start = j * Hs;
+        const int64_t len = (j < count - 1) ? L : N - start;        // repet.py:318-322
+        int rc = run_original(c, p, start, len, c->periods.as<int32_t>() + j, true, j > 0 ? O : 0, j < count - 1 ? O : 0);
+        if (rc != REPET_OK) { c->timing = timing; return rc; }
+        const double F = p->window_length / 2 + 1, T = (double)c->last_T, hi = std::min<double>(p->period_hi, c->last_T / 3);
+        bytes += 8.0 * len * c->n_channels + (12.0 + 24.0 + 12.0) * F * T * c->n_channels + 8.0 * F * T + 8.0 * T * hi;
+        flops += 2.0 * F * T * hi;
+    }
+    c->timing = timing;
+    mark(c, "extended_segments", bytes, flops);
+    c->last_n_periods = (int32_t)count;
+    return REPET_OK;
+}
+
+int exec_adaptive(repet_ctx* c, const repet_params* p) {
+    Tables* tb = nullptr;
+    RP_TRY(get_tables(c, p->window_length, &tb));
+    const int64_t N = c->n_samples;
+    const int64_t T = repet_frame_count(N, p->window_length, p->step_length, 1);
+    const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
+    const int Ls = p->seg_len_frames, Hs = p->seg_step_frames;
+    if (Ls <= 0 || Hs <= 0) return fail(REPET_ERR_BAD_ARG, "adaptive: bad segment length/step");
+    const int hi = std::min(p->period_hi, Ls / 3);
+    if (hi <= p->period_lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence (segment too short for the period range)");
+    if (p->filter_order < 1) return fail(REPET_ERR_BAD_ARG, "adaptive: filter_order must be >= 1");
+    RP_TRY(ensure_spectra(c, g, false, true));
+    RP_TRY(run_stft(c, g, tb, 0, N, 1, false, true));
+    const int LP = (int)round_up(hi, 64);
+    const int n_win = (int)ceil_div(T, Hs);
+    HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
+    HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
+    HIP_TRY(c->win_periods.ensure((size_t)n_win * sizeof(int32_t)));
+    HIP_TRY(c->periods.ensure((size_t)T * sizeof(int32_t)));
+    HIP_TRY(launch_gram_band(c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, c->stream));
+    mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
+    const int64_t left = (Ls - 1 + 1) / 2;    // ceil((Ls-1)/2), repet.py:1182
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, c->stream));
+    HIP_TRY(launch_periods(c->beat.as<float>(), n_win, LP, Ls, p->period_lo, p->period_hi, c->win_periods.as<int32_t>(), c->stream));
+    HIP_TRY(launch_expand_periods(c->win_periods.as<int32_t>(), n_win, Hs, T, p->period_lo, c->periods.as<int32_t>(), c->stream));
+    mark(c, "beat_periods", 4.0 * n_win * (double)Ls * hi, 0);
+    HIP_TRY(launch_mask_adaptive(mask_args(c, g, p->cutoff_bins), c->periods.as<int32_t>(), p->filter_order, c->stream));
+    mark(c, "mask_adaptive", (4.0 + 4.0 * p->filter_order + 16.0) * g.F * T * g.C, 0);
+    RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
+    c->last_T = T;
+    c->last_n_periods = (int32_t)T;
+    return REPET_OK;
+}
+
+int exec_sim(repet_ctx* c, const repet_params* p) {
+    Tables* tb = nullptr;
+    RP_TRY(get_tables(c, p->window_length, &tb));
+    const int64_t N = c->n_samples;
+    const int64_t T = repet_frame_count(N, p->window_length, p->step_length, 1);
+    const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
+    if (p->sim_number < 1) return fail(REPET_ERR_BAD_ARG, "similarity_number must be >= 1");
+    RP_TRY(ensure_spectra(c, g, true, false));
+    RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
+    const int64_t TS = round_up(T, 64);
+    HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
+    HIP_TRY(launch_gram_full(c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, c->stream));
+    mark(c, "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T, 2.0 * g.F * (double)T * T);
+    const int K = p->sim_number;
+    HIP_TRY(c->idx.ensure((size_t)T * K * sizeof(int32_t)));
+    HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
+    hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
+                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), c->stream);
+    if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
+    HIP_TRY(e);
+    mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), 0, c->stream));
+    mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
+    RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
+    c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = K;
+    return REPET_OK;
+}
+
+int exec_simonline(repet_ctx* c, const repet_params* p) {
+    Tables* tb = nullptr;
+    RP_TRY(get_tables(c, p->window_length, &tb));
+    const int64_t N = c->n_samples;
+    const int W = p->window_length, H = p->step_length, B = p->buffer_frames;
+    if (B < 1) return fail(REPET_ERR_BAD_ARG, "buffer length must be >= 1 frame");
+    if (N < (int64_t)(B - 2) * H + W)   // the warm-up slices B-1 whole frames (repet.py:795-810)
+        return fail(REPET_ERR_TOO_SHORT, "operands could not be broadcast together (signal shorter than the buffer)");
+    const int64_t T = repet_frame_count(N, W, H, 0);
+    const Geo g = make_geo(W, H, T, c->n_channels);
+    if (p->sim_number < 1) return fail(REPET_ERR_BAD_ARG, "similarity_number must be >= 1");
+    RP_TRY(ensure_spectra(c, g, true, false));
+    RP_TRY(run_stft(c, g, tb, 0, N, 0, true, false));
+    const int LP = (int)round_up(B, 64);
+    HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
+    HIP_TRY(launch_gram_band(c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, c->stream));
+    mark(c, "similarity_band", 4.0 * g.F * T + 4.0 * T * B, 2.0 * g.F * (double)T * B);
+    const int K = p->sim_number;
+    const int64_t rows = T >= B ? T - B + 1 : 0;
+    HIP_TRY(c->idx.ensure((size_t)std::max<int64_t>(rows, 1) * K * sizeof(int32_t)));
+    HIP_TRY(c->cnt.ensure((size_t)std::max<int64_t>(rows, 1) * sizeof(int32_t)));
+    hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
+                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), c->stream);
+    if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
+    HIP_TRY(e);
+    mark(c, "local_maxima", 4.0 * rows * B + 4.0 * K * rows, 0);
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), B - 1, c->stream));
+    mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
+    RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
+    c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = K;
+    return REPET_OK;
+}
+
+int check_params(const repet_params* p) {
+    if (!p) return fail(REPET_ERR_BAD_ARG, "params is null");
+    if (p->window_length < 64 || p->window_length > 8192 || (p->window_length & (p->window_length - 1)))
+        return fail(REPET_ERR_LIMIT, "window length must be a power of two in [64, 8192]");
+    if (p->step_length * 2 != p->window_length) return fail(REPET_ERR_BAD_ARG, "step length must be half the window length");
+    if (p->period_lo < 0 || p->cutoff_bins < 0 || p->sim_distance_frames < 0) return fail(REPET_ERR_BAD_ARG, "negative parameter");
+    return REPET_OK;
+}
+
+// copy a dense host matrix [rows][cols] into a pitched device matrix (pad columns zeroed)
+int h2d_pitched(repet_ctx* c, float* dst, int64_t dpitch, const float* src, int64_t rows, int64_t cols, int64_t rows_pad) {
+    HIP_TRY(hipMemsetAsync(dst, 0, (size_t)rows_pad * dpitch * sizeof(float), c->stream));
+    if (rows > 0)
+        HIP_TRY(hipMemcpy2DAsync(dst, dpitch * sizeof(float), src, cols * sizeof(float), cols * sizeof(float), rows,
+                                 hipMemcpyHostToDevice, c->stream));
+    return REPET_OK;
+}
+int d2h_pitched(repet_ctx* c, float* dst, const float* src, int64_t spitch, int64_t rows, int64_t cols) {
+    if (rows > 0)
+        HIP_TRY(hipMemcpy2DAsync(dst, cols * sizeof(float), src, spitch * sizeof(float), cols * sizeof(float), rows,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+thread_local std::map<int, repet_ctx*> g_thread_ctx;
+
+}  // namespace
+
+extern "C" {
+
+int repet_abi_version(void) { return REPET_ABI_VERSION; }
+
+int repet_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* repet_last_error(void) { return g_last_error.c_str(); }
+
+int64_t repet_frame_count(int64_t n, int32_t W, int32_t H, int32_t centred) {
+    if (H <= 0) return 0;
+    if (centred) {
+        const int64_t pad = W / 2;                                   // repet.py:1018
+        const int64_t num = n + 2 * pad - W;                         // repet.py:1024
+        const int64_t q = num >= 0 ? (num + H - 1) / H : -((-num) / H);
+        return q + 1;
+    }
+    const int64_t num = n - W;                                       // repet.py:781
+    const int64_t q = num >= 0 ? (num + H - 1) / H : -((-num) / H);
+    return q + 1;
+}
+
+int repet_ctx_create(int device, repet_ctx** out) {
+    if (!out) return fail(REPET_ERR_BAD_ARG, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(REPET_ERR_BAD_ARG, "no such device");
+    DeviceGuard guard(device);
+    auto* c = new repet_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(REPET_ERR_HIP, hipGetErrorString(e)); }
+    *out = c;
+    return REPET_OK;
+}
+
+int repet_ctx_destroy(repet_ctx* c) {
+    if (!c) return REPET_OK;
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->P, &c->S, &c->band, &c->beat,
+                      &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c})
+        b->release();
+    for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return REPET_OK;
+}
+
+int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int32_t ch) {
+    if (!c || !audio) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n < 0 || ch < 1) return fail(REPET_ERR_BAD_ARG, "audio_signal must be (number_samples, number_channels)");
+    if (dtype < REPET_F32 || dtype > REPET_I16) return fail(REPET_ERR_BAD_ARG, "unsupported dtype");
+    DeviceGuard guard(c->device);
+    const size_t esz = dtype == REPET_F64 ? 8 : (dtype == REPET_F32 ? 4 : 2);
+    const int64_t count = n * ch;
+    HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    if (dtype == REPET_F32) {
+        HIP_TRY(hipMemcpyAsync(c->audio.p, audio, (size_t)count * esz, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIP_TRY(c->staging.ensure(std::max<size_t>((size_t)count * esz, 256)));
+        HIP_TRY(hipMemcpyAsync(c->staging.p, audio, (size_t)count * esz, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_convert_in(c->staging.p, dtype, c->audio.as<float>(), count, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_samples = n;
+    c->n_channels = ch;
+    return REPET_OK;
+}
+
+int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timing* timing) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    RP_TRY(check_params(p));
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    DeviceGuard guard(c->device);
+    begin_timing(c, timing);
+    c->last_algo = algo;
+    c->last_n_periods = 0;
+    c->last_idx_rows = 0;
+    int rc;
+    switch (algo) {
+        case REPET_ORIGINAL: rc = exec_original(c, p); break;
+        case REPET_EXTENDED: rc = exec_extended(c, p); break;
+        case REPET_ADAPTIVE: rc = exec_adaptive(c, p); break;
+        case REPET_SIM: rc = exec_sim(c, p); break;
+        case REPET_SIMONLINE: rc = exec_simonline(c, p); break;
+        default: rc = fail(REPET_ERR_BAD_ARG, "unknown algorithm");
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
+    if (rc == REPET_OK) end_timing(c);
+    c->timing = nullptr;
+    return rc;
+}
+
+int repet_ctx_download(repet_ctx* c, double* out) {
+    if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    const int64_t count = c->n_samples * c->n_channels;
+    if (count == 0) return REPET_OK;
+    HIP_TRY(c->out64.ensure((size_t)count * sizeof(double)));
+    HIP_TRY(launch_convert_out(c->out.as<float>(), c->out64.as<double>(), count, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->out64.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+static int thread_ctx(int device, repet_ctx** out) {
+    auto it = g_thread_ctx.find(device);
+    if (it != g_thread_ctx.end()) { *out = it->second; return REPET_OK; }
+    repet_ctx* c = nullptr;
+    RP_TRY(repet_ctx_create(device, &c));
+    g_thread_ctx[device] = c;
+    *out = c;
+    return REPET_OK;
+}
+
+int repet_run(int algo, const void* audio, int dtype, int64_t n, int32_t ch, const repet_params* p, double* out,
+              int device, repet_timing* timing) {
+    repet_ctx* c = nullptr;
+    RP_TRY(thread_ctx(device, &c));
+    RP_TRY(repet_ctx_upload(c, audio, dtype, n, ch));
+    RP_TRY(repet_ctx_execute(c, algo, p, timing));
+    return repet_ctx_download(c, out);
+}
+
+int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
+                    const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {
+    if (n_clips < 0 || (n_clips > 0 && (!audio || !n_samples || !n_channels || !out)))
+        return fail(REPET_ERR_BAD_ARG, "null argument");
+    int avail = repet_device_count();
+    if (n_devices < 1 || n_devices > avail) return fail(REPET_ERR_BAD_ARG, "n_devices out of range");
+    // longest first, dealt round-robin: clip order[i] -> device i % n_devices
+    std::vector<int> order(n_clips);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
+    std::vector<int> rcs(n_devices, REPET_OK);
+    std::vector<std::string> msgs(n_devices);
+    auto worker = [&](int dev) {
+        repet_ctx* c = nullptr;
+        int rc = repet_ctx_create(dev, &c);
+        for (int i = dev; rc == REPET_OK && i < n_clips; i += n_devices) {
+            const int k = order[i];
+            rc = repet_ctx_upload(c, audio[k], dtype, n_samples[k], n_channels[k]);
+            if (rc == REPET_OK) rc = repet_ctx_execute(c, algo, p, nullptr);
+            if (rc == REPET_OK) rc = repet_ctx_download(c, out[k]);
+        }
+        if (rc != REPET_OK) msgs[dev] = g_last_error;
+        rcs[dev] = rc;
+        repet_ctx_destroy(c);
+    };
+    if (n_devices == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_devices; ++d) th.emplace_back(worker, d);
+        for (auto& t : th) t.join();
+    }
+    for (int d = 0; d < n_devices; ++d)
+        if (rcs[d] != REPET_OK) return fail(rcs[d], msgs[d]);
+    return REPET_OK;
+}
+
+// ---- stage-level exports ---------------------------------------------------------------------------
+
+int repet_stft(repet_ctx* c, const float* x, int64_t n, const float* window, int32_t W, int32_t H, int32_t centred,
+               float* spec_out, int64_t n_frames) {
+    if (!c || !x || !window || !spec_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (H < 1) return fail(REPET_ERR_BAD_ARG, "step length must be >= 1");
+    DeviceGuard guard(c->device);
+    const float2* tw = nullptr;
+    RP_TRY(upload_twiddle_only(c, W, &tw));
+    const int64_t T = repet_frame_count(n, W, H, centred);
+    if (T != n_frames) return fail(REPET_ERR_BAD_ARG, "n_frames does not match repet_frame_count");
+    const Geo g = make_geo(W, H, T, 1);
+    HIP_TRY(c->tmp_a.ensure(std::max<size_t>((size_t)n * sizeof(float), 256)));
+    HIP_TRY(c->tmp_b.ensure((size_t)W * sizeof(float)));
+    HIP_TRY(c->X.ensure((size_t)g.chan_stride * sizeof(float2)));
+    HIP_TRY(c->V.ensure((size_t)g.chan_stride * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->tmp_a.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tmp_b.p, window, (size_t)W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    StftArgs a{};
+    a.audio = c->tmp_a.as<float>(); a.n_samples = n; a.n_channels = 1; a.sample_offset = 0;
+    a.window = c->tmp_b.as<float>(); a.twiddle = tw; a.W = W; a.H = H; a.T = T; a.FS = g.FS; a.centred = centred;
+    a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
+    HIP_TRY(launch_stft(a, c->stream));
+    if (T > 0)
+        HIP_TRY(hipMemcpy2DAsync(spec_out, (size_t)g.F * sizeof(float2), c->X.p, (size_t)g.FS * sizeof(float2),
+                                 (size_t)g.F * sizeof(float2), T, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+int repet_istft(repet_ctx* c, const float* spec, int64_t T, const float* window, int32_t W, int32_t H, float* y_out,
+                int64_t n_out) {
+    if (!c || !spec || !window || !y_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (H < 1 || H > W) return fail(REPET_ERR_BAD_ARG, "bad step length");
+    DeviceGuard guard(c->device);
+    const float2* tw = nullptr;
+    RP_TRY(upload_twiddle_only(c, W, &tw));
+    const int64_t want = T * H - (W - H);                           // repet.py:1079,1098
+    if (n_out != want) return fail(REPET_ERR_BAD_ARG, "n_out must be T*H - (W-H)");
+    const Geo g = make_geo(W, H, T, 1);
+    HIP_TRY(c->X.ensure((size_t)g.chan_stride * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(c->X.p, 0, (size_t)g.chan_stride * sizeof(float2), c->stream));
+    HIP_TRY(hipMemcpy2DAsync(c->X.p, (size_t)g.FS * sizeof(float2), spec, (size_t)g.F * sizeof(float2),
+                             (size_t)g.F * sizeof(float2), T, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->frames.ensure((size_t)T * W * sizeof(float)));
+    HIP_TRY(c->tmp_a.ensure(std::max<size_t>((size_t)n_out * sizeof(float), 256)));
+    IstftArgs ia{};
+    ia.Y = c->X.as<float2>(); ia.chan_stride = g.chan_stride; ia.n_channels = 1; ia.T = T; ia.FS = g.FS; ia.W = W;
+    ia.twiddle = tw; ia.frames = c->frames.as<float>();
+    HIP_TRY(launch_istft_frames(ia, c->stream));
+    double cola = 0;
+    for (int i = 0; i < W; i += H) cola += window[i];
+    OlaArgs oa{};
+    oa.frames = c->frames.as<float>(); oa.n_channels = 1; oa.T = T; oa.W = W; oa.H = H; oa.trim = W - H;
+    oa.out = c->tmp_a.as<float>(); oa.n_out = n_out; oa.out_offset = 0; oa.scale = (float)(1.0 / cola);
+    HIP_TRY(launch_overlap_add(oa, c->stream));
+    HIP_TRY(hipMemcpyAsync(y_out, c->tmp_a.p, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+static int stage_matrix_in(repet_ctx* c, DevBuf& buf, const float* host, int64_t T, int F, int FS, int64_t Tpad) {
+    HIP_TRY(buf.ensure((size_t)Tpad * FS * sizeof(float)));
+    return h2d_pitched(c, buf.as<float>(), FS, host, T, F, Tpad);
+}
+
+int repet_selfsim(repet_ctx* c, const float* v, int64_t T, int32_t F, float* s_out) {
+    if (!c || !v || !s_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    const int FS = (int)round_up(F, kFreqAlign);
+    const int64_t Tpad = round_up(T, kTile), TS = round_up(T, 64);
+    HIP_TRY(c->tmp_a.ensure((size_t)T * F * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->tmp_a.p, v, (size_t)T * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->Vn.ensure((size_t)Tpad * FS * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->Vn.p, 0, (size_t)Tpad * FS * sizeof(float), c->stream));
+    HIP_TRY(launch_unit_rows(c->tmp_a.as<float>(), c->Vn.as<float>(), T, F, FS, c->stream));
+    HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
+    HIP_TRY(launch_gram_full(c->Vn.as<float>(), T, FS, c->S.as<float>(), TS, c->stream));
+    return d2h_pitched(c, s_out, c->S.as<float>(), TS, T, T);
+}
+
+int repet_beat_spectrum(repet_ctx* c, const float* p, int64_t T, int32_t F, float* beat_out, int32_t n_lags) {
+    if (!c || !p || !beat_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n_lags < 1 || n_lags > T) return fail(REPET_ERR_BAD_ARG, "n_lags must be in [1, T]");
+    DeviceGuard guard(c->device);
+    const int FS = (int)round_up(F, kFreqAlign);
+    const int64_t Tpad = round_up(T, kTile);
+    const int LP = (int)round_up(n_lags, 64);
+    RP_TRY(stage_matrix_in(c, c->P, p, T, F, FS, Tpad));
+    HIP_TRY(c->band.ensure((size_t)Tpad * LP * sizeof(float)));
+    HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
+    HIP_TRY(launch_gram_band(c->P.as<float>(), T, FS, c->band.as<float>(), n_lags, LP, c->stream));
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, n_lags, F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
+    return d2h_pitched(c, beat_out, c->beat.as<float>(), LP, 1, n_lags);
+}
+
+int repet_beat_spectrogram(repet_ctx* c, const float* p, int64_t T, int32_t F, int32_t Ls, int32_t Hs, float* beat_out) {
+    if (!c || !p || !beat_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (Ls < 1 || Hs < 1) return fail(REPET_ERR_BAD_ARG, "bad segment length/step");
+    DeviceGuard guard(c->device);
+    const int FS = (int)round_up(F, kFreqAlign);
+    const int64_t Tpad = round_up(T, kTile);
+    const int LP = (int)round_up(Ls, 64);
+    const int n_win = (int)ceil_div(T, Hs);
+    RP_TRY(stage_matrix_in(c, c->P, p, T, F, FS, Tpad));
+    HIP_TRY(c->band.ensure((size_t)Tpad * LP * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->band.p, 0, (size_t)Tpad * LP * sizeof(float), c->stream));
+    HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
+    HIP_TRY(launch_gram_band(c->P.as<float>(), T, FS, c->band.as<float>(), Ls, LP, c->stream));
+    const int64_t left = Ls / 2;                                     // ceil((Ls-1)/2)
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, Ls, F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, c->stream));
+    std::vector<float> win((size_t)n_win * Ls);
+    RP_TRY(d2h_pitched(c, win.data(), c->beat.as<float>(), LP, n_win, Ls));
+    // replicate with the reference's hole (repet.py:1194-1204): frame i+Hs-1 of each step stays zero
+    std::memset(beat_out, 0, (size_t)T * Ls * sizeof(float));
+    for (int w = 0; w < n_win; ++w) {
+        const int64_t i = (int64_t)w * Hs;
+        const int64_t end = std::min<int64_t>(i + Hs - 1, T);
+        std::memcpy(beat_out + i * Ls, win.data() + (size_t)w * Ls, (size_t)Ls * sizeof(float));
+        for (int64_t t = i; t < end; ++t) std::memcpy(beat_out + t * Ls, win.data() + (size_t)w * Ls, (size_t)Ls * sizeof(float));
+    }
+    return REPET_OK;
+}
+
+int repet_periods(repet_ctx* c, const float* beat, int32_t n_cols, int32_t n_lags, int32_t lo, int32_t hi, int32_t* out) {
+    if (!c || !beat || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (std::min(hi, n_lags / 3) <= lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c->beat.ensure((size_t)n_cols * n_lags * sizeof(float)));
+    HIP_TRY(c->periods.ensure((size_t)n_cols * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(c->beat.p, beat, (size_t)n_cols * n_lags * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_periods(c->beat.as<float>(), n_cols, n_lags, n_lags, lo, hi, c->periods.as<int32_t>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->periods.p, (size_t)n_cols * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+int repet_local_maxima(repet_ctx* c, const float* m, int32_t n_rows, int32_t n_cols, float min_value, int32_t d,
+                       int32_t number, int32_t* idx_out, int32_t* count_out) {
+    if (!c || !m || !idx_out || !count_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n_rows < 1 || n_cols < 1 || number < 1 || d < 0) return fail(REPET_ERR_BAD_ARG, "bad size");
+    DeviceGuard guard(c->device);
+    const int64_t pitch = round_up(n_cols, 4);
+    HIP_TRY(c->S.ensure((size_t)n_rows * pitch * sizeof(float)));
+    RP_TRY(h2d_pitched(c, c->S.as<float>(), pitch, m, n_rows, n_cols, n_rows));
+    HIP_TRY(c->idx.ensure((size_t)n_rows * number * sizeof(int32_t)));
+    HIP_TRY(c->cnt.ensure((size_t)n_rows * sizeof(int32_t)));
+    hipError_t e = launch_local_maxima(c->S.as<float>(), n_rows, 0, n_cols, pitch, 0, min_value, d, number,
+                                       c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), c->stream);
+    if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "row too long for the peak-picking kernel");
+    HIP_TRY(e);
+    HIP_TRY(hipMemcpyAsync(idx_out, c->idx.p, (size_t)n_rows * number * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(count_out, c->cnt.p, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+static int stage_mask_common(repet_ctx* c, const float* v, int64_t T, int F, MaskArgs* m, int* FS_out) {
+    const int FS = (int)round_up(F, kFreqAlign);
+    RP_TRY(stage_matrix_in(c, c->V, v, T, F, FS, T));
+    HIP_TRY(c->tmp_c.ensure((size_t)T * FS * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->tmp_c.p, 0, (size_t)T * FS * sizeof(float), c->stream));
+    *m = MaskArgs{};
+    m->V = c->V.as<float>(); m->chan_stride = T * FS; m->n_channels = 1; m->T = T; m->F = F; m->FS = FS;
+    m->X = nullptr; m->mask = c->tmp_c.as<float>(); m->cutoff = 0;
+    *FS_out = FS;
+    return REPET_OK;
+}
+
+int repet_mask_period(repet_ctx* c, const float* v, int64_t T, int32_t F, int32_t period, float* mask_out) {
+    if (!c || !v || !mask_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (period < 1) return fail(REPET_ERR_BAD_ARG, "period must be >= 1");
+    DeviceGuard guard(c->device);
+    MaskArgs m; int FS;
+    RP_TRY(stage_mask_common(c, v, T, F, &m, &FS));
+    HIP_TRY(launch_mask_period(m, nullptr, period, c->stream));
+    return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
+}
+
+int repet_mask_adaptive(repet_ctx* c, const float* v, int64_t T, int32_t F, const int32_t* periods, int32_t order,
+                        float* mask_out) {
+    if (!c || !v || !periods || !mask_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (order < 1) return fail(REPET_ERR_BAD_ARG, "filter_order must be >= 1");
+    DeviceGuard guard(c->device);
+    MaskArgs m; int FS;
+    RP_TRY(stage_mask_common(c, v, T, F, &m, &FS));
+    HIP_TRY(c->periods.ensure((size_t)T * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(c->periods.p, periods, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_mask_adaptive(m, c->periods.as<int32_t>(), order, c->stream));
+    return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
+}
+
+int repet_mask_sim(repet_ctx* c, const float* v, int64_t T, int32_t F, const int32_t* idx, const int32_t* count,
+                   int32_t number, float* mask_out) {
+    if (!c || !v || !idx || !count || !mask_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    MaskArgs m; int FS;
+    RP_TRY(stage_mask_common(c, v, T, F, &m, &FS));
+    HIP_TRY(c->idx.ensure((size_t)T * number * sizeof(int32_t)));
+    HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(c->idx.p, idx, (size_t)T * number * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->cnt.p, count, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), 0, c->stream));
+    return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
+}
+
+int repet_ctx_last_periods(repet_ctx* c, int32_t* out, int32_t capacity, int32_t* n_written) {
+    if (!c || !out || !n_written) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    const int n = std::min(capacity, c->last_n_periods);
+    if (n > 0) HIP_TRY(hipMemcpy(out, c->periods.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n_written = n;
+    return REPET_OK;
+}
+
+int repet_ctx_last_sim_indices(repet_ctx* c, int32_t* idx_out, int32_t* count_out, int32_t n_rows, int32_t number) {
+    if (!c || !idx_out || !count_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n_rows != c->last_idx_rows || number != c->last_idx_pitch) return fail(REPET_ERR_BAD_ARG, "shape does not match the last run");
+    DeviceGuard guard(c->device);
+    if (n_rows > 0) {
+        HIP_TRY(hipMemcpy(idx_out, c->idx.p, (size_t)n_rows * number * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(count_out, c->cnt.p, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return REPET_OK;
+}
+
+int repet_ctx_last_frame_count(repet_ctx* c, int64_t* n_frames) {
+    if (!c || !n_frames) return fail(REPET_ERR_BAD_ARG, "null argument");
+    *n_frames = c->last_T;
+    return REPET_OK;
+}
+
+}  // extern "C"

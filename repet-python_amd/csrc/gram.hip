@@ -1,0 +1,281 @@
+// K3 / K3b / K6: Gram matrix A A^T of a frame-major spectrogram A[Tpad][FS] in exact fp32 on the
+// matrix cores (v_mfma_f32_32x32x2_f32), for
+//   * the cosine self-similarity matrix of REPET-SIM        (repet.py:1223, np.matmul(Vn.T, Vn))
+//   * the banded similarity of the online variant            (repet.py:1244, one column per frame)
+//   * the beat spectrum as diagonal sums of the Gram of V^2  (repet.py:1108-1158, autocorrelation)
+//
+// Tile 128x128 per 256-thread workgroup (2x2 waves, each 2x2 MFMA tiles of 32x32), BK = 32, register
+// prefetch of the next K-tile and a double-buffered padded LDS image (pitch 36 floats: the 16-lane
+// groups of ds_read_b128 then cover all 64 banks). Both operands are row panels of the same matrix,
+// so A-tile and B-tile loads are identical and coalesce on 128-byte row chunks.
+// Only tiles on or above the diagonal are computed; the full variant mirrors them through LDS.
+#include "common.h"
+
+namespace repet {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDP = BK + 4;                     // LDS row pitch in floats
+constexpr int TILE_FLOATS = kTile * LDP;        // one operand tile in LDS
+constexpr int kGramLds = 4 * TILE_FLOATS * 4;   // 2 operands x 2 buffers, bytes (73,728)
+
+enum GramMode { GRAM_FULL = 0, GRAM_BAND = 1 };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ A, int64_t T, int FS,
+                                                      float* __restrict__ out, int64_t pitch, int n_lags) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int bi = blockIdx.x;
+    const int bj = (MODE == GRAM_FULL) ? (int)blockIdx.y : bi + (int)blockIdx.y;
+    const int nb = gridDim.x;
+    if (bj < bi || bj >= nb) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const float* Ag = A + (int64_t)bi * kTile * FS;
+    const float* Bg = A + (int64_t)bj * kTile * FS;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // staging: 128 rows x 8 float4 per operand tile = 1024 float4, 4 per thread
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            const int row = q >> 3, c4 = q & 7;
+            const int64_t off = (int64_t)row * FS + kt * BK + c4 * 4;
+            ra[i] = *reinterpret_cast<const float4*>(Ag + off);
+            rb[i] = *reinterpret_cast<const float4*>(Bg + off);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = lds + buf * 2 * TILE_FLOATS;
+        float* Bs = As + TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            const int row = q >> 3, c4 = q & 7;
+            *reinterpret_cast<float4*>(As + row * LDP + c4 * 4) = ra[i];
+            *reinterpret_cast<float4*>(Bs + row * LDP + c4 * 4) = rb[i];
+        }
+    };
+
+    const int nk = FS / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* As = lds + cur * 2 * TILE_FLOATS + (wr * 64 + lr) * LDP + 4 * lh;
+        const float* Bs = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + (wc * 64 + lr) * LDP + 4 * lh;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            const float4 a0 = *reinterpret_cast<const float4*>(As + ks * 8);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDP + ks * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(Bs + ks * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(Bs + 32 * LDP + ks * 8);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[n][q], acc[m][n], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
+    const int64_t gi0 = (int64_t)bi * kTile + wr * 64;
+    const int64_t gj0 = (int64_t)bj * kTile + wc * 64;
+    if (MODE == GRAM_FULL) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t gi = gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int64_t gj = gj0 + n * 32 + lr;
+                    if (gi < T && gj < T) out[gi * pitch + gj] = acc[m][n][r];
+                }
+        if (bi != bj) {
+            // mirror: transpose this wave's 64x64 block through a private LDS patch (pitch 65)
+            float* patch = lds + wave * (64 * 65);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int j = n * 32 + lr;
+                        patch[j * 65 + i] = acc[m][n][r];
+                    }
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the patch is wave-private
+            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < 64; ++j) {
+                const int64_t gj = gj0 + j, gi = gi0 + lane;
+                if (gj < T && gi < T) out[gj * pitch + gi] = patch[j * 65 + lane];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t gi = gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int64_t gj = gj0 + n * 32 + lr;
+                    const int64_t lag = gj - gi;
+                    if (gi < T && gj < T && lag >= 0 && lag < n_lags) out[gi * pitch + lag] = acc[m][n][r];
+                }
+    }
+}
+
+static hipError_t set_lds(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds);
+}
+
+hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    static hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_FULL>));
+    if (attr != hipSuccess) return attr;
+    const unsigned nb = (unsigned)ceil_div(T, kTile);
+    hipLaunchKernelGGL(gram_kernel<GRAM_FULL>, dim3(nb, nb), dim3(256), kGramLds, s, A, T, FS, S, TS, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
+                            hipStream_t s) {
+    if (T <= 0 || n_lags <= 0) return hipSuccess;
+    static hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_BAND>));
+    if (attr != hipSuccess) return attr;
+    const unsigned nb = (unsigned)ceil_div(T, kTile);
+    unsigned ndiag = (unsigned)((n_lags + 126) / kTile + 1);
+    if (ndiag > nb) ndiag = nb;
+    hipLaunchKernelGGL(gram_kernel<GRAM_BAND>, dim3(nb, ndiag), dim3(256), kGramLds, s, A, T, FS, band,
+                       (int64_t)LP, n_lags);
+    return hipGetLastError();
+}
+
+// ---- windowed diagonal sums of the band (beat spectrum / beat spectrogram) -------------------------
+// One workgroup per (window, 64-lag block); the window's rows are split over 4 waves and reduced in
+// a fixed order, so the result is bitwise reproducible.
+__global__ __launch_bounds__(256) void band_window_sum_kernel(const float* __restrict__ band, int64_t T, int LP,
+                                                              int n_lags, int n_freq, int64_t start0,
+                                                              int64_t step, int64_t len, float* beat,
+                                                              int beat_pitch) {
+    __shared__ float part[4][64];
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = blockIdx.x * 64 + lane;
+    const int64_t a = start0 + w * step;             // first frame of the window (may be < 0)
+    int64_t lo = a < 0 ? 0 : a;
+    int64_t hi = a + len - 1 - l;                    // last t with t + l inside the window
+    if (hi > T - 1 - l) hi = T - 1 - l;
+    float sum = 0.f;
+    if (l < n_lags && l < len) {
+        const int64_t rows = hi - lo + 1;
+        if (rows > 0) {
+            const int64_t chunk = ceil_div(rows, 4);
+            const int64_t t0 = lo + wave * chunk;
+            int64_t t1 = t0 + chunk;
+            if (t1 > hi + 1) t1 = hi + 1;
+            for (int64_t t = t0; t < t1; ++t) sum += band[t * LP + l];
+        }
+    }
+    part[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && l < n_lags) {
+        const float total = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        // unbiased by the window length minus the lag (repet.py:1135-1137), mean over F (repet.py:1156)
+        beat[(int64_t)w * beat_pitch + l] = (l < len) ? total / ((float)(len - l) * (float)n_freq) : 0.f;
+    }
+}
+
+hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,
+                                  int64_t start0, int64_t step, int64_t len, int32_t n_windows, float* beat,
+                                  int32_t beat_pitch, hipStream_t s) {
+    if (n_windows <= 0 || n_lags <= 0) return hipSuccess;
+    hipLaunchKernelGGL(band_window_sum_kernel, dim3((unsigned)ceil_div(n_lags, 64), (unsigned)n_windows),
+                       dim3(256), 0, s, band, T, LP, n_lags, n_freq, start0, step, len, beat, beat_pitch);
+    return hipGetLastError();
+}
+
+// ---- K7: period = argmax(beat[lo:hi]) + 1 + lo, first maximum wins (repet.py:1263-1289) ------------
+__global__ __launch_bounds__(64) void periods_kernel(const float* __restrict__ beat, int pitch, int lo, int hi,
+                                                     int* period) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float* b = beat + (int64_t)c * pitch;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    bool has_nan = false;
+    int nan_at = 0x7fffffff;
+    for (int l = lo + lane; l < hi; l += 64) {
+        const float v = b[l];
+        if (v != v) { if (!has_nan) { has_nan = true; nan_at = l; } continue; }
+        if (v > best) { best = v; arg = l; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off);
+        const int oa = __shfl_down(arg, off);
+        const int on = __shfl_down(nan_at, off);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        if (on < nan_at) nan_at = on;
+    }
+    if (lane == 0) {
+        // np.argmax returns the first NaN if any is present
+        if (nan_at != 0x7fffffff) arg = nan_at;
+        if (arg == 0x7fffffff) arg = lo;      // all -inf cannot happen; keep defined
+        period[c] = (arg - lo) + 1 + lo;
+    }
+}
+
+hipError_t launch_periods(const float* beat, int32_t n_cols, int32_t pitch, int32_t n_lags, int32_t lo,
+                          int32_t hi, int32_t* period, hipStream_t s) {
+    if (n_cols <= 0) return hipSuccess;
+    int h = hi < n_lags / 3 ? hi : n_lags / 3;
+    hipLaunchKernelGGL(periods_kernel, dim3((unsigned)n_cols), dim3(64), 0, s, beat, pitch, lo, h, period);
+    return hipGetLastError();
+}
+
+__global__ void expand_periods_kernel(const int* win_period, int n_windows, int step, int64_t T, int lo,
+                                      int* frame_period) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int w = (int)(t / step);
+    const int64_t i = (int64_t)w * step;
+    // columns i .. min(i+step-1, T)-1 copy window w; column i+step-1 keeps zeros -> argmax 0 -> lo+1
+    const int64_t end = (i + step - 1 < T) ? i + step - 1 : T;
+    int p = (t < end || t == i) ? win_period[w] : lo + 1;
+    frame_period[t] = p;
+}
+
+hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, int32_t step, int64_t T,
+                                 int32_t lo, int32_t* frame_period, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_periods_kernel, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, s, win_period,
+                       n_windows, step, T, lo, frame_period);
+    return hipGetLastError();
+}
+
+}  // namespace repet

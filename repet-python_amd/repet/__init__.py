@@ -1,0 +1,311 @@
+"""repet -- MI355X-native REPET (REpeating Pattern Extraction Technique), drop-in for zafarrafii/REPET-Python.
+
+Same call surface as the reference module ``repet.py``::
+
+    background_signal = repet.original(audio_signal, sampling_frequency)    # repet.py:67
+    background_signal = repet.extended(audio_signal, sampling_frequency)    # repet.py:205
+    background_signal = repet.adaptive(audio_signal, sampling_frequency)    # repet.py:422
+    background_signal = repet.sim(audio_signal, sampling_frequency)         # repet.py:571
+    background_signal = repet.simonline(audio_signal, sampling_frequency)   # repet.py:712
+
+``audio_signal`` is ``(number_samples, number_channels)``; the result is a fresh float64 array of the
+same shape. The nine module-level parameters below have the reference's names and defaults
+(repet.py:42-63) and are read at call time, so ``repet.period_range = [1, 5]`` before a call behaves as
+it does there. All arithmetic runs in hand-written HIP kernels for gfx950 behind ``librepet_hip.so``
+(``include/repet_hip.h``); this module only validates, derives the integer sizes with the reference's
+own rounding rules, and crosses the C ABI. There is no NumPy/CPU implementation of the separation
+path here: without the library or a GPU the calls raise.
+"""
+import numpy as np
+
+from . import _native
+from ._native import Context  # noqa: F401  (device-resident API used by bench.py)
+
+# ---- public parameters (repet.py:42-63) ----------------------------------------------------------------
+cutoff_frequency = 100
+period_range = [1, 10]
+segment_length = 10
+segment_step = 5
+filter_order = 5
+similarity_threshold = 0
+similarity_distance = 1
+similarity_number = 100
+buffer_length = 10
+
+_device = 0  # HIP device used by the one-shot calls
+
+
+def set_device(index):
+    """Select the HIP device for subsequent calls (the reference has no such notion)."""
+    global _device
+    _device = int(index)
+
+
+# ---- sizes derived exactly as the reference derives them ---------------------------------------------------
+def _window_length(sampling_frequency):
+    return pow(2, int(np.ceil(np.log2(0.04 * sampling_frequency))))  # repet.py:130
+
+
+def derive_params(sampling_frequency):
+    """Snapshot the module parameters into the integer ``repet_params`` of the C ABI.
+
+    Python ``round`` and ``np.round`` are half-to-even; every expression below is the one the reference
+    evaluates (line cited), so e.g. an 8 kHz clip gets a 312-frame online buffer (``round(312.5)``).
+    """
+    fs = sampling_frequency
+    w = _window_length(fs)
+    h = int(w / 2)                                                            # repet.py:132
+    pr = np.round(np.array(period_range) * fs / h).astype(int)                # repet.py:165
+    p = _native.Params()
+    p.window_length = w
+    p.step_length = h
+    p.period_lo = int(pr[0])
+    p.period_hi = int(pr[1])
+    p.cutoff_bins = int(round(cutoff_frequency * w / fs))                     # repet.py:173
+    p.filter_order = int(filter_order)
+    p.seg_len_frames = int(round(segment_length * fs / h))                    # repet.py:519
+    p.seg_step_frames = int(round(segment_step * fs / h))                     # repet.py:520
+    p.sim_distance_frames = int(round(similarity_distance * fs / h))          # repet.py:670
+    p.sim_number = int(similarity_number)
+    p.buffer_frames = int(round((buffer_length * fs) / h))                    # repet.py:787
+    p.seg_len_samples = int(round(segment_length * fs))                       # repet.py:266
+    p.seg_step_samples = int(round(segment_step * fs))                        # repet.py:267
+    p.sim_threshold = float(similarity_threshold)
+    return p
+
+
+def _separate(algo, audio_signal, sampling_frequency):
+    number_samples, number_channels = np.shape(audio_signal)   # 1-D input: ValueError, like repet.py:125
+    params = derive_params(sampling_frequency)
+    signal, code = _native.as_input(audio_signal)
+    background_signal = np.empty((number_samples, number_channels), dtype=np.float64)
+    lib = _native.lib()
+    if lib.repet_device_count() < 1:
+        raise RuntimeError("no HIP device visible: the REPET engine has no CPU fallback")
+    _native.check(lib.repet_run(_native.ALGO_IDS[algo], _native.ptr(signal), code, number_samples,
+                                number_channels, params, _native.ptr(background_signal), _device, None))
+    return background_signal
+
+
+def original(audio_signal, sampling_frequency):
+    """Original REPET: one repeating period, period-median model (repet.py:67-202)."""
+    return _separate("original", audio_signal, sampling_frequency)
+
+
+def extended(audio_signal, sampling_frequency):
+    """REPET extended: ``original`` on 10-s segments with triangular cross-fades (repet.py:205-419)."""
+    return _separate("extended", audio_signal, sampling_frequency)
+
+
+def adaptive(audio_signal, sampling_frequency):
+    """Adaptive REPET: time-varying period from a beat spectrogram (repet.py:422-568)."""
+    return _separate("adaptive", audio_signal, sampling_frequency)
+
+
+def sim(audio_signal, sampling_frequency):
+    """REPET-SIM: repeating frames found through the cosine self-similarity matrix (repet.py:571-709)."""
+    return _separate("sim", audio_signal, sampling_frequency)
+
+
+def simonline(audio_signal, sampling_frequency):
+    """Online REPET-SIM over a circular buffer of past frames (repet.py:712-911)."""
+    return _separate("simonline", audio_signal, sampling_frequency)
+
+
+def run_batch(algo, audio_signals, sampling_frequency, n_devices=1):
+    """Separate a list of independent clips, dealt longest-first over ``n_devices`` GPUs of this process."""
+    import ctypes as C
+    params = derive_params(sampling_frequency)
+    ins, outs, ns, cs, code = [], [], [], [], None
+    for a in audio_signals:
+        n, c = np.shape(a)
+        arr, k = _native.as_input(a)
+        if code is None:
+            code = k
+        elif k != code:
+            arr, k = np.ascontiguousarray(arr, dtype=np.float64), _native.F64
+            if code != _native.F64:
+                ins = [np.ascontiguousarray(x, dtype=np.float64) for x in ins]
+                code = _native.F64
+        ins.append(arr)
+        outs.append(np.empty((n, c), dtype=np.float64))
+        ns.append(n)
+        cs.append(c)
+    count = len(ins)
+    in_ptrs = (C.c_void_p * count)(*[x.ctypes.data for x in ins])
+    out_ptrs = (C.c_void_p * count)(*[x.ctypes.data for x in outs])
+    _native.check(_native.lib().repet_run_batch(
+        _native.ALGO_IDS[algo], count, in_ptrs, code if code is not None else _native.F64,
+        (C.c_int64 * count)(*ns), (C.c_int32 * count)(*cs), params, out_ptrs, int(n_devices)))
+    return outs
+
+
+# ---- private helpers of the reference, kept callable (README.md:79 uses repet._stft) -----------------------
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _stft(audio_signal, window_function, step_length):
+    """STFT of one channel, ``(window_length, number_frames)`` complex with all bins (repet.py:1001-1060)."""
+    x = _f32(audio_signal)
+    window = _f32(window_function)
+    w = len(window)
+    lib = _native.lib()
+    t = lib.repet_frame_count(len(x), w, int(step_length), 1)
+    f = w // 2 + 1
+    spec = np.empty((t, f, 2), dtype=np.float32)
+    _native.check(lib.repet_stft(_native.default_context(_device).handle, _native.ptr(x), len(x),
+                                 _native.ptr(window), w, int(step_length), 1, _native.ptr(spec), t))
+    half = (spec[..., 0] + 1j * spec[..., 1]).astype(complex).T          # (F, T)
+    return np.concatenate((half, np.conj(half[-2:0:-1])), axis=0)
+
+
+def _istft(audio_stft, window_function, step_length):
+    """Inverse STFT by overlap-add (repet.py:1063-1105); the mirrored bins are implied by the first half."""
+    window = _f32(window_function)
+    w, t = np.shape(audio_stft)
+    f = w // 2 + 1
+    half = np.ascontiguousarray(np.asarray(audio_stft)[:f].T)
+    spec = np.empty((t, f, 2), dtype=np.float32)
+    spec[..., 0] = half.real
+    spec[..., 1] = half.imag
+    n_out = t * int(step_length) - (w - int(step_length))
+    y = np.empty(n_out, dtype=np.float32)
+    _native.check(_native.lib().repet_istft(_native.default_context(_device).handle, _native.ptr(spec), t,
+                                            _native.ptr(window), w, int(step_length), _native.ptr(y), n_out))
+    return y.astype(np.float64)
+
+
+def _selfsimilaritymatrix(data_matrix):
+    """Cosine self-similarity between the columns (repet.py:1209-1225)."""
+    rows = _f32(np.asarray(data_matrix).T)
+    t, f = rows.shape
+    s = np.empty((t, t), dtype=np.float32)
+    _native.check(_native.lib().repet_selfsim(_native.default_context(_device).handle, _native.ptr(rows), t, f,
+                                              _native.ptr(s)))
+    return s.astype(np.float64)
+
+
+def _beatspectrum(audio_spectrogram):
+    """Beat spectrum of an (already squared) spectrogram (repet.py:1142-1158)."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    beat = np.empty(t, dtype=np.float32)
+    _native.check(_native.lib().repet_beat_spectrum(_native.default_context(_device).handle, _native.ptr(rows),
+                                                    t, f, _native.ptr(beat), t))
+    return beat.astype(np.float64)
+
+
+def _beatspectrogram(audio_spectrogram, segment_length, segment_step):
+    """Sliding beat spectrum, ``(segment_length, number_times)`` (repet.py:1161-1206)."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    out = np.empty((t, int(segment_length)), dtype=np.float32)
+    _native.check(_native.lib().repet_beat_spectrogram(_native.default_context(_device).handle,
+                                                       _native.ptr(rows), t, f, int(segment_length),
+                                                       int(segment_step), _native.ptr(out)))
+    return out.T.astype(np.float64)
+
+
+def _periods(beat_spectrogram, period_range):
+    """Repeating period(s): arg-max lag + 1 + period_range[0] (repet.py:1249-1291)."""
+    b = np.asarray(beat_spectrogram)
+    cols = _f32(b[np.newaxis, :] if b.ndim == 1 else b.T)
+    n_cols, n_lags = cols.shape
+    out = np.empty(n_cols, dtype=np.int32)
+    _native.check(_native.lib().repet_periods(_native.default_context(_device).handle, _native.ptr(cols),
+                                              n_cols, n_lags, int(period_range[0]), int(period_range[1]),
+                                              _native.ptr(out)))
+    return int(out[0]) if b.ndim == 1 else out.astype(int)
+
+
+def _local_maxima_rows(rows, minimum_value, minimum_distance, number_values):
+    rows = _f32(rows)
+    n_rows, n_cols = rows.shape
+    idx = np.empty((n_rows, int(number_values)), dtype=np.int32)
+    cnt = np.empty(n_rows, dtype=np.int32)
+    _native.check(_native.lib().repet_local_maxima(_native.default_context(_device).handle, _native.ptr(rows),
+                                                   n_rows, n_cols, float(minimum_value), int(minimum_distance),
+                                                   int(number_values), _native.ptr(idx), _native.ptr(cnt)))
+    return idx, cnt
+
+
+def _localmaxima(data_vector, minimum_value, minimum_distance, number_values):
+    """Values and indices of the top local maxima of a vector (repet.py:1294-1345)."""
+    v = np.asarray(data_vector, dtype=float)
+    idx, cnt = _local_maxima_rows(v[np.newaxis, :], minimum_value, minimum_distance, number_values)
+    keep = idx[0, :cnt[0]].astype(int)
+    return v[keep], keep
+
+
+def _indices(similarity_matrix, similarity_threshold, similarity_distance, similarity_number):
+    """Similar-frame indices of every frame: column i of the matrix is scanned (repet.py:1348-1383)."""
+    idx, cnt = _local_maxima_rows(np.asarray(similarity_matrix).T, similarity_threshold, similarity_distance,
+                                  similarity_number)
+    return [idx[i, :cnt[i]].astype(int) for i in range(len(cnt))]
+
+
+def _mask(audio_spectrogram, repeating_period):
+    """Period-median repeating mask (repet.py:1386-1458)."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    out = np.empty((t, f), dtype=np.float32)
+    _native.check(_native.lib().repet_mask_period(_native.default_context(_device).handle, _native.ptr(rows), t,
+                                                  f, int(repeating_period), _native.ptr(out)))
+    return out.T.astype(np.float64)
+
+
+def _adaptivemask(audio_spectrogram, repeating_periods, filter_order):
+    """Local-period median mask (repet.py:1461-1508)."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    per = np.ascontiguousarray(repeating_periods, dtype=np.int32)
+    out = np.empty((t, f), dtype=np.float32)
+    _native.check(_native.lib().repet_mask_adaptive(_native.default_context(_device).handle, _native.ptr(rows),
+                                                    t, f, _native.ptr(per), int(filter_order), _native.ptr(out)))
+    return out.T.astype(np.float64)
+
+
+def _simmask(audio_spectrogram, similarity_indices):
+    """Similarity-median mask from per-frame index lists (repet.py:1511-1545)."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    width = max(1, max((len(ix) for ix in similarity_indices), default=1))
+    idx = np.full((t, width), -1, dtype=np.int32)
+    cnt = np.zeros(t, dtype=np.int32)
+    for i, ix in enumerate(similarity_indices):
+        idx[i, :len(ix)] = ix
+        cnt[i] = len(ix)
+    out = np.empty((t, f), dtype=np.float32)
+    _native.check(_native.lib().repet_mask_sim(_native.default_context(_device).handle, _native.ptr(rows), t, f,
+                                               _native.ptr(idx), _native.ptr(cnt), width, _native.ptr(out)))
+    return out.T.astype(np.float64)
+
+
+# ---- file / display utilities of the reference (host side, off the hot path) --------------------------------
+def wavread(audio_file):
+    """Read a WAVE file, integers scaled to [-1, 1) by their bit depth (repet.py:914-931)."""
+    import scipy.io.wavfile
+    sampling_frequency, samples = scipy.io.wavfile.read(audio_file)
+    return samples / pow(2, samples.itemsize * 8 - 1), sampling_frequency
+
+
+def wavwrite(audio_signal, sampling_frequency, audio_file):
+    """Write a WAVE file with SciPy, dtype as given (repet.py:934-946)."""
+    import scipy.io.wavfile
+    scipy.io.wavfile.write(audio_file, sampling_frequency, audio_signal)
+
+
+def specshow(audio_spectrogram, time_duration, maximum_frequency, xtick_step=1, ytick_step=1000):
+    """Show a spectrogram in dB with second / Hz ticks (repet.py:949-997)."""
+    import matplotlib.pyplot as plt
+    number_frequencies, number_times = np.shape(audio_spectrogram)
+    per_second = number_times / time_duration
+    per_hertz = number_frequencies / maximum_frequency
+    plt.imshow(20 * np.log10(audio_spectrogram), aspect="auto", cmap="jet", origin="lower")
+    plt.xticks(ticks=np.arange(xtick_step * per_second, number_times, xtick_step * per_second),
+               labels=np.arange(xtick_step, time_duration, xtick_step).astype(int))
+    plt.yticks(ticks=np.arange(ytick_step * per_hertz, number_frequencies, ytick_step * per_hertz),
+               labels=np.arange(ytick_step, maximum_frequency, ytick_step).astype(int))
+    plt.xlabel("Time (s)")
+    plt.ylabel("Frequency (Hz)")

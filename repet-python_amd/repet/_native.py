@@ -1,0 +1,192 @@
+"""ctypes binding of librepet_hip.so (include/repet_hip.h). No CPU fallback: if the library or a GPU
+is missing the calls raise, loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("REPET_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "librepet_hip.so"))
+
+ABI_VERSION = 1
+ORIGINAL, EXTENDED, ADAPTIVE, SIM, SIMONLINE = range(5)
+ALGO_IDS = {"original": ORIGINAL, "extended": EXTENDED, "adaptive": ADAPTIVE, "sim": SIM, "simonline": SIMONLINE}
+F32, F64, I16 = 0, 1, 2
+MAX_STAGES = 16
+
+ERR_BAD_ARG, ERR_TOO_SHORT, ERR_HIP, ERR_OOM, ERR_LIMIT = -1, -2, -3, -4, -5
+
+
+class Params(C.Structure):
+    _fields_ = [("window_length", C.c_int32), ("step_length", C.c_int32), ("period_lo", C.c_int32),
+                ("period_hi", C.c_int32), ("cutoff_bins", C.c_int32), ("filter_order", C.c_int32),
+                ("seg_len_frames", C.c_int32), ("seg_step_frames", C.c_int32),
+                ("sim_distance_frames", C.c_int32), ("sim_number", C.c_int32), ("buffer_frames", C.c_int32),
+                ("reserved0", C.c_int32), ("seg_len_samples", C.c_int64), ("seg_step_samples", C.c_int64),
+                ("sim_threshold", C.c_double)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("n_stages", C.c_int32), ("reserved0", C.c_int32), ("total_ms", C.c_float),
+                ("stage_ms", C.c_float * MAX_STAGES), ("stage_name", (C.c_char * 24) * MAX_STAGES),
+                ("stage_bytes", C.c_double * MAX_STAGES), ("stage_flops", C.c_double * MAX_STAGES)]
+
+    def as_dict(self):
+        stages = []
+        for i in range(self.n_stages):
+            stages.append({"name": self.stage_name[i].value.decode(), "ms": float(self.stage_ms[i]),
+                           "bytes": float(self.stage_bytes[i]), "flops": float(self.stage_flops[i])})
+        return {"total_ms": float(self.total_ms), "stages": stages}
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "repet_abi_version": (C.c_int, []),
+    "repet_device_count": (C.c_int, []),
+    "repet_last_error": (C.c_char_p, []),
+    "repet_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "repet_ctx_destroy": (C.c_int, [_P]),
+    "repet_ctx_upload": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int32]),
+    "repet_ctx_execute": (C.c_int, [_P, C.c_int, C.POINTER(Params), C.POINTER(Timing)]),
+    "repet_ctx_download": (C.c_int, [_P, _P]),
+    "repet_run": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int32, C.POINTER(Params), _P, C.c_int,
+                            C.POINTER(Timing)]),
+    "repet_run_batch": (C.c_int, [C.c_int, C.c_int32, C.POINTER(_P), C.c_int, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int32), C.POINTER(Params), C.POINTER(_P), C.c_int32]),
+    "repet_frame_count": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "repet_stft": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64]),
+    "repet_istft": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, C.c_int64]),
+    "repet_selfsim": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "repet_beat_spectrum": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
+    "repet_beat_spectrogram": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "repet_periods": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "repet_local_maxima": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, _P, _P]),
+    "repet_mask_period": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "repet_mask_adaptive": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, _P]),
+    "repet_mask_sim": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
+    "repet_ctx_last_periods": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    "repet_ctx_last_sim_indices": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
+    "repet_ctx_last_frame_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load librepet_hip.so once. Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"librepet_hip.so not found at {LIB_PATH}: build it with `make -C repet-python_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.repet_abi_version() != ABI_VERSION:
+            raise RuntimeError("librepet_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().repet_last_error().decode(errors="replace")
+    if rc in (ERR_BAD_ARG, ERR_TOO_SHORT):
+        raise ValueError(msg)
+    if rc == ERR_OOM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"librepet_hip error {rc}: {msg}")
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_input(audio_signal):
+    """(array, dtype code) in a layout/dtype the ABI takes without a host-side conversion pass."""
+    a = np.asarray(audio_signal)
+    if a.dtype == np.float64:
+        code = F64
+    elif a.dtype == np.float32:
+        code = F32
+    elif a.dtype == np.int16:
+        code = I16
+    else:
+        a = a.astype(np.float64)
+        code = F64
+    return np.ascontiguousarray(a), code
+
+
+class Context:
+    """One device context: upload a clip once, execute variants on the resident copy, download."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        if lib().repet_device_count() < 1:
+            raise RuntimeError("no HIP device visible: the REPET engine has no CPU fallback")
+        check(lib().repet_ctx_create(int(device), C.byref(self._h)))
+        self.shape = None
+
+    def close(self):
+        if self._h:
+            lib().repet_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def upload(self, audio_signal):
+        n, c = np.shape(audio_signal)
+        a, code = as_input(audio_signal)
+        check(lib().repet_ctx_upload(self._h, ptr(a), code, n, c))
+        self.shape = (n, c)
+
+    def execute(self, algo, params, timing=False):
+        t = Timing() if timing else None
+        check(lib().repet_ctx_execute(self._h, ALGO_IDS[algo] if isinstance(algo, str) else algo,
+                                      C.byref(params), C.byref(t) if timing else None))
+        return t.as_dict() if timing else None
+
+    def download(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        check(lib().repet_ctx_download(self._h, ptr(out)))
+        return out
+
+    def last_periods(self, capacity):
+        out = np.empty(max(capacity, 1), dtype=np.int32)
+        n = C.c_int32()
+        check(lib().repet_ctx_last_periods(self._h, ptr(out), capacity, C.byref(n)))
+        return out[:n.value].copy()
+
+    def last_frame_count(self):
+        t = C.c_int64()
+        check(lib().repet_ctx_last_frame_count(self._h, C.byref(t)))
+        return t.value
+
+    def last_sim_indices(self, n_rows, number):
+        idx = np.empty((max(n_rows, 1), number), dtype=np.int32)
+        cnt = np.empty(max(n_rows, 1), dtype=np.int32)
+        check(lib().repet_ctx_last_sim_indices(self._h, ptr(idx), ptr(cnt), n_rows, number))
+        return idx[:n_rows], cnt[:n_rows]
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,161 @@
+"""Stage-level parity on the MI355X: every HIP stage export (through the C ABI) against the float64
+oracle on the same seeded inputs. Integer results (periods, peak indices) must match exactly when both
+sides see the same float32 values; floating-point stages are held to fp32-rounding tolerances."""
+import numpy as np
+import pytest
+
+import repet
+from helpers import golden_input
+from oracle import repet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def clip():
+    x, fs = golden_input("small_stereo")
+    return np.array(x), fs
+
+
+@pytest.mark.parametrize("fs,seconds", [(8000, 3.0), (16000, 2.0), (44100, 1.5), (96000, 0.5)])
+def test_stft_matches_oracle(fs, seconds):
+    from repet_synth import synth
+    x = synth(seconds, fs, 1, 11)[:, 0]
+    w, window, h = orc.stft_geometry(fs)
+    got = repet._stft(x, window, h)
+    want = orc.stft(x.astype(np.float32).astype(np.float64), window, h)
+    assert got.shape == want.shape
+    assert _rel(got, want) < 2e-6
+
+
+def test_stft_is_hermitian_and_handles_odd_lengths():
+    from repet_synth import synth
+    for n in (1, 255, 256, 257, 1000, 4097):
+        x = synth(1.0, 8000, 1, 3)[:n, 0]
+        w, window, h = orc.stft_geometry(8000)
+        got = repet._stft(x, window, h)
+        want = orc.stft(x.astype(np.float32).astype(np.float64), window, h)
+        assert got.shape == want.shape == (w, int(np.ceil(n / h)) + 1)
+        assert np.max(np.abs(got - want)) < 1e-5
+        assert np.allclose(got[1:w // 2], np.conj(got[:w // 2:-1]))
+
+
+@pytest.mark.parametrize("fs", [8000, 44100])
+def test_istft_roundtrip_and_oracle(fs):
+    from repet_synth import synth
+    x = synth(2.0, fs, 1, 5)[:, 0]
+    w, window, h = orc.stft_geometry(fs)
+    spec = orc.stft(x, window, h)
+    got = repet._istft(spec, window, h)
+    want = orc.istft(spec, window, h)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) < 2e-6
+    assert np.max(np.abs(got[:len(x)] - x)) < 2e-6          # COLA: exact reconstruction
+
+
+def test_selfsimilarity(clip):
+    x, fs = clip
+    w, window, h = orc.stft_geometry(fs)
+    _, mag = orc.spectrogram_channels(x, window, h)
+    v = np.mean(mag, axis=2).astype(np.float32).astype(np.float64)
+    got = repet._selfsimilaritymatrix(v)
+    want = orc.selfsimilaritymatrix(v)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) < 2e-6
+    assert np.array_equal(got, got.T)                         # mirrored tiles are bit-identical
+
+
+def test_selfsimilarity_silent_frame_gives_nan_row_and_column():
+    rs = np.random.RandomState(0)
+    v = rs.rand(40, 150)
+    v[:, 17] = 0.0
+    got = repet._selfsimilaritymatrix(v)
+    assert np.all(np.isnan(got[17])) and np.all(np.isnan(got[:, 17]))
+    keep = np.delete(np.arange(150), 17)
+    assert np.all(np.isfinite(got[np.ix_(keep, keep)]))
+
+
+def test_beat_spectrum_and_period(clip):
+    x, fs = clip
+    w, window, h = orc.stft_geometry(fs)
+    _, mag = orc.spectrogram_channels(x, window, h)
+    p = np.power(np.mean(mag, axis=2), 2).astype(np.float32).astype(np.float64)
+    got = repet._beatspectrum(p)
+    want = orc.beatspectrum(p)
+    assert _rel(got, want) < 2e-5
+    pr = orc.period_range_frames(orc.Params(), fs, h)
+    assert repet._periods(got, pr) == orc.periods(want, pr)
+    # period kernel alone, exact on identical float32 input
+    b32 = want.astype(np.float32)
+    assert repet._periods(b32, pr) == orc.periods(b32.astype(np.float64), pr)
+
+
+def test_beat_spectrogram_with_hole_quirk(clip):
+    x, fs = clip
+    w, window, h = orc.stft_geometry(fs)
+    _, mag = orc.spectrogram_channels(x[:6 * fs], window, h)
+    p = np.power(np.mean(mag, axis=2), 2).astype(np.float32).astype(np.float64)
+    seg_len, seg_step = 90, 40
+    got = repet._beatspectrogram(p, seg_len, seg_step)
+    want = orc.beatspectrogram(p, seg_len, seg_step)
+    assert got.shape == want.shape
+    assert _rel(got, want) < 2e-5
+    assert np.all(got[:, seg_step - 1] == 0)                  # repet.py:1202-1204 leaves this column zero
+    pr = [8, 80]
+    assert np.array_equal(repet._periods(want.astype(np.float32), pr),
+                          orc.periods(want.astype(np.float32).astype(np.float64), pr))
+
+
+def test_local_maxima_exact():
+    rs = np.random.RandomState(1)
+    for n, d, k in [(700, 31, 100), (700, 31, 5), (97, 200, 10), (64, 1, 100), (5, 2, 3), (300, 0, 20)]:
+        m = rs.rand(6, n).astype(np.float32)
+        m[2, rs.randint(0, n, 5)] = np.nan
+        m[3] = 0.25                                          # plateau: no strict maximum anywhere
+        m[4, ::7] = m[4, 3]                                  # exact ties
+        for r in range(6):
+            vals, idx = repet._localmaxima(m[r], 0.1, d, k)
+            wv, wi = orc.localmaxima(m[r].astype(np.float64), 0.1, d, k)
+            if len(np.unique(wv)) == len(wv):
+                assert np.array_equal(idx, wi), (n, d, k, r)
+            else:                                            # ties may be ordered differently
+                assert sorted(idx) == sorted(wi)
+
+
+def test_indices_on_similarity_matrix(clip):
+    x, fs = clip
+    w, window, h = orc.stft_geometry(fs)
+    _, mag = orc.spectrogram_channels(x, window, h)
+    s = orc.selfsimilaritymatrix(np.mean(mag, axis=2)).astype(np.float32)
+    got = repet._indices(s, 0, 31, 100)
+    want = orc.indices(s.astype(np.float64), 0, 31, 100)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+def test_masks(clip):
+    x, fs = clip
+    w, window, h = orc.stft_geometry(fs)
+    _, mag = orc.spectrogram_channels(x, window, h)
+    v = mag[:, :, 0].astype(np.float32).astype(np.float64)
+    t = v.shape[1]
+    for period in (32, 45, 166):
+        assert np.max(np.abs(repet._mask(v, period) - orc.mask(v, period))) < 1e-6
+    rs = np.random.RandomState(2)
+    per = rs.randint(32, 160, size=t)
+    for order in (1, 2, 3, 4, 5, 8):
+        assert np.max(np.abs(repet._adaptivemask(v, per, order) - orc.adaptivemask(v, per, order))) < 1e-6
+    lists = []
+    for i in range(t):
+        k = [0, 1, 2, 3, 7, 16, 25, 33, 49, 64, 81, 99, 100, 128, 150][i % 15]
+        lists.append(rs.choice(t, size=min(k, t), replace=False))
+    got = repet._simmask(v, lists)
+    want = orc.simmask(v, lists)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.max(np.abs(got[ok] - want[ok])) < 1e-6

@@ -1,0 +1,170 @@
+"""End-to-end parity of the five REPET variants on the MI355X, through the C ABI, against the float64
+oracle and against the committed golden vectors of the reference. Bar (BASELINE.json north_star):
+RMS error of background_signal <= 1e-4 absolute (full scale 1.0)."""
+import numpy as np
+import pytest
+
+import repet
+from helpers import golden_input, load_edge_cases, load_golden, rms_err
+from oracle import repet_oracle as orc
+from repet_synth import synth
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-4
+ALGOS = ["original", "extended", "adaptive", "sim", "simonline"]
+CASES = ["small_mono", "small_stereo", "mid_stereo", "g44k_stereo"]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("algo", ALGOS)
+def test_variant_matches_oracle_and_golden(case, algo):
+    x, fs = golden_input(case)
+    got = getattr(repet, algo)(x, fs)
+    assert got.dtype == np.float64 and got.shape == x.shape and got.flags.c_contiguous
+    want = orc.ALGORITHMS[algo](np.array(x), fs)
+    err = rms_err(got, want)
+    assert err <= RMS_TOL, f"rms {err:.3e}"
+    g = load_golden(case)
+    stride = int(g["sample_stride"])
+    assert rms_err(got[::stride], g[f"{algo}.samples"]) <= RMS_TOL
+    assert np.max(np.abs(got - want)) < 5e-3
+
+
+def test_input_is_not_mutated_and_dtypes_accepted():
+    x, fs = golden_input("small_stereo")
+    x = np.array(x[:4 * fs])
+    keep = x.copy()
+    ref = repet.original(x, fs)
+    assert np.array_equal(x, keep)
+    as32 = repet.original(x.astype(np.float32), fs)
+    assert as32.dtype == np.float64 and rms_err(as32, ref) < 1e-5
+    ints = (x * 32767).astype(np.int16)
+    as16 = repet.original(ints, fs)
+    assert rms_err(as16 / 32767.0, ref) < 1e-4
+    fortran = np.asfortranarray(x)
+    assert rms_err(repet.original(fortran, fs), ref) == 0.0
+
+
+def test_edge_cases_behave_like_the_reference():
+    edge = load_edge_cases()
+    fs = 44100
+    base = synth(16, fs, 2, 5)
+
+    def outcome(algo, x):
+        try:
+            y = getattr(repet, algo)(x, fs)
+            return {"ok": True, "nan_count": int(np.isnan(y).sum()), "all_zero": bool(np.all(y == 0))}
+        except Exception as e:  # noqa: BLE001
+            return {"ok": False, "error": type(e).__name__}
+
+    for key, algo, x in [("original_2.9s", "original", base[:int(2.9 * fs)]),
+                         ("original_3.2s", "original", base[:int(3.2 * fs)]),
+                         ("sim_0.5s", "sim", base[:int(0.5 * fs)]),
+                         ("simonline_9s", "simonline", base[:9 * fs]),
+                         ("simonline_441343", "simonline", base[:441343]),
+                         ("simonline_441344", "simonline", base[:441344]),
+                         ("simonline_441345", "simonline", base[:441345])]:
+        want = edge[key]
+        got = outcome(algo, x)
+        assert got["ok"] == want["ok"], key
+        if want["ok"]:
+            assert got["all_zero"] == want["all_zero"], key
+            assert (got["nan_count"] > 0) == (want["nan_count"] > 0), key
+        else:
+            assert got["error"] == want["error"], key
+
+    x149 = synth(14.9, fs, 2, 5)
+    assert edge["extended_14.9s_equals_original"]
+    assert np.array_equal(repet.extended(x149, fs), repet.original(x149, fs))
+
+
+def test_silent_gap_gives_nan_only_for_sim():
+    edge = load_edge_cases()
+    fs = 44100
+    gap = synth(16, fs, 2, 5)[:8 * fs].copy()
+    gap[100000:140000] = 0.0
+    y = repet.sim(gap, fs)
+    want = orc.sim(gap, fs)
+    assert np.array_equal(np.isnan(y), np.isnan(want))
+    assert int(np.isnan(y).sum()) == edge["silence_gap_sim"]["nan_count"]
+    ok = ~np.isnan(want)
+    assert rms_err(y[ok], want[ok]) <= RMS_TOL
+    assert np.all(np.isfinite(repet.original(gap, fs)))
+    assert np.all(np.isfinite(repet.adaptive(gap, fs)))
+
+
+def test_module_parameters_change_behaviour():
+    x, fs = golden_input("small_stereo")
+    saved = (repet.period_range, repet.similarity_number, repet.cutoff_frequency, repet.filter_order)
+    try:
+        repet.period_range = [0.5, 3]
+        repet.similarity_number = 13
+        repet.cutoff_frequency = 250
+        repet.filter_order = 4
+        p = orc.Params(period_range=(0.5, 3), similarity_number=13, cutoff_frequency=250, filter_order=4)
+        for algo in ALGOS:
+            got = getattr(repet, algo)(x, fs)
+            want = orc.ALGORITHMS[algo](np.array(x), fs, p)
+            assert rms_err(got, want) <= RMS_TOL, algo
+    finally:
+        repet.period_range, repet.similarity_number, repet.cutoff_frequency, repet.filter_order = saved
+
+
+def test_integer_intermediates_through_the_context():
+    x, fs = golden_input("mid_stereo")
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    g = load_golden("mid_stereo")
+
+    ctx.execute("original", p)
+    assert ctx.last_periods(4)[0] == int(g["original.period"])
+
+    ctx.execute("extended", p)
+    assert np.array_equal(ctx.last_periods(64), g["extended.periods"])
+
+    ctx.execute("adaptive", p)
+    t = ctx.last_frame_count()
+    got = ctx.last_periods(t)
+    assert np.mean(got != g["adaptive.periods"]) <= 0.01
+
+    ctx.execute("sim", p)
+    t = ctx.last_frame_count()
+    idx, cnt = ctx.last_sim_indices(t, p.sim_number)
+    assert np.mean(cnt != g["sim.counts"]) <= 0.02
+    fstride = int(g["frame_stride"])
+    differ = 0
+    for row, frame in zip(g["sim.indices"], g["sim.index_frames"]):
+        differ += set(idx[frame, :cnt[frame]]) != set(row[row >= 0])
+    assert differ / len(g["sim.index_frames"]) <= 0.10   # fp32 similarity can flip near-ties
+
+    timing = ctx.execute("sim", p, timing=True)
+    names = [s["name"] for s in timing["stages"]]
+    assert names == ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_frames", "overlap_add"]
+    assert timing["total_ms"] > 0
+    ctx.close()
+
+
+def test_batch_api_matches_single_calls():
+    fs = 8000
+    clips = [synth(d, fs, 2, s) for d, s in [(4, 1), (7, 2), (5, 3)]]
+    outs = repet.run_batch("original", clips, fs, n_devices=1)
+    for x, y in zip(clips, outs):
+        assert np.array_equal(y, repet.original(x, fs))
+
+
+@pytest.mark.slow
+def test_sim_headline_config_properties():
+    """cfg 2 (180 s, 44.1 kHz stereo): strided golden samples + size-independent properties."""
+    g = load_golden("cfg2_sim")
+    x, fs = golden_input("cfg2_sim")
+    y = repet.sim(x, fs)
+    stride = int(g["sample_stride"])
+    assert rms_err(y[::stride], g["sim.samples"]) <= RMS_TOL
+    n = (len(y) // fs) * fs
+    per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, 2) ** 2, axis=1))
+    assert np.max(np.abs(per_s - g["sim.rms_per_second"])) < 2e-4
+    # the soft mask never amplifies: background energy <= mixture energy per second (COLA-exact STFT)
+    mix = np.sqrt(np.mean(np.array(x[:n]).reshape(-1, fs, 2) ** 2, axis=1))
+    assert np.all(per_s <= mix * 1.001 + 1e-6)
