@@ -136,7 +136,7 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
                                int32_t idx_pitch, int32_t* count, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
     const int n_pad = (int)round_up(n_cols, 4);
-    const int cand_cap = (n_cols + 1) / 2 + 4;                       // strict 1-neighbour peaks cannot be adjacent
+    const int cand_cap = (d > 0 ? (n_cols + 1) / 2 : n_cols) + 4;    // strict 1-neighbour peaks cannot be adjacent
     const int peak_cap = (d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1); // peaks are more than d apart
     const size_t bytes = (size_t)(n_pad + cand_cap + 2 * peak_cap) * 4;
     if (bytes > 160 * 1024 - 64) return hipErrorInvalidValue;

@@ -122,8 +122,9 @@ def test_local_maxima_exact():
             wv, wi = orc.localmaxima(m[r].astype(np.float64), 0.1, d, k)
             if len(np.unique(wv)) == len(wv):
                 assert np.array_equal(idx, wi), (n, d, k, r)
-            else:                                            # ties may be ordered differently
-                assert sorted(idx) == sorted(wi)
+            else:                                            # exact ties: any tied element may sit at the cut
+                assert np.array_equal(np.sort(vals), np.sort(wv))
+                assert np.array_equal(m[r][idx].astype(np.float64), vals) and len(set(idx)) == len(idx)
 
 
 def test_indices_on_similarity_matrix(clip):
