@@ -97,6 +97,14 @@ int repet_ctx_upload(repet_ctx* ctx, const void* audio, int dtype, int64_t n_sam
 int repet_ctx_execute(repet_ctx* ctx, int algo, const repet_params* p, repet_timing* timing /* nullable */);
 int repet_ctx_download(repet_ctx* ctx, double* out);
 
+/* extended only (repet.py:205-419): the segment plan of an n_samples clip (repet.py:271-281), and a run
+ * restricted to segments [first, first+n_segments). Contributions of the other segments stay zero, and
+ * the cross-fade is linear in the segments, so the outputs of disjoint ranges (e.g. one range per GPU)
+ * add up to the full result. */
+int64_t repet_extended_segment_count(int64_t n_samples, const repet_params* p);
+int repet_ctx_execute_extended_range(repet_ctx* ctx, const repet_params* p, int64_t first, int64_t n_segments,
+                                     repet_timing* timing /* nullable */);
+
 /* ---- one-shot drop-in: replaces repet.<algo>(audio_signal, fs) (repet.py:67,205,422,571,712) -- */
 int repet_run(int algo, const void* audio, int dtype, int64_t n_samples, int32_t n_channels,
               const repet_params* p, double* out, int device, repet_timing* timing /* nullable */);

@@ -344,6 +344,28 @@ def extended(x, fs, p=None, trace=None):
     return out
 
 
+def extended_range(x, fs, first, count, p=None):
+    """Contribution of segments [first, first+count) to :func:`extended`: sum_j w_j * original(segment_j)
+    with w_j = [rising half | 1 | falling half] of triang(2*overlap) (repet.py:380-414, which is linear
+    in the segments). Used to check the multi-GPU segment sharding."""
+    p = p or Params()
+    n, c = np.shape(x)
+    segs, overlap = extended_plan(n, fs, p)
+    out = np.zeros((n, c))
+    if len(segs) == 1:
+        return original(x, fs, p) if (first, count) == (0, 1) else out
+    tri = scipy.signal.windows.triang(2 * overlap)
+    for j in range(first, first + count):
+        start, length = segs[j]
+        piece = original(x[start:start + length], fs, p)
+        if j > 0:
+            piece[:overlap] *= tri[:overlap, np.newaxis]
+        if j < len(segs) - 1:
+            piece[length - overlap:] *= tri[overlap:, np.newaxis]
+        out[start:start + length] += piece
+    return out
+
+
 def adaptive(x, fs, p=None, trace=None):
     """repet.py:422-568."""
     p = p or Params()

@@ -267,21 +267,35 @@ int exec_original(repet_ctx* c, const repet_params* p) {
     return REPET_OK;
 }
 
-int exec_extended(repet_ctx* c, const repet_params* p) {
+int64_t extended_segment_count(int64_t N, const repet_params* p) {
+    const int64_t L = p->seg_len_samples, Hs = p->seg_step_samples;
+    if (L <= 0 || Hs <= 0 || Hs > L) return -1;
+    return (N < L + Hs) ? 1 : 1 + (N - L) / Hs;          // repet.py:271-281
+}
+
+// segments [first, first+n_seg) of the resident clip; contributions of other segments are left zero,
+// so partial results of disjoint ranges simply add up (repet.py:380-414 is linear in the segments)
+int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_t n_seg = -1) {
     const int64_t N = c->n_samples, L = p->seg_len_samples, Hs = p->seg_step_samples;
     if (L <= 0 || Hs <= 0 || Hs > L) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step");
-    if (N < L + Hs) return exec_original(c, p);                    // repet.py:271
-    const int64_t count = 1 + (N - L) / Hs;                         // repet.py:279
+    const int64_t count = extended_segment_count(N, p);
+    if (n_seg < 0) n_seg = count - first;
+    if (first < 0 || n_seg < 0 || first + n_seg > count) return fail(REPET_ERR_BAD_ARG, "extended: segment range outside the plan");
+    if (count == 1) {                                               // repet.py:271
+        if (n_seg == 1) return exec_original(c, p);
+        HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
+        return REPET_OK;
+    }
     const int64_t O = L - Hs;
-    HIP_TRY(c->periods.ensure((size_t)count * sizeof(int32_t)));
+    HIP_TRY(c->periods.ensure((size_t)std::max<int64_t>(n_seg, 1) * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
     repet_timing* timing = c->timing;       // one "segments" stage instead of 5 marks per segment
     c->timing = nullptr;
     double bytes = 0, flops = 0;
-    for (int64_t j = 0; j < count; ++j) {
+    for (int64_t j = first; j < first + n_seg; ++j) {
         const int64_t start = j * Hs;
         const int64_t len = (j < count - 1) ? L : N - start;        // repet.py:318-322
-        int rc = run_original(c, p, start, len, c->periods.as<int32_t>() + j, true, j > 0 ? O : 0, j < count - 1 ? O : 0);
+        int rc = run_original(c, p, start, len, c->periods.as<int32_t>() + (j - first), true, j > 0 ? O : 0, j < count - 1 ? O : 0);
         if (rc != REPET_OK) { c->timing = timing; return rc; }
         const double F = p->window_length / 2 + 1, T = (double)c->last_T, hi = std::min<double>(p->period_hi, c->last_T / 3);
         bytes += 8.0 * len * c->n_channels + (12.0 + 24.0 + 12.0) * F * T * c->n_channels + 8.0 * F * T + 8.0 * T * hi;
@@ -289,7 +303,7 @@ int exec_extended(repet_ctx* c, const repet_params* p) {
     }
     c->timing = timing;
     mark(c, "extended_segments", bytes, flops);
-    c->last_n_periods = (int32_t)count;
+    c->last_n_periods = (int32_t)n_seg;
     return REPET_OK;
 }
 
@@ -510,6 +524,29 @@ int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timin
         case REPET_SIMONLINE: rc = exec_simonline(c, p); break;
         default: rc = fail(REPET_ERR_BAD_ARG, "unknown algorithm");
     }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
+    if (rc == REPET_OK) end_timing(c);
+    c->timing = nullptr;
+    return rc;
+}
+
+int64_t repet_extended_segment_count(int64_t n_samples, const repet_params* p) {
+    if (!p) return -1;
+    return extended_segment_count(n_samples, p);
+}
+
+int repet_ctx_execute_extended_range(repet_ctx* c, const repet_params* p, int64_t first, int64_t n_seg,
+                                     repet_timing* timing) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    RP_TRY(check_params(p));
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    if (n_seg < 0) return fail(REPET_ERR_BAD_ARG, "negative segment count");
+    DeviceGuard guard(c->device);
+    begin_timing(c, timing);
+    c->last_algo = REPET_EXTENDED;
+    c->last_n_periods = 0;
+    int rc = exec_extended(c, p, first, n_seg);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
     if (rc == REPET_OK) end_timing(c);

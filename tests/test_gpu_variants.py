@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import repet
+from repet import _native, parallel
 from helpers import golden_input, load_edge_cases, load_golden, rms_err
 from oracle import repet_oracle as orc
 from repet_synth import synth
@@ -144,6 +145,26 @@ def test_integer_intermediates_through_the_context():
     assert names == ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_frames", "overlap_add"]
     assert timing["total_ms"] > 0
     ctx.close()
+
+
+def test_extended_segment_ranges_add_up():
+    """Multi-GPU sharding of `extended`: disjoint segment ranges (one per GPU) sum to the full result."""
+    x, fs = golden_input("mid_stereo")
+    p = repet.derive_params(fs)
+    n_seg = _native.lib().repet_extended_segment_count(len(x), p)
+    assert n_seg == 3
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute("extended", p)
+    full = ctx.download()
+    total = np.zeros_like(full)
+    for first, count in parallel.segment_ranges(n_seg, 2):
+        ctx.execute_extended_range(p, first, count)
+        total += ctx.download()
+    ctx.close()
+    assert rms_err(total, full) < 1e-7
+    with pytest.raises(ValueError):
+        repet.Context(0).execute_extended_range(p, 0, 1)      # nothing uploaded
 
 
 def test_batch_api_matches_single_calls():
