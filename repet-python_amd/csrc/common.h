@@ -81,10 +81,12 @@ struct MaskArgs {
     const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t F, FS;
     float2* X; float* mask; int32_t cutoff;
 };
+// max_count / min_period bound the list length so the launcher can pick the smallest compiled network.
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
-                           int64_t first_frame, hipStream_t s);
+                           int64_t first_frame, int32_t max_count, hipStream_t s);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
-hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host, hipStream_t s);
+hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
+                              int32_t min_period, hipStream_t s);
 
 // elementwise helpers
 hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);

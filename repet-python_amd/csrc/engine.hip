@@ -253,7 +253,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
     HIP_TRY(launch_periods(c->beat.as<float>(), 1, LP, (int)T, p->period_lo, p->period_hi, period_slot, c->stream));
     mark(c, "beat_period", 4.0 * T * hi, 0);
-    HIP_TRY(launch_mask_period(mask_args(c, g, p->cutoff_bins), period_slot, 0, c->stream));
+    HIP_TRY(launch_mask_period(mask_args(c, g, p->cutoff_bins), period_slot, 0, p->period_lo + 1, c->stream));
     mark(c, "mask_period", (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
     RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, weighted, fade_in, fade_out));
     c->last_T = T;
@@ -362,7 +362,9 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
     HIP_TRY(e);
     mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), 0, c->stream));
+    // peaks are more than d frames apart: at most ceil(T/(d+1)) of them, whatever similarity_number says
+    const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), 0, max_peaks, c->stream));
     mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = K;
@@ -395,7 +397,8 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
     HIP_TRY(e);
     mark(c, "local_maxima", 4.0 * rows * B + 4.0 * K * rows, 0);
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), B - 1, c->stream));
+    const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream));
     mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
     RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = K;
@@ -797,7 +800,7 @@ int repet_mask_period(repet_ctx* c, const float* v, int64_t T, int32_t F, int32_
     DeviceGuard guard(c->device);
     MaskArgs m; int FS;
     RP_TRY(stage_mask_common(c, v, T, F, &m, &FS));
-    HIP_TRY(launch_mask_period(m, nullptr, period, c->stream));
+    HIP_TRY(launch_mask_period(m, nullptr, period, period, c->stream));
     return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
 }
 
@@ -824,7 +827,7 @@ int repet_mask_sim(repet_ctx* c, const float* v, int64_t T, int32_t F, const int
     HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
     HIP_TRY(hipMemcpyAsync(c->idx.p, idx, (size_t)T * number * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->cnt.p, count, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), 0, c->stream));
+    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), 0, number, c->stream));
     return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
 }
 

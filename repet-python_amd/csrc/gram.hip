@@ -23,7 +23,7 @@ constexpr int kGramLds = 4 * TILE_FLOATS * 4;   // 2 operands x 2 buffers, bytes
 enum GramMode { GRAM_FULL = 0, GRAM_BAND = 1 };
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ A, int64_t T, int FS,
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, int64_t T, int FS,
                                                       float* __restrict__ out, int64_t pitch, int n_lags) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bi = blockIdx.x;
@@ -48,38 +48,50 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // staging: 128 rows x 8 float4 per operand tile = 1024 float4, 4 per thread
-    float4 ra[4], rb[4];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i;
-            const int row = q >> 3, c4 = q & 7;
-            const int64_t off = (int64_t)row * FS + kt * BK + c4 * 4;
-            ra[i] = *reinterpret_cast<const float4*>(Ag + off);
-            rb[i] = *reinterpret_cast<const float4*>(Bg + off);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* As = lds + buf * 2 * TILE_FLOATS;
-        float* Bs = As + TILE_FLOATS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i;
-            const int row = q >> 3, c4 = q & 7;
-            *reinterpret_cast<float4*>(As + row * LDP + c4 * 4) = ra[i];
-            *reinterpret_cast<float4*>(Bs + row * LDP + c4 * 4) = rb[i];
-        }
-    };
+    // staging: 128 rows x 8 float4 per operand tile = 1024 float4, 4 per thread and operand
+    // (wave-uniform 64-bit base in SGPRs + one 32-bit per-lane offset shared by both operands)
+    const unsigned g0 = (unsigned)(((tid + 0) >> 3) * FS + (tid & 7) * 4);
+    const unsigned g1 = (unsigned)(((tid + 256) >> 3) * FS + (tid & 7) * 4);
+    const unsigned g2 = (unsigned)(((tid + 512) >> 3) * FS + (tid & 7) * 4);
+    const unsigned g3 = (unsigned)(((tid + 768) >> 3) * FS + (tid & 7) * 4);
+    const int l0 = ((tid + 0) >> 3) * LDP + (tid & 7) * 4;      // LDS float offsets of the same four chunks
+    const int l1 = l0 + 32 * LDP, l2 = l0 + 64 * LDP, l3 = l0 + 96 * LDP;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define REPET_LOAD_TILE(kt)                                                     \
+    {                                                                           \
+        const float* Ak = Ag + (kt) * BK;                                       \
+        const float* Bk = Bg + (kt) * BK;                                       \
+        ra0 = *reinterpret_cast<const float4*>(Ak + g0);                        \
+        rb0 = *reinterpret_cast<const float4*>(Bk + g0);                        \
+        ra1 = *reinterpret_cast<const float4*>(Ak + g1);                        \
+        rb1 = *reinterpret_cast<const float4*>(Bk + g1);                        \
+        ra2 = *reinterpret_cast<const float4*>(Ak + g2);                        \
+        rb2 = *reinterpret_cast<const float4*>(Bk + g2);                        \
+        ra3 = *reinterpret_cast<const float4*>(Ak + g3);                        \
+        rb3 = *reinterpret_cast<const float4*>(Bk + g3);                        \
+    }
+#define REPET_STORE_TILE(buf)                                                   \
+    {                                                                           \
+        float* As_ = lds + (buf) * 2 * TILE_FLOATS;                             \
+        float* Bs_ = As_ + TILE_FLOATS;                                         \
+        *reinterpret_cast<float4*>(As_ + l0) = ra0;                             \
+        *reinterpret_cast<float4*>(Bs_ + l0) = rb0;                             \
+        *reinterpret_cast<float4*>(As_ + l1) = ra1;                             \
+        *reinterpret_cast<float4*>(Bs_ + l1) = rb1;                             \
+        *reinterpret_cast<float4*>(As_ + l2) = ra2;                             \
+        *reinterpret_cast<float4*>(Bs_ + l2) = rb2;                             \
+        *reinterpret_cast<float4*>(As_ + l3) = ra3;                             \
+        *reinterpret_cast<float4*>(Bs_ + l3) = rb3;                             \
+    }
 
     const int nk = FS / BK;
-    load_tile(0);
-    store_tile(0);
+    REPET_LOAD_TILE(0)
+    REPET_STORE_TILE(0)
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) REPET_LOAD_TILE(kt + 1)
         const float* As = lds + cur * 2 * TILE_FLOATS + (wr * 64 + lr) * LDP + 4 * lh;
         const float* Bs = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + (wc * 64 + lr) * LDP + 4 * lh;
 #pragma unroll
@@ -88,19 +100,22 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
             const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDP + ks * 8);
             const float4 b0 = *reinterpret_cast<const float4*>(Bs + ks * 8);
             const float4 b1 = *reinterpret_cast<const float4*>(Bs + 32 * LDP + ks * 8);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[n][q], acc[m][n], 0, 0, 0);
+#define REPET_MFMA4(AX, BX)                                                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b0.BX, acc[0][0], 0, 0, 0);           \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b1.BX, acc[0][1], 0, 0, 0);           \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b0.BX, acc[1][0], 0, 0, 0);           \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b1.BX, acc[1][1], 0, 0, 0);
+            REPET_MFMA4(x, x)
+            REPET_MFMA4(y, y)
+            REPET_MFMA4(z, z)
+            REPET_MFMA4(w, w)
+#undef REPET_MFMA4
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (kt + 1 < nk) REPET_STORE_TILE(cur ^ 1)
         __syncthreads();
     }
+#undef REPET_LOAD_TILE
+#undef REPET_STORE_TILE
 
     // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
     const int64_t gi0 = (int64_t)bi * kTile + wr * 64;

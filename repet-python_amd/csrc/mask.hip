@@ -11,25 +11,32 @@
 // mask[1..cutoff] = 1 (repet.py:185) and the multiplication into the STFT happen in the same pass.
 #include "common.h"
 
+#include <type_traits>
+
 namespace repet {
 
 #include "median_networks.inc"
 
-// Median of n gathered values with the N-wire network; `load(k)` returns the k-th value (k < n).
+// Median of n gathered values with the N-wire network; `load(k)` returns the k-th value (k < n <= N).
 template <int N, class Load>
 __device__ __forceinline__ float median_network(int n, Load load) {
     float a[N];
-    const int low_pads = (N - n) >> 1;        // -1 pads below, +inf above: medians stay at N/2-1, N/2
+    if (n == N) {                             // full list (the common case): no per-slot branches
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        if (k < n) a[k] = load(k);
-        else a[k] = (k - n < low_pads) ? -1.0f : INFINITY;
+        for (int k = 0; k < N; ++k) a[k] = load(k);
+    } else {
+        const int low_pads = (N - n) >> 1;    // -1 pads below, +inf above: medians stay at N/2-1, N/2
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (k < n) a[k] = load(k);
+            else a[k] = (k - n < low_pads) ? -1.0f : INFINITY;
+        }
     }
     MedianNet<N>::run(a);
     return (n & 1) ? a[N / 2 - 1] : 0.5f * (a[N / 2 - 1] + a[N / 2]);
 }
 
-// Order statistics by bisection over the (non-negative) float bit patterns.
+// Order statistics by bisection over the (non-negative) float bit patterns (lists longer than 128).
 template <class Load>
 __device__ __forceinline__ float median_bisect(int n, Load load) {
     const int k = (n - 1) >> 1;               // lower median rank
@@ -53,21 +60,13 @@ __device__ __forceinline__ float median_bisect(int n, Load load) {
     return 0.5f * (lower + upper);
 }
 
-template <class Load>
-__device__ __forceinline__ float median_select(int n, Load load) {
+// NET = network size compiled into the kernel (0 = bisection). One instantiation per size keeps the
+// register allocation of the small networks small (occupancy) instead of the maximum over all sizes.
+template <int NET, class Load>
+__device__ __forceinline__ float median_of(int n, Load load) {
     if (n <= 0) return __uint_as_float(0x7fc00000u);     // np.median of an empty slice
-    if (n <= 2) return median_network<2>(n, load);
-    if (n <= 4) return median_network<4>(n, load);
-    if (n <= 8) return median_network<8>(n, load);
-    if (n <= 16) return median_network<16>(n, load);
-    if (n <= 24) return median_network<24>(n, load);
-    if (n <= 32) return median_network<32>(n, load);
-    if (n <= 48) return median_network<48>(n, load);
-    if (n <= 64) return median_network<64>(n, load);
-    if (n <= 80) return median_network<80>(n, load);
-    if (n <= 100) return median_network<100>(n, load);
-    if (n <= 128) return median_network<128>(n, load);
-    return median_bisect(n, load);
+    if constexpr (NET == 0) return median_bisect(n, load);
+    else return median_network<NET>(n, load);
 }
 
 __device__ __forceinline__ float soft_mask(float v, float model, int f, int cutoff) {
@@ -83,7 +82,25 @@ __device__ __forceinline__ void emit(const MaskArgs& a, int c, int64_t t, int f,
     if (a.X) { float2 x = a.X[o]; x.x *= m; x.y *= m; a.X[o] = x; }
 }
 
+// Pick the compiled network size for lists of at most `max_n` entries and call fn(integral_constant).
+template <class Fn>
+static void dispatch_net(int max_n, Fn&& fn) {
+    if (max_n <= 2) fn(std::integral_constant<int, 2>{});
+    else if (max_n <= 4) fn(std::integral_constant<int, 4>{});
+    else if (max_n <= 8) fn(std::integral_constant<int, 8>{});
+    else if (max_n <= 16) fn(std::integral_constant<int, 16>{});
+    else if (max_n <= 24) fn(std::integral_constant<int, 24>{});
+    else if (max_n <= 32) fn(std::integral_constant<int, 32>{});
+    else if (max_n <= 48) fn(std::integral_constant<int, 48>{});
+    else if (max_n <= 64) fn(std::integral_constant<int, 64>{});
+    else if (max_n <= 80) fn(std::integral_constant<int, 80>{});
+    else if (max_n <= 100) fn(std::integral_constant<int, 100>{});
+    else if (max_n <= 128) fn(std::integral_constant<int, 128>{});
+    else fn(std::integral_constant<int, 0>{});
+}
+
 // ---- REPET-SIM / online: list of similar frames per frame ----------------------------------------
+template <int NET>
 __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                        const int* __restrict__ count, int64_t first_frame) {
     const int64_t t = blockIdx.x;
@@ -98,24 +115,28 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
     const int64_t r = t - first_frame;
     const int n = count[r];
     const int* list = idx + r * (int64_t)idx_pitch;
+    const unsigned FSu = (unsigned)a.FS;
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
-        const int fc = active ? f : a.F - 1;
-        const float med = median_select(n, [&](int k) { return Vc[(int64_t)list[k] * a.FS + fc]; });
-        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
+        const unsigned fcu = (unsigned)(active ? f : a.F - 1);
+        const float med = median_of<NET>(n, [&](int k) { return Vc[(unsigned)list[k] * FSu + fcu]; });
+        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fcu], med, f, a.cutoff));
     }
 }
 
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
-                           int64_t first_frame, hipStream_t s) {
+                           int64_t first_frame, int32_t max_count, hipStream_t s) {
     if (m.T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mask_sim_kernel, dim3((unsigned)m.T, (unsigned)m.n_channels), dim3(256), 0, s, m, idx,
-                       idx_pitch, count, first_frame);
+    dispatch_net(max_count, [&](auto net) {
+        hipLaunchKernelGGL(mask_sim_kernel<decltype(net)::value>, dim3((unsigned)m.T, (unsigned)m.n_channels),
+                           dim3(256), 0, s, m, idx, idx_pitch, count, first_frame);
+    });
     return hipGetLastError();
 }
 
 // ---- adaptive: taps at i + {..}*period[i] (repet.py:1478-1498) ------------------------------------
+template <int NET>
 __global__ __launch_bounds__(256) void mask_adaptive_kernel(MaskArgs a, const int* __restrict__ periods, int order) {
     const int64_t t = blockIdx.x;
     const int c = blockIdx.y;
@@ -130,27 +151,31 @@ __global__ __launch_bounds__(256) void mask_adaptive_kernel(MaskArgs a, const in
         const int64_t j = t + (int64_t)(first_tap + k) * per;
         if (j >= 0 && j < a.T) { if (n == 0) k_lo = k; ++n; }
     }
-    const int64_t base = t + (int64_t)(first_tap + k_lo) * per;
+    const unsigned b0 = (unsigned)(t + (int64_t)(first_tap + k_lo) * per), pu = (unsigned)per, FSu = (unsigned)a.FS;
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
-        const int fc = active ? f : a.F - 1;
-        const float med = median_select(n, [&](int k) { return Vc[(base + (int64_t)k * per) * a.FS + fc]; });
-        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
+        const unsigned fcu = (unsigned)(active ? f : a.F - 1);
+        const float med = median_of<NET>(n, [&](int k) { return Vc[(b0 + (unsigned)k * pu) * FSu + fcu]; });
+        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fcu], med, f, a.cutoff));
     }
 }
 
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s) {
     if (m.T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mask_adaptive_kernel, dim3((unsigned)m.T, (unsigned)m.n_channels), dim3(256), 0, s, m,
-                       periods, order);
+    dispatch_net(order, [&](auto net) {
+        hipLaunchKernelGGL(mask_adaptive_kernel<decltype(net)::value>, dim3((unsigned)m.T, (unsigned)m.n_channels),
+                           dim3(256), 0, s, m, periods, order);
+    });
     return hipGetLastError();
 }
 
 // ---- original / extended: one median per position q inside the period (repet.py:1401-1446) ---------
 // grid (period_max, C); workgroups with q >= period exit. The model of position q is the median over
 // the segments that really contain frame s*p+q (all S for q < T-(S-1)p, else the first S-1); it is
-// computed once and applied to every segment.
+// computed once and applied to every segment. The period is read on the device, so the network size
+// is chosen for the smallest admissible period (most segments): max_segments = ceil(T / min_period).
+template <int NET>
 __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int* __restrict__ period_dev,
                                                           int period_host) {
     const int p = period_dev ? period_dev[0] : period_host;
@@ -162,27 +187,33 @@ __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int*
     const float* Vc = a.V + c * a.chan_stride;
     const int S = (int)((a.T + p - 1) / p);
     const int n = (q < a.T - (int64_t)(S - 1) * p) ? S : S - 1;     // segments holding real data at q
+    const unsigned FSu = (unsigned)a.FS, pu = (unsigned)p, qu = (unsigned)q;
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
-        const int fc = active ? f : a.F - 1;
-        const float med = median_select(n, [&](int k) { return Vc[((int64_t)k * p + q) * a.FS + fc]; });
+        const unsigned fcu = (unsigned)(active ? f : a.F - 1);
+        const float med = median_of<NET>(n, [&](int k) { return Vc[((unsigned)k * pu + qu) * FSu + fcu]; });
         if (active)
             for (int s = 0; s < n; ++s) {
                 const int64_t t = (int64_t)s * p + q;
-                emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
+                emit(a, c, t, f, soft_mask(Vc[t * a.FS + fcu], med, f, a.cutoff));
             }
     }
 }
 
-hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host, hipStream_t s) {
+hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
+                              int32_t min_period, hipStream_t s) {
     if (m.T <= 0) return hipSuccess;
     // the period lives on the device when it was just estimated there; the grid covers the largest
     // admissible period (a third of the frames, repet.py:1266) and surplus workgroups exit
     unsigned gx = period_dev ? (unsigned)(m.T / 3 + 2) : (unsigned)period_host;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(mask_period_kernel, dim3(gx, (unsigned)m.n_channels), dim3(256), 0, s, m, period_dev,
-                       period_host);
+    const int pmin = period_dev ? (min_period > 0 ? min_period : 1) : period_host;
+    const int max_segments = (int)((m.T + pmin - 1) / pmin);
+    dispatch_net(max_segments, [&](auto net) {
+        hipLaunchKernelGGL(mask_period_kernel<decltype(net)::value>, dim3(gx, (unsigned)m.n_channels), dim3(256), 0, s,
+                           m, period_dev, period_host);
+    });
     return hipGetLastError();
 }
 
