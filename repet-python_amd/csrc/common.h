@@ -80,7 +80,12 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
 struct MaskArgs {
     const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t F, FS;
     float2* X; float* mask; int32_t cutoff;
+    int64_t pad_row;   // rows pad_row / pad_row+1 of every channel of V hold -1.0f / +inf (median pads)
 };
+constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
+constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
+hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
+                                hipStream_t s);
 // max_count / min_period bound the list length so the launcher can pick the smallest compiled network.
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s);

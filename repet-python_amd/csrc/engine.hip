@@ -81,6 +81,7 @@ struct repet_ctx {
     int32_t last_n_periods = 0;
     int64_t last_idx_rows = 0;
     int32_t last_idx_pitch = 0;
+    int32_t last_idx_number = 0;
     // timing
     std::vector<hipEvent_t> events;
     repet_timing* timing = nullptr;
@@ -177,13 +178,15 @@ struct Geo {
 Geo make_geo(int W, int H, int64_t T, int C) {
     Geo g;
     g.W = W; g.H = H; g.F = W / 2 + 1; g.FS = (int)round_up(g.F, kFreqAlign);
-    g.T = T; g.Tpad = round_up(T > 0 ? T : 1, kTile); g.chan_stride = g.Tpad * g.FS; g.C = C;
+    g.T = T; g.Tpad = round_up(T > 0 ? T : 1, kTile); g.chan_stride = (g.Tpad + kPadRows) * g.FS; g.C = C;
     return g;
 }
 
 int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p) {
     HIP_TRY(c->X.ensure((size_t)g.C * g.chan_stride * sizeof(float2)));
     HIP_TRY(c->V.ensure((size_t)g.C * g.chan_stride * sizeof(float)));
+    if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
+    HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, g.C, g.Tpad, g.FS, c->stream));
     const size_t row_bytes = (size_t)g.FS * sizeof(float);
     if (want_vn) {
         HIP_TRY(c->Vn.ensure((size_t)g.chan_stride * sizeof(float)));
@@ -212,7 +215,7 @@ int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64
 MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
     MaskArgs m{};
     m.V = c->V.as<float>(); m.chan_stride = g.chan_stride; m.n_channels = g.C; m.T = g.T; m.F = g.F; m.FS = g.FS;
-    m.X = c->X.as<float2>(); m.mask = nullptr; m.cutoff = cutoff;
+    m.X = c->X.as<float2>(); m.mask = nullptr; m.cutoff = cutoff; m.pad_row = g.Tpad;
     return m;
 }
 
@@ -354,20 +357,20 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
     HIP_TRY(launch_gram_full(c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, c->stream));
     mark(c, "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T, 2.0 * g.F * (double)T * T);
-    const int K = p->sim_number;
-    HIP_TRY(c->idx.ensure((size_t)T * K * sizeof(int32_t)));
+    const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
+    HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
     hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
-                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), c->stream);
+                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
     HIP_TRY(e);
     mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
     // peaks are more than d frames apart: at most ceil(T/(d+1)) of them, whatever similarity_number says
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), 0, max_peaks, c->stream));
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream));
     mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
-    c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = K;
+    c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = KP; c->last_idx_number = K;
     return REPET_OK;
 }
 
@@ -388,20 +391,20 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
     HIP_TRY(launch_gram_band(c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, c->stream));
     mark(c, "similarity_band", 4.0 * g.F * T + 4.0 * T * B, 2.0 * g.F * (double)T * B);
-    const int K = p->sim_number;
+    const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;
-    HIP_TRY(c->idx.ensure((size_t)std::max<int64_t>(rows, 1) * K * sizeof(int32_t)));
+    HIP_TRY(c->idx.ensure((size_t)std::max<int64_t>(rows, 1) * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)std::max<int64_t>(rows, 1) * sizeof(int32_t)));
     hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
-                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), c->stream);
+                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
     HIP_TRY(e);
     mark(c, "local_maxima", 4.0 * rows * B + 4.0 * K * rows, 0);
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), K, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream));
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream));
     mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
     RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
-    c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = K;
+    c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = KP; c->last_idx_number = K;
     return REPET_OK;
 }
 
@@ -784,12 +787,13 @@ int repet_local_maxima(repet_ctx* c, const float* m, int32_t n_rows, int32_t n_c
 
 static int stage_mask_common(repet_ctx* c, const float* v, int64_t T, int F, MaskArgs* m, int* FS_out) {
     const int FS = (int)round_up(F, kFreqAlign);
-    RP_TRY(stage_matrix_in(c, c->V, v, T, F, FS, T));
+    RP_TRY(stage_matrix_in(c, c->V, v, T, F, FS, T + kPadRows));
+    HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), (T + kPadRows) * FS, 1, T, FS, c->stream));
     HIP_TRY(c->tmp_c.ensure((size_t)T * FS * sizeof(float)));
     HIP_TRY(hipMemsetAsync(c->tmp_c.p, 0, (size_t)T * FS * sizeof(float), c->stream));
     *m = MaskArgs{};
-    m->V = c->V.as<float>(); m->chan_stride = T * FS; m->n_channels = 1; m->T = T; m->F = F; m->FS = FS;
-    m->X = nullptr; m->mask = c->tmp_c.as<float>(); m->cutoff = 0;
+    m->V = c->V.as<float>(); m->chan_stride = (T + kPadRows) * FS; m->n_channels = 1; m->T = T; m->F = F; m->FS = FS;
+    m->X = nullptr; m->mask = c->tmp_c.as<float>(); m->cutoff = 0; m->pad_row = T;
     *FS_out = FS;
     return REPET_OK;
 }
@@ -823,11 +827,14 @@ int repet_mask_sim(repet_ctx* c, const float* v, int64_t T, int32_t F, const int
     DeviceGuard guard(c->device);
     MaskArgs m; int FS;
     RP_TRY(stage_mask_common(c, v, T, F, &m, &FS));
-    HIP_TRY(c->idx.ensure((size_t)T * number * sizeof(int32_t)));
+    const int KP = std::max(number, kMinIdxPitch);
+    HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(c->idx.p, idx, (size_t)T * number * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->idx.p, 0, (size_t)T * KP * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemcpy2DAsync(c->idx.p, (size_t)KP * sizeof(int32_t), idx, (size_t)number * sizeof(int32_t),
+                             (size_t)number * sizeof(int32_t), T, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->cnt.p, count, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), 0, number, c->stream));
+    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, number, c->stream));
     return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
 }
 
@@ -842,10 +849,11 @@ int repet_ctx_last_periods(repet_ctx* c, int32_t* out, int32_t capacity, int32_t
 
 int repet_ctx_last_sim_indices(repet_ctx* c, int32_t* idx_out, int32_t* count_out, int32_t n_rows, int32_t number) {
     if (!c || !idx_out || !count_out) return fail(REPET_ERR_BAD_ARG, "null argument");
-    if (n_rows != c->last_idx_rows || number != c->last_idx_pitch) return fail(REPET_ERR_BAD_ARG, "shape does not match the last run");
+    if (n_rows != c->last_idx_rows || number != c->last_idx_number) return fail(REPET_ERR_BAD_ARG, "shape does not match the last run");
     DeviceGuard guard(c->device);
     if (n_rows > 0) {
-        HIP_TRY(hipMemcpy(idx_out, c->idx.p, (size_t)n_rows * number * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(idx_out, (size_t)number * sizeof(int32_t), c->idx.p, (size_t)c->last_idx_pitch * sizeof(int32_t),
+                            (size_t)number * sizeof(int32_t), n_rows, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(count_out, c->cnt.p, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
     return REPET_OK;

@@ -3,7 +3,7 @@
 //
 // Spectrograms are frame-major V[c][t][FS], so "the same 64 frequency bins of frame idx[k]" is one
 // coalesced 256-byte read per wave. A wave owns 64 consecutive bins of one frame; every lane gathers
-// its <= 128 values into registers (the index list is wave-uniform, so the row bases sit in SGPRs),
+// its <= 128 values into registers (the index list is wave-uniform, so the row offsets sit in SGPRs),
 // runs a pruned odd-even merge-sort network (median_networks.inc) and reads the two middle order
 // statistics; np.median's even/odd rule and its NaN for an empty list are reproduced. Lists longer
 // than 128 fall back to a 31-step bisection on the float bit patterns that re-reads the values.
@@ -17,21 +17,16 @@ namespace repet {
 
 #include "median_networks.inc"
 
-// Median of n gathered values with the N-wire network; `load(k)` returns the k-th value (k < n <= N).
+// Median of n gathered values with the N-wire network. `load(k)` must return the k-th value for
+// k < n and, for n <= k < N, the pad of slot k: -1.0f for the first (N-n)/2 pad slots, +inf for the
+// rest, which keeps the two middle order statistics of the n real values at wires N/2-1 and N/2.
+// (The kernels fetch the pads from two constant rows behind each channel's spectrogram, selected
+// with scalar arithmetic, so there is ONE branch-free gather whatever the list length.)
 template <int N, class Load>
 __device__ __forceinline__ float median_network(int n, Load load) {
     float a[N];
-    if (n == N) {                             // full list (the common case): no per-slot branches
 #pragma unroll
-        for (int k = 0; k < N; ++k) a[k] = load(k);
-    } else {
-        const int low_pads = (N - n) >> 1;    // -1 pads below, +inf above: medians stay at N/2-1, N/2
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (k < n) a[k] = load(k);
-            else a[k] = (k - n < low_pads) ? -1.0f : INFINITY;
-        }
-    }
+    for (int k = 0; k < N; ++k) a[k] = load(k);
     MedianNet<N>::run(a);
     return (n & 1) ? a[N / 2 - 1] : 0.5f * (a[N / 2 - 1] + a[N / 2]);
 }
@@ -69,6 +64,25 @@ __device__ __forceinline__ float median_of(int n, Load load) {
     else return median_network<NET>(n, load);
 }
 
+// Row gather through a buffer resource: one shared per-lane VGPR offset (the bin) plus a wave-uniform
+// SGPR offset per row (buffer_load_dword v, v_bin, s[rsrc], s_row offen) -- no per-row address VGPRs.
+struct RowGather {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int bin_bytes;
+    __device__ __forceinline__ float operator()(int row_bytes_offset) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, bin_bytes, row_bytes_offset, 0));
+    }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t channel_rsrc(const float* Vc, int64_t chan_stride) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vc), 0, (int)(chan_stride * 4), 0x00020000);
+}
+// byte offset of the pad row for network slot k >= n (wave-uniform)
+template <int NET>
+__device__ __forceinline__ int pad_offset(int k, int n, int pad_row_bytes, int row_bytes) {
+    const int low_pads = (NET - n) >> 1;
+    return pad_row_bytes + ((k - n < low_pads) ? 0 : row_bytes);
+}
+
 __device__ __forceinline__ float soft_mask(float v, float model, int f, int cutoff) {
     const float m = (fminf(v, model) + kMaskEps) / (v + kMaskEps);
     // fminf drops a NaN model; np.minimum propagates it (empty similarity list -> NaN frame)
@@ -99,6 +113,20 @@ static void dispatch_net(int max_n, Fn&& fn) {
     else fn(std::integral_constant<int, 0>{});
 }
 
+__global__ void fill_pad_rows_kernel(float* V, int64_t chan_stride, int64_t pad_row, int FS) {
+    const int c = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * FS) return;
+    V[c * chan_stride + pad_row * FS + k] = (k < FS) ? -1.0f : INFINITY;
+}
+
+hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)ceil_div(2 * FS, 256), (unsigned)n_channels), dim3(256), 0, s,
+                       V, chan_stride, pad_row, FS);
+    return hipGetLastError();
+}
+
 // ---- REPET-SIM / online: list of similar frames per frame ----------------------------------------
 template <int NET>
 __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
@@ -115,13 +143,20 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
     const int64_t r = t - first_frame;
     const int n = count[r];
     const int* list = idx + r * (int64_t)idx_pitch;
-    const unsigned FSu = (unsigned)a.FS;
+    const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
+    RowGather g{channel_rsrc(Vc, a.chan_stride), 0};
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
-        const unsigned fcu = (unsigned)(active ? f : a.F - 1);
-        const float med = median_of<NET>(n, [&](int k) { return Vc[(unsigned)list[k] * FSu + fcu]; });
-        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fcu], med, f, a.cutoff));
+        const int fc = active ? f : a.F - 1;
+        g.bin_bytes = fc * 4;
+        // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the loop; hoisted, hipcc
+        // parks all NET offsets in VGPRs and halves the occupancy
+        int n_it = n;
+        asm volatile("" : "+s"(n_it));
+        const float med = median_of<NET>(n_it, [&](int k) {
+            return g(k < n_it ? list[k] * row_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
+        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
     }
 }
 
@@ -151,13 +186,21 @@ __global__ __launch_bounds__(256) void mask_adaptive_kernel(MaskArgs a, const in
         const int64_t j = t + (int64_t)(first_tap + k) * per;
         if (j >= 0 && j < a.T) { if (n == 0) k_lo = k; ++n; }
     }
-    const unsigned b0 = (unsigned)(t + (int64_t)(first_tap + k_lo) * per), pu = (unsigned)per, FSu = (unsigned)a.FS;
+    const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
+    const int base_bytes = (int)(t + (int64_t)(first_tap + k_lo) * per) * row_bytes, step_bytes = (int)per * row_bytes;
+    RowGather g{channel_rsrc(Vc, a.chan_stride), 0};
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
-        const unsigned fcu = (unsigned)(active ? f : a.F - 1);
-        const float med = median_of<NET>(n, [&](int k) { return Vc[(b0 + (unsigned)k * pu) * FSu + fcu]; });
-        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fcu], med, f, a.cutoff));
+        const int fc = active ? f : a.F - 1;
+        g.bin_bytes = fc * 4;
+        // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the loop; hoisted, hipcc
+        // parks all NET offsets in VGPRs and halves the occupancy
+        int n_it = n;
+        asm volatile("" : "+s"(n_it));
+        const float med = median_of<NET>(n_it, [&](int k) {
+            return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
+        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
     }
 }
 
@@ -187,16 +230,24 @@ __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int*
     const float* Vc = a.V + c * a.chan_stride;
     const int S = (int)((a.T + p - 1) / p);
     const int n = (q < a.T - (int64_t)(S - 1) * p) ? S : S - 1;     // segments holding real data at q
-    const unsigned FSu = (unsigned)a.FS, pu = (unsigned)p, qu = (unsigned)q;
+    const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
+    const int base_bytes = q * row_bytes, step_bytes = p * row_bytes;
+    RowGather g{channel_rsrc(Vc, a.chan_stride), 0};
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
-        const unsigned fcu = (unsigned)(active ? f : a.F - 1);
-        const float med = median_of<NET>(n, [&](int k) { return Vc[((unsigned)k * pu + qu) * FSu + fcu]; });
+        const int fc = active ? f : a.F - 1;
+        g.bin_bytes = fc * 4;
+        // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the loop; hoisted, hipcc
+        // parks all NET offsets in VGPRs and halves the occupancy
+        int n_it = n;
+        asm volatile("" : "+s"(n_it));
+        const float med = median_of<NET>(n_it, [&](int k) {
+            return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
         if (active)
             for (int s = 0; s < n; ++s) {
                 const int64_t t = (int64_t)s * p + q;
-                emit(a, c, t, f, soft_mask(Vc[t * a.FS + fcu], med, f, a.cutoff));
+                emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
             }
     }
 }
