@@ -10,8 +10,10 @@
 // log2(w) in-place passes M[p] = max(M[p], M[p+step]) leave M[p] = max(v[p .. p+w-1]) with
 // w = 2^floor(log2 d) > d/2, so each clipped window is the union of two overlapping w-windows:
 //   left  = max(M[p-d], M[p-w]),  right = max(M[p+1], M[p+d-w+1]).
-// Every thread keeps its own elements in registers, so the test costs 4 LDS reads per element and
-// the whole row about 20 LDS accesses per element, with no data-dependent loop.
+// Everything moves in float4: 16-byte global loads and ds_read/write_b128, the first two doubling steps
+// are done in registers from a thread's own group and its right neighbour, and the later steps are
+// aligned float4 shifts. Every thread keeps its own elements in registers, so the final test costs
+// 4 LDS reads per element and there is no data-dependent loop.
 // Survivors are compacted with one LDS atomic per wave and ranked by counting (value descending,
 // higher index first on exact ties) so the top `number` land in idx[row][0..count) already sorted.
 #include "common.h"
@@ -31,90 +33,127 @@ __device__ __forceinline__ int wave_prefix_slot(bool flag, int* counter, int lan
 
 struct PeakArgs {
     const float* M; int64_t row0; int n; int64_t pitch; int mode; float min_value; int d; int number;
-    int* idx; int idx_pitch; int* count; int lp; int peak_cap;
+    int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap;
 };
 
-// JMAX: padded elements per thread (lp = n + 2d <= 256*JMAX). KEEP: originals stay in registers.
-template <int JMAX, bool KEEP>
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float nan_to_inf(float v) { return (v != v) ? INFINITY : v; }
+
+// The padded row lives in LDS as `groups` float4: dl = round_up(d,4) "-inf" pads, the n values, then
+// "-inf" up to the end (at least d + 4 of them). Thread `tid` owns groups tid + 256*q, q < QMAX, and
+// keeps their original values in registers.
+template <int QMAX>
 __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* M = smem;                                           // lp floats (padded row, then window maxima)
-    float* pval = smem + a.lp;                                 // peak_cap
+    float4* M4 = reinterpret_cast<float4*>(smem);              // groups float4 (row, then window maxima)
+    float* M = smem;
+    float* pval = smem + 4 * a.groups;                         // peak_cap (multiple of 4)
     int* pidx = reinterpret_cast<int*>(pval + a.peak_cap);     // peak_cap
     __shared__ int n_peak;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int n = a.n, d = a.d, lp = a.lp;
+    const int n = a.n, d = a.d, dl = a.dl, groups = a.groups;
     const int64_t r = blockIdx.x;           // row within this launch
     const int64_t j = a.row0 + r;           // absolute row (mode 1: current frame)
     if (tid == 0) n_peak = 0;
 
-    // element q of this thread sits at padded position p = tid + 256*q; real index i = p - d
-    auto fetch = [&](int i) -> float {
-        float v;
-        if (a.mode == 0) {
-            v = a.M[j * a.pitch + i];
-        } else {   // circular-buffer order of the online variant: column c holds frame j - ((j - c) mod B)
-            int l = (int)((j - i) % n);
-            if (l < 0) l += n;
-            v = a.M[(j - l) * a.pitch + l];
-        }
-        return (v != v) ? INFINITY : v;
+    auto fetch = [&](int i) -> float {      // element i of the row, -inf outside [0, n)
+        if (i < 0 || i >= n) return -INFINITY;
+        if (a.mode == 0) return nan_to_inf(a.M[j * a.pitch + i]);
+        // circular-buffer order of the online variant: column c holds frame j - ((j - c) mod B)
+        int l = (int)(j - i) % n;
+        if (l < 0) l += n;
+        return nan_to_inf(a.M[(j - l) * a.pitch + l]);
     };
 
-    float own[KEEP ? JMAX : 1];
+    const bool vec_ok = (a.mode == 0) && ((a.pitch & 3) == 0);
+    const float* src = a.M + j * a.pitch;
+    float4 own[QMAX];
 #pragma unroll
-    for (int q = 0; q < JMAX; ++q) {
-        const int p = tid + 256 * q;
-        if (p < lp) {
-            const int i = p - d;
-            const float v = (i >= 0 && i < n) ? fetch(i) : -INFINITY;
-            if constexpr (KEEP) own[q] = v;
-            M[p] = v;
+    for (int q = 0; q < QMAX; ++q) {
+        const int g = tid + 256 * q;
+        if (g < groups) {
+            const int i0 = 4 * g - dl;
+            float4 v;
+            if (vec_ok && i0 >= 0 && i0 + 3 < n) {
+                v = *reinterpret_cast<const float4*>(src + i0);
+                v = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
+            } else {
+                v = make_float4(fetch(i0), fetch(i0 + 1), fetch(i0 + 2), fetch(i0 + 3));
+            }
+            own[q] = v;
+            M4[g] = v;
         }
     }
     __syncthreads();
 
     int w = 1;
     while (2 * w <= d) w *= 2;              // w = 2^floor(log2 d) (1 when d <= 1)
-    for (int step = 1; step < w; step *= 2) {
-        float tmp[JMAX];
+    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (w >= 2) {
+        // steps 1 (and 2) in registers: windows of min(w,4) starting at each of the thread's elements
+        float4 tmp[QMAX];
 #pragma unroll
-        for (int q = 0; q < JMAX; ++q) {
-            const int p = tid + 256 * q;
-            if (p < lp) {
-                const float x = M[p];
-                tmp[q] = (p + step < lp) ? fmaxf(x, M[p + step]) : x;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < JMAX; ++q) {
-            const int p = tid + 256 * q;
-            if (p < lp) M[p] = tmp[q];
-        }
-        __syncthreads();
-    }
-
-    // strict local-maximum test and compaction of the survivors
-#pragma unroll
-    for (int q = 0; q < JMAX; ++q) {
-        const int p = tid + 256 * q;
-        const int i = p - d;
-        bool ok = false;
-        float v = 0.f;
-        if (256 * q < lp) {                 // wave-uniform guard: whole rounds past the row are skipped
-            if (p < lp && i >= 0 && i < n) {
-                if constexpr (KEEP) v = own[q]; else v = fetch(i);
-                ok = (v >= a.min_value) && (v < INFINITY);
-                if (d > 0) {
-                    const float left = fmaxf(M[p - d], M[p - w]);
-                    const float right = fmaxf(M[p + 1], M[p + d - w + 1]);
-                    ok = ok && (v > left) && (v > right);
+        for (int q = 0; q < QMAX; ++q) {
+            const int g = tid + 256 * q;
+            if (g < groups) {
+                const float4 x = own[q];
+                const float4 y = (g + 1 < groups) ? M4[g + 1] : ninf;
+                const float p01 = fmaxf(x.x, x.y), p12 = fmaxf(x.y, x.z), p23 = fmaxf(x.z, x.w), p34 = fmaxf(x.w, y.x);
+                if (w == 2) tmp[q] = make_float4(p01, p12, p23, p34);
+                else {
+                    const float p45 = fmaxf(y.x, y.y), p56 = fmaxf(y.y, y.z);
+                    tmp[q] = make_float4(fmaxf(p01, p23), fmaxf(p12, p34), fmaxf(p23, p45), fmaxf(p34, p56));
                 }
             }
-            const int slot = wave_prefix_slot(ok, &n_peak, lane);
-            if (ok && slot < a.peak_cap) { pval[slot] = v; pidx[slot] = i; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const int g = tid + 256 * q;
+            if (g < groups) M4[g] = tmp[q];
+        }
+        __syncthreads();
+        for (int gs = 1; 4 * gs < w; gs *= 2) {     // steps 4, 8, ...: aligned float4 shifts
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                const int g = tid + 256 * q;
+                if (g < groups) tmp[q] = (g + gs < groups) ? max4(M4[g], M4[g + gs]) : M4[g];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                const int g = tid + 256 * q;
+                if (g < groups) M4[g] = tmp[q];
+            }
+            __syncthreads();
+        }
+    }
+
+    // strict local-maximum test; survivors are compacted with one LDS atomic per wave and element slot
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const int g = tid + 256 * q;
+        if (256 * q < groups) {             // wave-uniform guard
+            const float vals[4] = {own[q].x, own[q].y, own[q].z, own[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int p = 4 * g + e;
+                const int i = p - dl;
+                const float v = vals[e];
+                bool ok = (g < groups) && i >= 0 && i < n && (v >= a.min_value) && (v < INFINITY);
+                if (d > 0 && ok) {
+                    const float left = fmaxf(M[p - d], M[p - w]);
+                    const float right = fmaxf(M[p + 1], M[p + d - w + 1]);
+                    ok = (v > left) && (v > right);
+                }
+                if (__any(ok)) {            // peaks are rare: most (wave, slot) pairs skip the compaction
+                    const int slot = wave_prefix_slot(ok, &n_peak, lane);
+                    if (ok && slot < a.peak_cap) { pval[slot] = v; pidx[slot] = i; }
+                }
+            }
         }
     }
     __syncthreads();
@@ -123,19 +162,26 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
     int np_ = n_peak;
     if (np_ > a.peak_cap) np_ = a.peak_cap;
     const int kept = np_ < a.number ? np_ : a.number;
+    for (int k = np_ + tid; k < ((np_ + 3) & ~3); k += 256) pval[k] = -INFINITY;   // pad to a float4 boundary
+    __syncthreads();
     int* out = a.idx + r * (int64_t)a.idx_pitch;
+    const float4* pv4 = reinterpret_cast<const float4*>(pval);
     for (int p = tid; p < np_; p += 256) {
         const float v = pval[p];
         const int i = pidx[p];
         int rank = 0;
-        for (int q = 0; q < np_; ++q) {
-            const float u = pval[q];
-            rank += (u > v) || (u == v && pidx[q] > i);
+        for (int q4 = 0; 4 * q4 < np_; ++q4) {
+            const float4 u = pv4[q4];
+            rank += (u.x > v) + (u.y > v) + (u.z > v) + (u.w > v);
+            if (u.x == v || u.y == v || u.z == v || u.w == v) {     // exact ties: rare
+                rank += (u.x == v && pidx[4 * q4] > i) + (u.y == v && pidx[4 * q4 + 1] > i) +
+                        (u.z == v && pidx[4 * q4 + 2] > i) + (u.w == v && pidx[4 * q4 + 3] > i);
+            }
         }
         if (rank < a.number) {
             int o = i;
             if (a.mode == 1) {
-                int l = (int)((j - i) % n);
+                int l = (int)(j - i) % n;
                 if (l < 0) l += n;
                 o = (int)(j - l);
             }
@@ -146,12 +192,12 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
     if (tid == 0) a.count[r] = kept;
 }
 
-template <int JMAX, bool KEEP>
+template <int QMAX>
 static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, size_t bytes, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&local_maxima_kernel<JMAX, KEEP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&local_maxima_kernel<QMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((local_maxima_kernel<JMAX, KEEP>), dim3((unsigned)n_rows), dim3(256), bytes, s, a);
+    hipLaunchKernelGGL((local_maxima_kernel<QMAX>), dim3((unsigned)n_rows), dim3(256), bytes, s, a);
     return hipGetLastError();
 }
 
@@ -163,18 +209,18 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
     PeakArgs a{};
     a.M = M; a.row0 = row0; a.n = n_cols; a.pitch = pitch; a.mode = mode; a.min_value = min_value; a.d = d;
     a.number = number; a.idx = idx; a.idx_pitch = idx_pitch; a.count = count;
-    a.lp = n_cols + 2 * d;
-    a.peak_cap = (d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1);         // peaks are more than d apart
-    const size_t bytes = (size_t)(a.lp + 2 * a.peak_cap) * 4;
-    const int per_thread = (int)ceil_div(a.lp, 256);
-    if (bytes > 160 * 1024 - 64 || per_thread > 128) return hipErrorInvalidValue;
-    if (per_thread <= 2) return launch_one<2, true>(a, n_rows, bytes, s);
-    if (per_thread <= 4) return launch_one<4, true>(a, n_rows, bytes, s);
-    if (per_thread <= 8) return launch_one<8, true>(a, n_rows, bytes, s);
-    if (per_thread <= 16) return launch_one<16, true>(a, n_rows, bytes, s);
-    if (per_thread <= 32) return launch_one<32, true>(a, n_rows, bytes, s);
-    if (per_thread <= 64) return launch_one<64, true>(a, n_rows, bytes, s);
-    return launch_one<128, false>(a, n_rows, bytes, s);
+    a.dl = (int)round_up(d, 4);
+    a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 1);
+    a.peak_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart
+    const size_t bytes = (size_t)(4 * a.groups + 2 * a.peak_cap) * 4;
+    const int per_thread = (int)ceil_div(a.groups, 256);
+    if (bytes > 160 * 1024 - 64 || per_thread > 32) return hipErrorInvalidValue;
+    if (per_thread <= 1) return launch_one<1>(a, n_rows, bytes, s);
+    if (per_thread <= 2) return launch_one<2>(a, n_rows, bytes, s);
+    if (per_thread <= 4) return launch_one<4>(a, n_rows, bytes, s);
+    if (per_thread <= 8) return launch_one<8>(a, n_rows, bytes, s);
+    if (per_thread <= 16) return launch_one<16>(a, n_rows, bytes, s);
+    return launch_one<32>(a, n_rows, bytes, s);
 }
 
 }  // namespace repet

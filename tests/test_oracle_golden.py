@@ -99,3 +99,28 @@ def test_localmaxima_matches_definition():
         order = np.argsort(v[want])[::-1][:k]
         vals, idx = orc.localmaxima(v, 0.2, d, k)
         assert np.array_equal(idx, want[order])
+
+
+# ---- BASELINE.json config sizes: oracle vs the reference's strided samples and integer intermediates ----
+CONFIG_CASES = [("cfg5_simonline", "simonline"), ("cfg4_adaptive", "adaptive"), ("cfg3_extended", "extended")]
+if __import__("os").environ.get("REPET_FULL_GOLDEN") == "1":      # 180-s sim: ~1.5 CPU-minutes for the oracle
+    CONFIG_CASES += [("cfg2_sim", "sim"), ("cfg2_sim", "original")]
+
+
+@pytest.mark.parametrize("case,algo", CONFIG_CASES)
+def test_config_size_goldens(case, algo):
+    y, tr, g = _run(case, algo)
+    stride = int(g["sample_stride"])
+    assert np.max(np.abs(y[::stride] - g[f"{algo}.samples"])) <= TOL
+    fs = int(g["fs"])
+    n = (len(y) // fs) * fs
+    per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, y.shape[1]) ** 2, axis=1))
+    assert np.max(np.abs(per_s - g[f"{algo}.rms_per_second"])) <= 1e-9
+    if algo == "adaptive":
+        assert np.array_equal(tr["repeating_periods"], g["adaptive.periods"])
+    if algo == "extended":
+        assert np.array_equal(tr["segment_periods"], g["extended.periods"]) and len(g["extended.periods"]) == 119
+    if algo == "simonline":
+        assert np.array_equal(np.array([len(ix) for ix in tr["similarity_indices"]]), g["simonline.counts"])
+    if algo == "sim":
+        assert np.array_equal(np.array([len(ix) for ix in tr["similarity_indices"]]), g["sim.counts"])
