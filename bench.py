@@ -56,10 +56,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=180.0, help="clip length in seconds (config 2: 180)")
     ap.add_argument("--algo", default="sim")
+    ap.add_argument("--fs", type=int, default=44100)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=1, help="independent clips per rank and step (config 5: 64 in total)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[i-1]: 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz mono, "
+                         "5 simonline 30-s clips (64 over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="length of the CPU-baseline sample clip")
     args = ap.parse_args()
 
+    if args.config == 3:
+        args.algo, args.duration = "extended", 600.0
+    elif args.config == 4:
+        args.algo, args.duration, args.fs, args.channels = "adaptive", 300.0, 48000, 1
+    elif args.config == 5:
+        args.algo, args.duration = "simonline", 30.0
+        args.clips = max(1, 64 // max(args.gpus, 1))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,11 +92,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    fs, channels = 44100, 2
-    clip = synth(args.duration, fs, channels, seed=rank)
+    fs, channels = args.fs, args.channels
     params = repet.derive_params(fs)
-    ctx = repet.Context(local_rank)
-    ctx.upload(clip)                      # input resident in HBM (fp32, interleaved) before timing starts
+    ctxs = []
+    for k in range(args.clips):           # inputs resident in HBM (fp32, interleaved) before timing starts
+        clip = synth(args.duration, fs, channels, seed=rank * args.clips + k)
+        ctx = repet.Context(local_rank)
+        ctx.upload(clip)
+        ctxs.append(ctx)
 
     def barrier():
         if dist is not None:
@@ -91,15 +107,17 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ctx.execute(args.algo, params)
+        for ctx in ctxs:
+            ctx.execute(args.algo, params)
     stage_ms, stage_meta = {}, {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tm = ctx.execute(args.algo, params, timing=True)     # blocks until the stream is idle
-        for s in tm["stages"]:
-            stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
-            stage_meta[s["name"]] = s
+        for ctx in ctxs:
+            tm = ctx.execute(args.algo, params, timing=True)     # blocks until the stream is idle
+            for s in tm["stages"]:
+                stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
+                stage_meta[s["name"]] = s
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -107,11 +125,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    out = ctx.download()
+    out = ctxs[-1].download()
     assert out.shape == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
 
     if rank == 0:
-        steps = max(args.steps, 1)
+        steps = max(args.steps, 1) * args.clips      # stage figures are per clip
         stages = []
         for name, total in stage_ms.items():
             ms = total / steps
@@ -133,16 +151,16 @@ def main():
         roof["ms_per_launch"] = dom["ms"]
         roof["algorithmic_per_launch"] = meta["flops"] if roof["bound"] == "mfma" else meta["bytes"]
         line = {
-            "metric": f"audio-seconds/sec (x real-time) for repet.{args.algo}, 44.1 kHz stereo",
-            "value": round(args.duration * args.steps * world / elapsed, 2),
+            "metric": f"audio-seconds/sec (x real-time) for repet.{args.algo}, {fs / 1000:g} kHz {'stereo' if channels == 2 else str(channels) + '-ch'}",
+            "value": round(args.duration * args.clips * args.steps * world / elapsed, 2),
             "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"repet.{args.algo} on one {args.duration:g}-s 44.1 kHz stereo synthetic clip per GPU "
-                                   f"(BASELINE.json configs[1]), clip resident in HBM",
-                       "clips_per_step": world, "samples_per_clip": int(clip.shape[0]), "channels": channels,
+            "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch synthetic clip(s) per GPU "
+                                   f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
+                       "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
                        "frames": int(ctx.last_frame_count()), "parallelism": f"clip-parallel x{world}, no collective"},
             "roofline": roof,
             "stages": stages,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace repet {
 
@@ -47,11 +48,16 @@ struct OlaArgs {
 };
 hipError_t launch_overlap_add(const OlaArgs& a, hipStream_t s);
 
+// Tile list for the Gram kernels: upper-triangle 128x128 tiles with bj - bi < ndiag (ndiag = nb: all),
+// ordered for XCD locality; returns the padded list length (a multiple of 8).
+int gram_tile_list(int nb, int ndiag, std::vector<int2>* out);
+inline int gram_band_diagonals(int n_lags) { return (n_lags + 126) / kTile + 1; }
 // K3: S[T][TS] = A A^T for A[Tpad][FS] fp32 (rows >= T are zero), MFMA fp32, upper tiles mirrored.
-hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, hipStream_t s);
+hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, const int2* tiles,
+                            int32_t n_tiles, hipStream_t s);
 // K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
-hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags,
-                            int32_t LP, hipStream_t s);
+hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
+                            const int2* tiles, int32_t n_tiles, hipStream_t s);
 
 // Windowed diagonal sums of the band: beat[w][l] = sum_{t=lo_w}^{hi_w - l} band[t][l] / ((len - l) * F)
 //   window w covers frames [start0 + w*step, start0 + w*step + len) clipped to [0,T).

@@ -75,6 +75,8 @@ struct repet_ctx {
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
     std::map<int, std::unique_ptr<Tables>> tables;
+    DevBuf tiles;                 // Gram tile list of the last (nb, ndiag)
+    int tiles_nb = -1, tiles_ndiag = -1, tiles_count = 0;
     // last run
     int last_algo = -1;
     int64_t last_T = 0;
@@ -128,6 +130,37 @@ int upload_twiddle_only(repet_ctx* c, int W, const float2** tw) {
     Tables* t = nullptr;
     RP_TRY(get_tables(c, W, &t));
     *tw = t->twiddle.as<float2>();
+    return REPET_OK;
+}
+
+// device tile list for nb tile rows and ndiag diagonals (cached per context)
+int get_tiles(repet_ctx* c, int64_t T, int ndiag, const int2** tiles, int* count) {
+    const int nb = (int)ceil_div(T, kTile);
+    if (ndiag > nb) ndiag = nb;
+    if (c->tiles_nb != nb || c->tiles_ndiag != ndiag) {
+        std::vector<int2> host;
+        const int n = gram_tile_list(nb, ndiag, &host);
+        HIP_TRY(hipStreamSynchronize(c->stream));          // the previous list may still be in use
+        HIP_TRY(c->tiles.ensure(std::max<size_t>(host.size() * sizeof(int2), 256)));
+        HIP_TRY(hipMemcpyAsync(c->tiles.p, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->tiles_nb = nb; c->tiles_ndiag = ndiag; c->tiles_count = n;
+    }
+    *tiles = c->tiles.as<int2>();
+    *count = c->tiles_count;
+    return REPET_OK;
+}
+
+int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS) {
+    const int2* tiles; int n;
+    RP_TRY(get_tiles(c, T, 1 << 30, &tiles, &n));
+    HIP_TRY(launch_gram_full(A, T, FS, S, TS, tiles, n, c->stream));
+    return REPET_OK;
+}
+int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP) {
+    const int2* tiles; int n;
+    RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
+    HIP_TRY(launch_gram_band(A, T, FS, band, n_lags, LP, tiles, n, c->stream));
     return REPET_OK;
 }
 
@@ -251,7 +284,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     const int LP = (int)round_up(hi, 64);
     HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
-    HIP_TRY(launch_gram_band(c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, c->stream));
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
     mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
     HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
     HIP_TRY(launch_periods(c->beat.as<float>(), 1, LP, (int)T, p->period_lo, p->period_hi, period_slot, c->stream));
@@ -329,7 +362,7 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
     HIP_TRY(c->win_periods.ensure((size_t)n_win * sizeof(int32_t)));
     HIP_TRY(c->periods.ensure((size_t)T * sizeof(int32_t)));
-    HIP_TRY(launch_gram_band(c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, c->stream));
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
     mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
     const int64_t left = (Ls - 1 + 1) / 2;    // ceil((Ls-1)/2), repet.py:1182
     HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, c->stream));
@@ -355,7 +388,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    HIP_TRY(launch_gram_full(c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, c->stream));
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS));
     mark(c, "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T, 2.0 * g.F * (double)T * T);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
@@ -389,7 +422,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_stft(c, g, tb, 0, N, 0, true, false));
     const int LP = (int)round_up(B, 64);
     HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
-    HIP_TRY(launch_gram_band(c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, c->stream));
+    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP));
     mark(c, "similarity_band", 4.0 * g.F * T + 4.0 * T * B, 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;
@@ -481,7 +514,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->P, &c->S, &c->band, &c->beat,
-                      &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c})
+                      &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -705,7 +738,7 @@ int repet_selfsim(repet_ctx* c, const float* v, int64_t T, int32_t F, float* s_o
     HIP_TRY(hipMemsetAsync(c->Vn.p, 0, (size_t)Tpad * FS * sizeof(float), c->stream));
     HIP_TRY(launch_unit_rows(c->tmp_a.as<float>(), c->Vn.as<float>(), T, F, FS, c->stream));
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    HIP_TRY(launch_gram_full(c->Vn.as<float>(), T, FS, c->S.as<float>(), TS, c->stream));
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, FS, c->S.as<float>(), TS));
     return d2h_pitched(c, s_out, c->S.as<float>(), TS, T, T);
 }
 
@@ -719,7 +752,7 @@ int repet_beat_spectrum(repet_ctx* c, const float* p, int64_t T, int32_t F, floa
     RP_TRY(stage_matrix_in(c, c->P, p, T, F, FS, Tpad));
     HIP_TRY(c->band.ensure((size_t)Tpad * LP * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
-    HIP_TRY(launch_gram_band(c->P.as<float>(), T, FS, c->band.as<float>(), n_lags, LP, c->stream));
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, FS, c->band.as<float>(), n_lags, LP));
     HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, n_lags, F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
     return d2h_pitched(c, beat_out, c->beat.as<float>(), LP, 1, n_lags);
 }
@@ -736,7 +769,7 @@ int repet_beat_spectrogram(repet_ctx* c, const float* p, int64_t T, int32_t F, i
     HIP_TRY(c->band.ensure((size_t)Tpad * LP * sizeof(float)));
     HIP_TRY(hipMemsetAsync(c->band.p, 0, (size_t)Tpad * LP * sizeof(float), c->stream));
     HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
-    HIP_TRY(launch_gram_band(c->P.as<float>(), T, FS, c->band.as<float>(), Ls, LP, c->stream));
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, FS, c->band.as<float>(), Ls, LP));
     const int64_t left = Ls / 2;                                     // ceil((Ls-1)/2)
     HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, Ls, F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, c->stream));
     std::vector<float> win((size_t)n_win * Ls);

@@ -5,11 +5,13 @@
 //   * the beat spectrum as diagonal sums of the Gram of V^2  (repet.py:1108-1158, autocorrelation)
 //
 // Tile 128x128 per 256-thread workgroup (2x2 waves, each 2x2 MFMA tiles of 32x32), BK = 32, register
-// prefetch of the next K-tile and a double-buffered padded LDS image (pitch 36 floats: the 16-lane
+// prefetch two K-tiles ahead and a double-buffered padded LDS image (pitch 36 floats: the 16-lane
 // groups of ds_read_b128 then cover all 64 banks). Both operands are row panels of the same matrix,
 // so A-tile and B-tile loads are identical and coalesce on 128-byte row chunks.
 // Only tiles on or above the diagonal are computed; the full variant mirrors them through LDS.
 #include "common.h"
+
+#include <vector>
 
 namespace repet {
 
@@ -22,14 +24,17 @@ constexpr int kGramLds = 4 * TILE_FLOATS * 4;   // 2 operands x 2 buffers, bytes
 
 enum GramMode { GRAM_FULL = 0, GRAM_BAND = 1 };
 
+// tiles[blockIdx.x] = (bi, bj) with bj >= bi, or (-1,-1) for a filler slot. The host orders the list so
+// that the blocks resident together on one XCD (ids congruent mod 8 under round-robin dispatch) walk one
+// 8x8 super-block of tiles at a time: 64 tiles share 8 + 8 row panels through that XCD's L2.
 template <int MODE>
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, int64_t T, int FS,
-                                                      float* __restrict__ out, int64_t pitch, int n_lags) {
+                                                      float* __restrict__ out, int64_t pitch, int n_lags,
+                                                      const int2* __restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bi = blockIdx.x;
-    const int bj = (MODE == GRAM_FULL) ? (int)blockIdx.y : bi + (int)blockIdx.y;
-    const int nb = gridDim.x;
-    if (bj < bi || bj >= nb) return;
+    const int2 tile = tiles[blockIdx.x];
+    const int bi = tile.x, bj = tile.y;
+    if (bi < 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,66 +61,76 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
     const unsigned g3 = (unsigned)(((tid + 768) >> 3) * FS + (tid & 7) * 4);
     const int l0 = ((tid + 0) >> 3) * LDP + (tid & 7) * 4;      // LDS float offsets of the same four chunks
     const int l1 = l0 + 32 * LDP, l2 = l0 + 64 * LDP, l3 = l0 + 96 * LDP;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define REPET_LOAD_TILE(kt)                                                     \
+    // two staging register sets: the loads of K-tile kt+2 are issued while tile kt is multiplied and have a
+    // whole iteration to land before they are written to LDS (HBM/L2 latency ~ one K-tile of MFMAs)
+    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;      // set P
+    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;      // set Q
+#define REPET_LOAD_TILE(S, kt)                                                  \
     {                                                                           \
         const float* Ak = Ag + (kt) * BK;                                       \
         const float* Bk = Bg + (kt) * BK;                                       \
-        ra0 = *reinterpret_cast<const float4*>(Ak + g0);                        \
-        rb0 = *reinterpret_cast<const float4*>(Bk + g0);                        \
-        ra1 = *reinterpret_cast<const float4*>(Ak + g1);                        \
-        rb1 = *reinterpret_cast<const float4*>(Bk + g1);                        \
-        ra2 = *reinterpret_cast<const float4*>(Ak + g2);                        \
-        rb2 = *reinterpret_cast<const float4*>(Bk + g2);                        \
-        ra3 = *reinterpret_cast<const float4*>(Ak + g3);                        \
-        rb3 = *reinterpret_cast<const float4*>(Bk + g3);                        \
+        S##a0 = *reinterpret_cast<const float4*>(Ak + g0);                      \
+        S##b0 = *reinterpret_cast<const float4*>(Bk + g0);                      \
+        S##a1 = *reinterpret_cast<const float4*>(Ak + g1);                      \
+        S##b1 = *reinterpret_cast<const float4*>(Bk + g1);                      \
+        S##a2 = *reinterpret_cast<const float4*>(Ak + g2);                      \
+        S##b2 = *reinterpret_cast<const float4*>(Bk + g2);                      \
+        S##a3 = *reinterpret_cast<const float4*>(Ak + g3);                      \
+        S##b3 = *reinterpret_cast<const float4*>(Bk + g3);                      \
     }
-#define REPET_STORE_TILE(buf)                                                   \
+#define REPET_STORE_TILE(S, buf)                                                \
     {                                                                           \
         float* As_ = lds + (buf) * 2 * TILE_FLOATS;                             \
         float* Bs_ = As_ + TILE_FLOATS;                                         \
-        *reinterpret_cast<float4*>(As_ + l0) = ra0;                             \
-        *reinterpret_cast<float4*>(Bs_ + l0) = rb0;                             \
-        *reinterpret_cast<float4*>(As_ + l1) = ra1;                             \
-        *reinterpret_cast<float4*>(Bs_ + l1) = rb1;                             \
-        *reinterpret_cast<float4*>(As_ + l2) = ra2;                             \
-        *reinterpret_cast<float4*>(Bs_ + l2) = rb2;                             \
-        *reinterpret_cast<float4*>(As_ + l3) = ra3;                             \
-        *reinterpret_cast<float4*>(Bs_ + l3) = rb3;                             \
+        *reinterpret_cast<float4*>(As_ + l0) = S##a0;                           \
+        *reinterpret_cast<float4*>(Bs_ + l0) = S##b0;                           \
+        *reinterpret_cast<float4*>(As_ + l1) = S##a1;                           \
+        *reinterpret_cast<float4*>(Bs_ + l1) = S##b1;                           \
+        *reinterpret_cast<float4*>(As_ + l2) = S##a2;                           \
+        *reinterpret_cast<float4*>(Bs_ + l2) = S##b2;                           \
+        *reinterpret_cast<float4*>(As_ + l3) = S##a3;                           \
+        *reinterpret_cast<float4*>(Bs_ + l3) = S##b3;                           \
     }
-
-    const int nk = FS / BK;
-    REPET_LOAD_TILE(0)
-    REPET_STORE_TILE(0)
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) REPET_LOAD_TILE(kt + 1)
-        const float* As = lds + cur * 2 * TILE_FLOATS + (wr * 64 + lr) * LDP + 4 * lh;
-        const float* Bs = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + (wc * 64 + lr) * LDP + 4 * lh;
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            const float4 a0 = *reinterpret_cast<const float4*>(As + ks * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDP + ks * 8);
-            const float4 b0 = *reinterpret_cast<const float4*>(Bs + ks * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(Bs + 32 * LDP + ks * 8);
 #define REPET_MFMA4(AX, BX)                                                                       \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b0.BX, acc[0][0], 0, 0, 0);           \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.AX, b1.BX, acc[0][1], 0, 0, 0);           \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b0.BX, acc[1][0], 0, 0, 0);           \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.AX, b1.BX, acc[1][1], 0, 0, 0);
-            REPET_MFMA4(x, x)
-            REPET_MFMA4(y, y)
-            REPET_MFMA4(z, z)
-            REPET_MFMA4(w, w)
-#undef REPET_MFMA4
-        }
-        if (kt + 1 < nk) REPET_STORE_TILE(cur ^ 1)
+#define REPET_COMPUTE(buf)                                                                              \
+    {                                                                                                   \
+        const float* As = lds + (buf) * 2 * TILE_FLOATS + (wr * 64 + lr) * LDP + 4 * lh;                \
+        const float* Bs = lds + (buf) * 2 * TILE_FLOATS + TILE_FLOATS + (wc * 64 + lr) * LDP + 4 * lh;  \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 8; ++ks) {                                         \
+            const float4 a0 = *reinterpret_cast<const float4*>(As + ks * 8);                            \
+            const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDP + ks * 8);                 \
+            const float4 b0 = *reinterpret_cast<const float4*>(Bs + ks * 8);                            \
+            const float4 b1 = *reinterpret_cast<const float4*>(Bs + 32 * LDP + ks * 8);                 \
+            REPET_MFMA4(x, x) REPET_MFMA4(y, y) REPET_MFMA4(z, z) REPET_MFMA4(w, w)                     \
+        }                                                                                               \
+    }
+
+    const int nk = FS / BK;                 // FS is a multiple of 32; nk >= 2 for every supported window
+    REPET_LOAD_TILE(p, 0)
+    REPET_STORE_TILE(p, 0)
+    if (nk > 1) REPET_LOAD_TILE(q, 1)
+    __syncthreads();
+    // iteration kt: LDS[kt&1] holds tile kt, one register set holds tile kt+1, the other receives kt+2
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) REPET_LOAD_TILE(p, kt + 2)
+        REPET_COMPUTE(0)
+        if (kt + 1 < nk) REPET_STORE_TILE(q, 1)
         __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 3 < nk) REPET_LOAD_TILE(q, kt + 3)
+            REPET_COMPUTE(1)
+            if (kt + 2 < nk) REPET_STORE_TILE(p, 0)
+            __syncthreads();
+        }
     }
 #undef REPET_LOAD_TILE
 #undef REPET_STORE_TILE
+#undef REPET_MFMA4
+#undef REPET_COMPUTE
 
     // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
     const int64_t gi0 = (int64_t)bi * kTile + wr * 64;
@@ -170,25 +185,43 @@ static hipError_t set_lds(const void* fn) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds);
 }
 
-hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, hipStream_t s) {
-    if (T <= 0) return hipSuccess;
-    static hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_FULL>));
+// Upper-triangle tile list (bj - bi < ndiag) in XCD-aware order, see gram_kernel.
+int gram_tile_list(int nb, int ndiag, std::vector<int2>* out) {
+    std::vector<int2> seq;
+    const int SB = 8;                                       // super-block edge in tiles
+    const int nsb = (nb + SB - 1) / SB;
+    for (int I = 0; I < nsb; ++I)
+        for (int J = I; J < nsb; ++J)
+            for (int i = I * SB; i < (I + 1) * SB && i < nb; ++i)
+                for (int j = (J * SB > i ? J * SB : i); j < (J + 1) * SB && j < nb; ++j)
+                    if (j - i < ndiag) seq.push_back(make_int2(i, j));
+    const int n = (int)seq.size();
+    const int per = (n + 7) / 8;                            // contiguous share of each XCD
+    out->assign((size_t)per * 8, make_int2(-1, -1));
+    for (int x = 0; x < 8; ++x)
+        for (int k = 0; k < per; ++k) {
+            const int src = x * per + k;
+            if (src < n) (*out)[(size_t)k * 8 + x] = seq[src];
+        }
+    return per * 8;
+}
+
+hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, const int2* tiles,
+                            int32_t n_tiles, hipStream_t s) {
+    if (T <= 0 || n_tiles <= 0) return hipSuccess;
+    hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_FULL>));
     if (attr != hipSuccess) return attr;
-    const unsigned nb = (unsigned)ceil_div(T, kTile);
-    hipLaunchKernelGGL(gram_kernel<GRAM_FULL>, dim3(nb, nb), dim3(256), kGramLds, s, A, T, FS, S, TS, 0);
+    hipLaunchKernelGGL(gram_kernel<GRAM_FULL>, dim3((unsigned)n_tiles), dim3(256), kGramLds, s, A, T, FS, S, TS, 0, tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
-                            hipStream_t s) {
-    if (T <= 0 || n_lags <= 0) return hipSuccess;
-    static hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_BAND>));
+                            const int2* tiles, int32_t n_tiles, hipStream_t s) {
+    if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
+    hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_BAND>));
     if (attr != hipSuccess) return attr;
-    const unsigned nb = (unsigned)ceil_div(T, kTile);
-    unsigned ndiag = (unsigned)((n_lags + 126) / kTile + 1);
-    if (ndiag > nb) ndiag = nb;
-    hipLaunchKernelGGL(gram_kernel<GRAM_BAND>, dim3(nb, ndiag), dim3(256), kGramLds, s, A, T, FS, band,
-                       (int64_t)LP, n_lags);
+    hipLaunchKernelGGL(gram_kernel<GRAM_BAND>, dim3((unsigned)n_tiles), dim3(256), kGramLds, s, A, T, FS, band,
+                       (int64_t)LP, n_lags, tiles);
     return hipGetLastError();
 }
 

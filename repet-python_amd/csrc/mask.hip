@@ -128,13 +128,17 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
 }
 
 // ---- REPET-SIM / online: list of similar frames per frame ----------------------------------------
-template <int NET>
+// SPLIT: F-1 (= W/2) is a multiple of 64, so the wave-per-64-bins kernel covers bins [0, F-1) in whole
+// blocks (4 per wave, balanced) and the lone Nyquist bin F-1 of 64 FRAMES is packed into one wave by
+// mask_sim_nyquist_kernel; without it the 17th block would cost a full network pass for one lane.
+template <int NET, bool SPLIT>
 __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                        const int* __restrict__ count, int64_t first_frame) {
     const int64_t t = blockIdx.x;
     const int c = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nfb = (a.F + 63) >> 6;
+    const int nbins = SPLIT ? a.F - 1 : a.F;
+    const int nfb = (nbins + 63) >> 6;
     const float* Vc = a.V + c * a.chan_stride;
     if (t < first_frame) {           // online warm-up frames contribute nothing (repet.py:834)
         for (int f = threadIdx.x; f < a.F; f += 256) emit(a, c, t, f, 0.f);
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
     RowGather g{channel_rsrc(Vc, a.chan_stride), 0};
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
-        const bool active = f < a.F;
-        const int fc = active ? f : a.F - 1;
+        const bool active = f < nbins;
+        const int fc = active ? f : nbins - 1;
         g.bin_bytes = fc * 4;
         // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the loop; hoisted, hipcc
         // parks all NET offsets in VGPRs and halves the occupancy
@@ -160,12 +164,45 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
     }
 }
 
+// One lane per frame, bin F-1 only: the index list, its length and every row offset are per-lane here.
+template <int NET>
+__global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
+                                                              const int* __restrict__ count, int64_t first_frame) {
+    const int c = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t n_rows = a.T - first_frame;
+    const bool active = r0 < n_rows;
+    const int64_t r = active ? r0 : n_rows - 1;
+    const int64_t t = first_frame + r;
+    const float* Vc = a.V + c * a.chan_stride;
+    const int n = count[r];
+    const int* list = idx + r * (int64_t)idx_pitch;
+    const int f = a.F - 1;
+    const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = channel_rsrc(Vc, a.chan_stride);
+    const float med = median_of<NET>(n, [&](int k) {
+        const int row_off = k < n ? list[k] * row_bytes : pad_offset<NET>(k, n, pad_bytes, row_bytes);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_off + f * 4, 0, 0)); });
+    if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + f], med, f, a.cutoff));
+}
+
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s) {
     if (m.T <= 0) return hipSuccess;
+    const bool split = m.F > 64 && ((m.F - 1) & 63) == 0;
+    const int64_t rows = m.T - first_frame;
     dispatch_net(max_count, [&](auto net) {
-        hipLaunchKernelGGL(mask_sim_kernel<decltype(net)::value>, dim3((unsigned)m.T, (unsigned)m.n_channels),
-                           dim3(256), 0, s, m, idx, idx_pitch, count, first_frame);
+        constexpr int NET = decltype(net)::value;
+        if (split) {
+            hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3((unsigned)m.T, (unsigned)m.n_channels), dim3(256), 0, s,
+                               m, idx, idx_pitch, count, first_frame);
+            if (rows > 0)
+                hipLaunchKernelGGL(mask_sim_nyquist_kernel<NET>, dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels),
+                                   dim3(64), 0, s, m, idx, idx_pitch, count, first_frame);
+        } else {
+            hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3((unsigned)m.T, (unsigned)m.n_channels), dim3(256), 0, s,
+                               m, idx, idx_pitch, count, first_frame);
+        }
     });
     return hipGetLastError();
 }

@@ -52,6 +52,82 @@ def prune(ces, outputs):
     return kept
 
 
+def lower(n, ces):
+    """Comparators -> instructions. A comparator whose low (high) output is never read again keeps only
+    its max (min); two dependent min-only (max-only) steps fuse into one v_min3 (v_max3).
+    Returns a list of (op, dst, srcs) with op in {'ce','min','max','min3','max3'}; 'ce' has dst (lo, hi)."""
+    live = {n // 2 - 1, n // 2}
+    ops = []
+    for (i, j) in reversed(ces):
+        lo_live, hi_live = i in live, j in live
+        if not (lo_live or hi_live):
+            continue
+        if lo_live and hi_live:
+            ops.append(["ce", (i, j), (i, j)])
+        elif lo_live:
+            ops.append(["min", i, (i, j)])
+        else:
+            ops.append(["max", j, (i, j)])
+        live.add(i)
+        live.add(j)
+    ops.reverse()
+    # fuse  x = min(a,b) ; y = min(x,c)  ->  y = min3(a,b,c)  when x is read by nothing else
+    out = []
+    skip = set()
+    for k, op in enumerate(ops):
+        if k in skip:
+            continue
+        kind, dst, srcs = op
+        if kind in ("min", "max"):
+            # next op that touches wire dst
+            nxt = None
+            for m in range(k + 1, len(ops)):
+                if m in skip:
+                    continue
+                if dst in ops[m][2]:
+                    nxt = m
+                    break
+            if nxt is not None and ops[nxt][0] == kind:
+                # no op between k and nxt may touch the source wires of op k (they must still hold their values)
+                clean = all(not (set(srcs) & set(ops[m][2])) for m in range(k + 1, nxt) if m not in skip)
+                if clean:
+                    other = [w for w in ops[nxt][2] if w != dst]
+                    out_dst = ops[nxt][1]
+                    ops[nxt] = [kind + "3", out_dst, (srcs[0], srcs[1], other[0])]
+                    continue        # op k disappears; the fused op is emitted at position nxt
+        out.append(op)
+    return out
+
+
+def simulate(n, ops, a):
+    a = list(a)
+    for kind, dst, srcs in ops:
+        if kind == "ce":
+            lo, hi = min(a[srcs[0]], a[srcs[1]]), max(a[srcs[0]], a[srcs[1]])
+            a[dst[0]], a[dst[1]] = lo, hi
+        elif kind == "min":
+            a[dst] = min(a[srcs[0]], a[srcs[1]])
+        elif kind == "max":
+            a[dst] = max(a[srcs[0]], a[srcs[1]])
+        elif kind == "min3":
+            a[dst] = min(a[srcs[0]], a[srcs[1]], a[srcs[2]])
+        else:
+            a[dst] = max(a[srcs[0]], a[srcs[1]], a[srcs[2]])
+    return a
+
+
+def check_ops(n, ops, trials=400):
+    rnd = random.Random(1000 + n)
+    for _ in range(trials):
+        if rnd.random() < 0.3:
+            a = [rnd.randint(0, 3) for _ in range(n)]
+        else:
+            a = [rnd.random() for _ in range(n)]
+        want = sorted(a)
+        got = simulate(n, ops, a)
+        assert got[n // 2 - 1] == want[n // 2 - 1] and got[n // 2] == want[n // 2], n
+
+
 def check(n, ces, trials=300):
     rnd = random.Random(n)
     for _ in range(trials):
@@ -74,30 +150,45 @@ def main():
              "// MedianNet<N>::run(a): afterwards a[N/2-1] <= a[N/2] are the two middle order statistics.",
              "// A comparator is two integer min/max on the float bit patterns: every value is a non-negative float",
              "// (a magnitude), +inf or the -1.0f pad, for which signed-integer order equals float order. The asm is",
-             "// volatile so the comparators issue in network order: the live set stays at N values + 1 temporary",
-             "// (hipcc otherwise stretches live ranges to ~2N registers and halves the occupancy), and no NaN",
-             "// canonicalisation ops are inserted in front of the min/max.",
+             "// volatile so the steps issue in network order: the live set stays at N values + 1 temporary (hipcc",
+             "// otherwise stretches live ranges to ~2N registers and halves the occupancy), and no NaN",
+             "// canonicalisation ops are inserted in front of the min/max. Steps whose other output is dead keep",
+             "// one instruction; dependent min-only / max-only pairs are fused into v_min3_i32 / v_max3_i32.",
              "#define REPET_CE(i, j) { float lo_, hi_; asm volatile(\"v_min_i32 %0, %2, %3\\n\\tv_max_i32 %1, %2, %3\" : \"=&v\"(lo_), \"=v\"(hi_) : \"v\"(a[i]), \"v\"(a[j])); a[i] = lo_; a[j] = hi_; }",
+             "#define REPET_MIN(d, i, j) { float r_; asm volatile(\"v_min_i32 %0, %1, %2\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j])); a[d] = r_; }",
+             "#define REPET_MAX(d, i, j) { float r_; asm volatile(\"v_max_i32 %0, %1, %2\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j])); a[d] = r_; }",
+             "#define REPET_MIN3(d, i, j, k) { float r_; asm volatile(\"v_min3_i32 %0, %1, %2, %3\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j]), \"v\"(a[k])); a[d] = r_; }",
+             "#define REPET_MAX3(d, i, j, k) { float r_; asm volatile(\"v_max3_i32 %0, %1, %2, %3\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j]), \"v\"(a[k])); a[d] = r_; }",
              "template <int N> struct MedianNet;"]
     for n in SIZES:
         full = batcher(n)
         ces = prune(full, (n // 2 - 1, n // 2))
         check(n, ces)
-        print(f"N={n}: {len(full)} comparators, {len(ces)} after pruning", file=sys.stderr)
+        ops = lower(n, ces)
+        check_ops(n, ops)
+        n_instr = sum(2 if o[0] == "ce" else 1 for o in ops)
+        print(f"N={n}: {len(full)} comparators, {len(ces)} after pruning, {n_instr} instructions "
+              f"({2 * len(ces)} before output-level pruning and min3/max3 fusion)", file=sys.stderr)
         lines.append(f"template <> struct MedianNet<{n}> {{")
-        lines.append(f"    static constexpr int kComparators = {len(ces)};")
+        lines.append(f"    static constexpr int kInstructions = {n_instr};")
         lines.append(f"    static __device__ __forceinline__ void run(float (&a)[{n}]) {{")
         row = []
-        for (i, j) in ces:
-            row.append(f"REPET_CE({i},{j})")
-            if len(row) == 8:
+        for kind, dst, srcs in ops:
+            if kind == "ce":
+                row.append(f"REPET_CE({srcs[0]},{srcs[1]})")
+            elif kind in ("min", "max"):
+                row.append(f"REPET_{kind.upper()}({dst},{srcs[0]},{srcs[1]})")
+            else:
+                row.append(f"REPET_{kind.upper()}({dst},{srcs[0]},{srcs[1]},{srcs[2]})")
+            if len(row) == 6:
                 lines.append("        " + " ".join(row))
                 row = []
         if row:
             lines.append("        " + " ".join(row))
         lines.append("    }")
         lines.append("};")
-    lines.append("#undef REPET_CE")
+    for m in ("CE", "MIN", "MAX", "MIN3", "MAX3"):
+        lines.append(f"#undef REPET_{m}")
     text = "\n".join(lines) + "\n"
     if not os.path.exists(out) or open(out).read() != text:   # keep the mtime when nothing changed
         with open(out, "w") as fh:

@@ -26,6 +26,19 @@ OPS(max3_i32, E8_3("v_max3_i32"))
 OPS(med3_i32, E8_3("v_med3_i32"))
 OPS(pk_min_f16, E8("v_pk_min_f16"))
 
+OPS(mul_f32, E8("v_mul_f32"))
+OPS(add_u32, E8("v_add_u32"))
+OPS(and_b32, E8("v_and_b32"))
+OPS(xor_b32, E8("v_xor_b32"))
+OPS(lshl_b32, "v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n v_lshlrev_b32 %4, 1, %4\n v_lshlrev_b32 %5, 1, %5\n v_lshlrev_b32 %6, 1, %6\n v_lshlrev_b32 %7, 1, %7\n")
+OPS(mov_b32, "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
+OPS(cndmask, "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+OPS(cmp_lt_f32, "v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8\n")
+OPS(swap_b32, "v_swap_b32 %0, %1\n v_swap_b32 %2, %3\n v_swap_b32 %4, %5\n v_swap_b32 %6, %7\n v_swap_b32 %0, %1\n v_swap_b32 %2, %3\n v_swap_b32 %4, %5\n v_swap_b32 %6, %7\n")
+OPS(max_f32_dpp, E8("v_max_f32"))
+OPS(sub_f32, E8("v_sub_f32"))
+OPS(max_i16, E8("v_pk_max_i16"))
+
 template <class K> void run(const char* name, K kern, float* d, int per_iter) {
     const int iters = 2000, blocks = 256 * 4;   // 512 threads = 8 waves; 4 blocks/CU -> 8 waves/SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -46,5 +59,9 @@ int main() {
     run("v_add_f32", k_add_f32, d, 64); run("v_fma_f32", k_fma_f32, d, 64); run("v_med3_f32", k_med3_f32, d, 64);
     run("v_min3_f32", k_min3_f32, d, 64); run("v_max3_i32", k_max3_i32, d, 64); run("v_med3_i32", k_med3_i32, d, 64);
     run("v_pk_min_f16", k_pk_min_f16, d, 64);
+    run("v_mul_f32", k_mul_f32, d, 64); run("v_sub_f32", k_sub_f32, d, 64); run("v_add_u32", k_add_u32, d, 64); run("v_and_b32", k_and_b32, d, 64);
+    run("v_xor_b32", k_xor_b32, d, 64); run("v_lshlrev_b32", k_lshl_b32, d, 64); run("v_mov_b32", k_mov_b32, d, 64);
+    run("v_cndmask_b32", k_cndmask, d, 64); run("v_cmp_lt_f32", k_cmp_lt_f32, d, 64); run("v_swap_b32", k_swap_b32, d, 64);
+    run("v_pk_max_i16", k_max_i16, d, 64);
     return 0;
 }
