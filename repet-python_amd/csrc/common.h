@@ -25,8 +25,12 @@ struct StftArgs {
     int64_t sample_offset;   // first sample of the clip inside `audio` (segments of `extended`)
     const float* window; const float2* twiddle;   // twiddle[m] = exp(-2 pi i m / W), m < W
     int32_t W, H; int64_t T; int32_t FS; int32_t centred;
-    float2* X; float* V; int64_t chan_stride;     // elements between channels in X and V (= Tpad*FS)
+    float2* X; float* V; int64_t chan_stride;     // elements between channels in X and V
     float* Vm; float* Vn; float* P;
+    // batch of equal-length clips (segments of `extended`): blockIdx.y = b
+    int32_t n_batch; int64_t batch_sample_stride; // samples between the starts of consecutive clips
+    int64_t batch_spec_stride;                    // elements between clips in X and V (= C*chan_stride)
+    int64_t batch_mean_stride;                    // elements between clips in Vm/Vn/P (= Tpad*FS)
 };
 hipError_t launch_stft(const StftArgs& a, hipStream_t s);
 
@@ -36,6 +40,19 @@ struct IstftArgs {
     const float2* twiddle; float* frames;  // frames[c][t][W]
 };
 hipError_t launch_istft_frames(const IstftArgs& a, hipStream_t s);
+
+// K9 fused (hop = W/2 only): masked spectrum -> inverse FFT -> overlap-add -> out[n][C], no frames buffer.
+struct IstftOlaArgs {
+    const float2* Y; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t FS; int32_t W;
+    const float2* twiddle; int64_t trim; float* out; int64_t n_out; int64_t out_offset; float scale;
+    int32_t accumulate_weighted; int64_t fade_in, fade_out;
+    int64_t first_hop, last_hop;   // filled by the launcher
+    // batch of segments (extended): blockIdx.y = slot, segment j = batch_first + slot*batch_step reads its
+    // spectra at j_local*batch_spec_stride, writes at out_offset + j*batch_out_stride, and fades in unless
+    // j == 0 / out unless j == batch_total-1 over `overlap` samples (fade_in/fade_out are ignored then)
+    int32_t n_batch, batch_first, batch_step, batch_total, batch_local0; int64_t batch_spec_stride, batch_out_stride, overlap;
+};
+hipError_t launch_istft_ola(const IstftOlaArgs& a, hipStream_t s);
 
 // Overlap-add of frames[c][t][W] at hop H into out[n][C] (interleaved), out sample n takes padded
 // position n + trim; multiplied by `scale` (1/sum(window[0:W:H])).
@@ -57,13 +74,15 @@ hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int
                             int32_t n_tiles, hipStream_t s);
 // K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
-                            const int2* tiles, int32_t n_tiles, hipStream_t s);
+                            const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t a_batch_stride,
+                            int64_t band_batch_stride, hipStream_t s);
 
 // Windowed diagonal sums of the band: beat[w][l] = sum_{t=lo_w}^{hi_w - l} band[t][l] / ((len - l) * F)
 //   window w covers frames [start0 + w*step, start0 + w*step + len) clipped to [0,T).
 hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,
                                   int64_t start0, int64_t step, int64_t len, int32_t n_windows,
-                                  float* beat, int32_t beat_pitch, hipStream_t s);
+                                  float* beat, int32_t beat_pitch, int32_t n_batch, int64_t band_batch_stride,
+                                  int64_t beat_batch_stride, hipStream_t s);
 
 // K7: period[c] = argmax(beat[c][lo:hi]) + 1 + lo (first max wins), hi = min(period_hi, n_lags/3).
 hipError_t launch_periods(const float* beat, int32_t n_cols, int32_t pitch, int32_t n_lags, int32_t lo,
@@ -87,6 +106,7 @@ struct MaskArgs {
     const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t F, FS;
     float2* X; float* mask; int32_t cutoff;
     int64_t pad_row;   // rows pad_row / pad_row+1 of every channel of V hold -1.0f / +inf (median pads)
+    int32_t n_batch; int64_t batch_stride;   // mask_period only: blockIdx.z = clip, elements between clips
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size

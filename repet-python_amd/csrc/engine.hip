@@ -160,7 +160,7 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
 int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP) {
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
-    HIP_TRY(launch_gram_band(A, T, FS, band, n_lags, LP, tiles, n, c->stream));
+    HIP_TRY(launch_gram_band(A, T, FS, band, n_lags, LP, tiles, n, 1, 0, 0, c->stream));
     return REPET_OK;
 }
 
@@ -215,33 +215,39 @@ Geo make_geo(int W, int H, int64_t T, int C) {
     return g;
 }
 
-int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p) {
-    HIP_TRY(c->X.ensure((size_t)g.C * g.chan_stride * sizeof(float2)));
-    HIP_TRY(c->V.ensure((size_t)g.C * g.chan_stride * sizeof(float)));
+// B: number of equal-geometry clips handled together (segments of `extended`); buffers are [B][C][rows][FS]
+int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B = 1) {
+    HIP_TRY(c->X.ensure((size_t)B * g.C * g.chan_stride * sizeof(float2)));
+    HIP_TRY(c->V.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
     if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
-    HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, g.C, g.Tpad, g.FS, c->stream));
-    const size_t row_bytes = (size_t)g.FS * sizeof(float);
+    HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream));
+    const size_t mean_elems = (size_t)g.Tpad * g.FS;
     if (want_vn) {
-        HIP_TRY(c->Vn.ensure((size_t)g.chan_stride * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(c->Vn.as<float>() + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * row_bytes, c->stream));
+        HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
+        for (int b = 0; b < B; ++b)
+            HIP_TRY(hipMemsetAsync(c->Vn.as<float>() + b * mean_elems + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), c->stream));
     }
     if (want_p) {
-        HIP_TRY(c->P.ensure((size_t)g.chan_stride * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(c->P.as<float>() + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * row_bytes, c->stream));
+        HIP_TRY(c->P.ensure(B * mean_elems * sizeof(float)));
+        if (B == 1) HIP_TRY(hipMemsetAsync(c->P.as<float>() + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), c->stream));
+        else HIP_TRY(hipMemsetAsync(c->P.p, 0, B * mean_elems * sizeof(float), c->stream));
     }
     return REPET_OK;
 }
 
-int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64_t n, int centred, bool vn, bool p) {
+int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64_t n, int centred, bool vn, bool p,
+             int B = 1, int64_t batch_sample_stride = 0) {
     StftArgs a{};
     a.audio = c->audio.as<float>(); a.n_samples = n; a.n_channels = g.C; a.sample_offset = offset;
     a.window = tb->window.as<float>(); a.twiddle = tb->twiddle.as<float2>();
     a.W = g.W; a.H = g.H; a.T = g.T; a.FS = g.FS; a.centred = centred;
     a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
     a.Vm = nullptr; a.Vn = vn ? c->Vn.as<float>() : nullptr; a.P = p ? c->P.as<float>() : nullptr;
+    a.n_batch = B; a.batch_sample_stride = batch_sample_stride; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
+    a.batch_mean_stride = g.Tpad * g.FS;
     HIP_TRY(launch_stft(a, c->stream));
     const double in_b = 4.0 * n * g.C, spec_b = (8.0 + 4.0) * g.F * g.T * g.C, mean_b = 4.0 * g.F * g.T;
-    mark(c, "stft", in_b + spec_b + mean_b, 0);
+    mark(c, "stft", B * (in_b + spec_b + mean_b), 0);
     return REPET_OK;
 }
 
@@ -249,56 +255,84 @@ MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
     MaskArgs m{};
     m.V = c->V.as<float>(); m.chan_stride = g.chan_stride; m.n_channels = g.C; m.T = g.T; m.F = g.F; m.FS = g.FS;
     m.X = c->X.as<float2>(); m.mask = nullptr; m.cutoff = cutoff; m.pad_row = g.Tpad;
+    m.n_batch = 1; m.batch_stride = (int64_t)g.C * g.chan_stride;
     return m;
 }
 
-// masked spectrum -> time frames -> overlap-add into c->out
+// masked spectrum -> inverse FFT + overlap-add (one fused kernel) -> c->out
 int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_t n_out, int64_t out_offset,
               bool weighted, int64_t fade_in, int64_t fade_out) {
-    HIP_TRY(c->frames.ensure((size_t)g.C * g.T * g.W * sizeof(float)));
-    IstftArgs ia{};
-    ia.Y = c->X.as<float2>(); ia.chan_stride = g.chan_stride; ia.n_channels = g.C; ia.T = g.T; ia.FS = g.FS; ia.W = g.W;
-    ia.twiddle = tb->twiddle.as<float2>(); ia.frames = c->frames.as<float>();
-    HIP_TRY(launch_istft_frames(ia, c->stream));
-    mark(c, "istft_frames", 8.0 * g.F * g.T * g.C + 4.0 * g.W * g.T * g.C, 0);
-    OlaArgs oa{};
-    oa.frames = c->frames.as<float>(); oa.n_channels = g.C; oa.T = g.T; oa.W = g.W; oa.H = g.H; oa.trim = trim;
-    oa.out = c->out.as<float>(); oa.n_out = n_out; oa.out_offset = out_offset; oa.scale = (float)(1.0 / tb->cola);
-    oa.accumulate_weighted = weighted ? 1 : 0; oa.fade_in = fade_in; oa.fade_out = fade_out;
-    HIP_TRY(launch_overlap_add(oa, c->stream));
-    mark(c, "overlap_add", 4.0 * g.W * g.T * g.C + 4.0 * n_out * g.C, 0);
+    IstftOlaArgs a{};
+    a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+    a.twiddle = tb->twiddle.as<float2>(); a.trim = trim; a.out = c->out.as<float>(); a.n_out = n_out;
+    a.out_offset = out_offset; a.scale = (float)(1.0 / tb->cola);
+    a.accumulate_weighted = weighted ? 1 : 0; a.fade_in = fade_in; a.fade_out = fade_out;
+    hipError_t e = launch_istft_ola(a, c->stream);
+    if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
+    HIP_TRY(e);
+    mark(c, "istft_ola", 8.0 * g.F * g.T * g.C + 4.0 * n_out * g.C, 0);
     return REPET_OK;
 }
 
-// ---- original on samples [offset, offset+n) of the resident clip (also one segment of extended) ----
-int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n, int32_t* period_slot,
-                 bool weighted, int64_t fade_in, int64_t fade_out) {
+// ---- original on B equal-length clips of the resident signal: clip b covers samples
+// [offset + b*hop, offset + b*hop + n). B = 1, hop = 0 is repet.original itself; B > 1 are segments
+// seg_first .. seg_first+B-1 of `extended` (of seg_total), whose outputs are cross-faded into c->out.
+int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n, int B, int64_t hop,
+                 int32_t* period_slots, bool weighted, int seg_first, int seg_total, int64_t overlap) {
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, p->window_length, &tb));
     const int64_t T = repet_frame_count(n, p->window_length, p->step_length, 1);
     const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
     const int hi = (int)std::min<int64_t>(p->period_hi, T / 3);
     if (hi <= p->period_lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence (clip too short for the period range)");
-    RP_TRY(ensure_spectra(c, g, false, true));
-    RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true));
+    RP_TRY(ensure_spectra(c, g, false, true, B));
+    RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true, B, hop));
     const int LP = (int)round_up(hi, 64);
-    HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
-    HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
-    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
-    mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
-    HIP_TRY(launch_periods(c->beat.as<float>(), 1, LP, (int)T, p->period_lo, p->period_hi, period_slot, c->stream));
-    mark(c, "beat_period", 4.0 * T * hi, 0);
-    HIP_TRY(launch_mask_period(mask_args(c, g, p->cutoff_bins), period_slot, 0, p->period_lo + 1, c->stream));
-    mark(c, "mask_period", (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
-    RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, weighted, fade_in, fade_out));
+    const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP;
+    HIP_TRY(c->band.ensure((size_t)B * band_stride * sizeof(float)));
+    HIP_TRY(c->beat.ensure((size_t)B * LP * sizeof(float)));
+    {
+        const int2* tiles; int n_tiles;
+        RP_TRY(get_tiles(c, T, gram_band_diagonals(hi), &tiles, &n_tiles));
+        HIP_TRY(launch_gram_band(c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, tiles, n_tiles, B, mean_stride,
+                                 band_stride, c->stream));
+    }
+    mark(c, "gram_band", B * (4.0 * g.F * T + 4.0 * T * hi), B * 2.0 * g.F * T * hi);
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, B, band_stride, LP, c->stream));
+    HIP_TRY(launch_periods(c->beat.as<float>(), B, LP, (int)T, p->period_lo, p->period_hi, period_slots, c->stream));
+    mark(c, "beat_period", B * 4.0 * T * hi, 0);
+    MaskArgs m = mask_args(c, g, p->cutoff_bins);
+    m.n_batch = B;
+    HIP_TRY(launch_mask_period(m, period_slots, 0, p->period_lo + 1, c->stream));
+    mark(c, "mask_period", B * (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
+    if (!weighted) {
+        RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, false, 0, 0));
+    } else {
+        // segments that overlap in the output must not be accumulated concurrently: one launch per residue
+        // class modulo ceil(n / hop) (2 for the default 10 s / 5 s), each class writes disjoint samples
+        const int classes = hop > 0 ? (int)ceil_div(n, hop) : 1;
+        for (int k = 0; k < classes && k < B; ++k) {
+            IstftOlaArgs a{};
+            a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+            a.twiddle = tb->twiddle.as<float2>(); a.trim = g.W - g.H; a.out = c->out.as<float>(); a.n_out = n;
+            a.out_offset = 0; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 1;
+            a.n_batch = (B - k + classes - 1) / classes; a.batch_first = seg_first + k; a.batch_step = classes;
+            a.batch_total = seg_total; a.batch_local0 = k; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
+            a.batch_out_stride = hop > 0 ? hop : 0; a.overlap = overlap;
+            if (hop == 0) a.out_offset = offset;          // single (last) segment: explicit offset, j = seg_first
+            hipError_t e = launch_istft_ola(a, c->stream);
+            if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
+            HIP_TRY(e);
+        }
+        mark(c, "istft_ola", B * (8.0 * g.F * g.T * g.C + 4.0 * n * g.C), 0);
+    }
     c->last_T = T;
     return REPET_OK;
 }
 
 int exec_original(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->periods.ensure(sizeof(int32_t)));
-    RP_TRY(run_original(c, p, 0, c->n_samples, c->periods.as<int32_t>(), false, 0, 0));
+    RP_TRY(run_original(c, p, 0, c->n_samples, 1, 0, c->periods.as<int32_t>(), false, 0, 1, 0));
     c->last_n_periods = 1;
     return REPET_OK;
 }
@@ -310,7 +344,9 @@ int64_t extended_segment_count(int64_t N, const repet_params* p) {
 }
 
 // segments [first, first+n_seg) of the resident clip; contributions of other segments are left zero,
-// so partial results of disjoint ranges simply add up (repet.py:380-414 is linear in the segments)
+// so partial results of disjoint ranges simply add up (repet.py:380-414 is linear in the segments).
+// All segments but the last have the same length and run as ONE batch per stage; the last one
+// (it absorbs the remainder, repet.py:320-322) runs on its own.
 int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_t n_seg = -1) {
     const int64_t N = c->n_samples, L = p->seg_len_samples, Hs = p->seg_step_samples;
     if (L <= 0 || Hs <= 0 || Hs > L) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step");
@@ -325,20 +361,18 @@ int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_
     const int64_t O = L - Hs;
     HIP_TRY(c->periods.ensure((size_t)std::max<int64_t>(n_seg, 1) * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
-    repet_timing* timing = c->timing;       // one "segments" stage instead of 5 marks per segment
-    c->timing = nullptr;
-    double bytes = 0, flops = 0;
-    for (int64_t j = first; j < first + n_seg; ++j) {
-        const int64_t start = j * Hs;
-        const int64_t len = (j < count - 1) ? L : N - start;        // repet.py:318-322
-        int rc = run_original(c, p, start, len, c->periods.as<int32_t>() + (j - first), true, j > 0 ? O : 0, j < count - 1 ? O : 0);
-        if (rc != REPET_OK) { c->timing = timing; return rc; }
-        const double F = p->window_length / 2 + 1, T = (double)c->last_T, hi = std::min<double>(p->period_hi, c->last_T / 3);
-        bytes += 8.0 * len * c->n_channels + (12.0 + 24.0 + 12.0) * F * T * c->n_channels + 8.0 * F * T + 8.0 * T * hi;
-        flops += 2.0 * F * T * hi;
+    const int64_t last = count - 1;
+    const int64_t uniform = std::min(first + n_seg, last) - first;  // equal-length segments in the range
+    if (uniform > 0)
+        RP_TRY(run_original(c, p, first * Hs, L, (int)uniform, Hs, c->periods.as<int32_t>(), true, (int)first, (int)count, O));
+    if (first + n_seg == count) {                                   // the longer last segment, repet.py:320-322
+        repet_timing* timing = c->timing;                           // its stages are not listed separately
+        if (uniform > 0) c->timing = nullptr;
+        int rc = run_original(c, p, last * Hs, N - last * Hs, 1, 0, c->periods.as<int32_t>() + uniform, true, (int)last, (int)count, O);
+        c->timing = timing;
+        if (rc != REPET_OK) return rc;
+        if (uniform > 0) mark(c, "last_segment", 0, 0);
     }
-    c->timing = timing;
-    mark(c, "extended_segments", bytes, flops);
     c->last_n_periods = (int32_t)n_seg;
     return REPET_OK;
 }
@@ -365,7 +399,7 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
     mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
     const int64_t left = (Ls - 1 + 1) / 2;    // ceil((Ls-1)/2), repet.py:1182
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, c->stream));
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0, c->stream));
     HIP_TRY(launch_periods(c->beat.as<float>(), n_win, LP, Ls, p->period_lo, p->period_hi, c->win_periods.as<int32_t>(), c->stream));
     HIP_TRY(launch_expand_periods(c->win_periods.as<int32_t>(), n_win, Hs, T, p->period_lo, c->periods.as<int32_t>(), c->stream));
     mark(c, "beat_periods", 4.0 * n_win * (double)Ls * hi, 0);
@@ -753,7 +787,7 @@ int repet_beat_spectrum(repet_ctx* c, const float* p, int64_t T, int32_t F, floa
     HIP_TRY(c->band.ensure((size_t)Tpad * LP * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, FS, c->band.as<float>(), n_lags, LP));
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, n_lags, F, 0, 0, T, 1, c->beat.as<float>(), LP, c->stream));
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, n_lags, F, 0, 0, T, 1, c->beat.as<float>(), LP, 1, 0, 0, c->stream));
     return d2h_pitched(c, beat_out, c->beat.as<float>(), LP, 1, n_lags);
 }
 
@@ -771,7 +805,7 @@ int repet_beat_spectrogram(repet_ctx* c, const float* p, int64_t T, int32_t F, i
     HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, FS, c->band.as<float>(), Ls, LP));
     const int64_t left = Ls / 2;                                     // ceil((Ls-1)/2)
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, Ls, F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, c->stream));
+    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, Ls, F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0, c->stream));
     std::vector<float> win((size_t)n_win * Ls);
     RP_TRY(d2h_pitched(c, win.data(), c->beat.as<float>(), LP, n_win, Ls));
     // replicate with the reference's hole (repet.py:1194-1204): frame i+Hs-1 of each step stays zero

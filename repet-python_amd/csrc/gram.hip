@@ -30,8 +30,11 @@ enum GramMode { GRAM_FULL = 0, GRAM_BAND = 1 };
 template <int MODE>
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, int64_t T, int FS,
                                                       float* __restrict__ out, int64_t pitch, int n_lags,
-                                                      const int2* __restrict__ tiles) {
+                                                      const int2* __restrict__ tiles, int64_t a_batch_stride,
+                                                      int64_t out_batch_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    A += blockIdx.y * a_batch_stride;           // batch of equal-shape matrices (segments of `extended`)
+    out += blockIdx.y * out_batch_stride;
     const int2 tile = tiles[blockIdx.x];
     const int bi = tile.x, bj = tile.y;
     if (bi < 0) return;
@@ -211,17 +214,19 @@ hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
     hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_FULL>));
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gram_kernel<GRAM_FULL>, dim3((unsigned)n_tiles), dim3(256), kGramLds, s, A, T, FS, S, TS, 0, tiles);
+    hipLaunchKernelGGL(gram_kernel<GRAM_FULL>, dim3((unsigned)n_tiles), dim3(256), kGramLds, s, A, T, FS, S, TS, 0, tiles,
+                       (int64_t)0, (int64_t)0);
     return hipGetLastError();
 }
 
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
-                            const int2* tiles, int32_t n_tiles, hipStream_t s) {
+                            const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t a_batch_stride,
+                            int64_t band_batch_stride, hipStream_t s) {
     if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
     hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_BAND>));
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gram_kernel<GRAM_BAND>, dim3((unsigned)n_tiles), dim3(256), kGramLds, s, A, T, FS, band,
-                       (int64_t)LP, n_lags, tiles);
+    hipLaunchKernelGGL(gram_kernel<GRAM_BAND>, dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
+                       kGramLds, s, A, T, FS, band, (int64_t)LP, n_lags, tiles, a_batch_stride, band_batch_stride);
     return hipGetLastError();
 }
 
@@ -231,8 +236,11 @@ hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, 
 __global__ __launch_bounds__(256) void band_window_sum_kernel(const float* __restrict__ band, int64_t T, int LP,
                                                               int n_lags, int n_freq, int64_t start0,
                                                               int64_t step, int64_t len, float* beat,
-                                                              int beat_pitch) {
+                                                              int beat_pitch, int64_t band_batch_stride,
+                                                              int64_t beat_batch_stride) {
     __shared__ float part[4][64];
+    band += blockIdx.z * band_batch_stride;
+    beat += blockIdx.z * beat_batch_stride;
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = blockIdx.x * 64 + lane;
@@ -262,10 +270,13 @@ __global__ __launch_bounds__(256) void band_window_sum_kernel(const float* __res
 
 hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,
                                   int64_t start0, int64_t step, int64_t len, int32_t n_windows, float* beat,
-                                  int32_t beat_pitch, hipStream_t s) {
+                                  int32_t beat_pitch, int32_t n_batch, int64_t band_batch_stride,
+                                  int64_t beat_batch_stride, hipStream_t s) {
     if (n_windows <= 0 || n_lags <= 0) return hipSuccess;
-    hipLaunchKernelGGL(band_window_sum_kernel, dim3((unsigned)ceil_div(n_lags, 64), (unsigned)n_windows),
-                       dim3(256), 0, s, band, T, LP, n_lags, n_freq, start0, step, len, beat, beat_pitch);
+    hipLaunchKernelGGL(band_window_sum_kernel,
+                       dim3((unsigned)ceil_div(n_lags, 64), (unsigned)n_windows, (unsigned)(n_batch > 0 ? n_batch : 1)),
+                       dim3(256), 0, s, band, T, LP, n_lags, n_freq, start0, step, len, beat, beat_pitch,
+                       band_batch_stride, beat_batch_stride);
     return hipGetLastError();
 }
 

@@ -258,10 +258,14 @@ hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32
 template <int NET>
 __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int* __restrict__ period_dev,
                                                           int period_host) {
-    const int p = period_dev ? period_dev[0] : period_host;
+    const int bz = blockIdx.z;                  // clip of the batch (segments of `extended`)
+    const int p = period_dev ? period_dev[bz] : period_host;
     const int q = blockIdx.x;
     if (q >= p) return;
     const int c = blockIdx.y;
+    a.V += bz * a.batch_stride;
+    if (a.X) a.X += bz * a.batch_stride;
+    if (a.mask) a.mask += bz * a.batch_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nfb = (a.F + 63) >> 6;
     const float* Vc = a.V + c * a.chan_stride;
@@ -299,7 +303,8 @@ hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int3
     const int pmin = period_dev ? (min_period > 0 ? min_period : 1) : period_host;
     const int max_segments = (int)((m.T + pmin - 1) / pmin);
     dispatch_net(max_segments, [&](auto net) {
-        hipLaunchKernelGGL(mask_period_kernel<decltype(net)::value>, dim3(gx, (unsigned)m.n_channels), dim3(256), 0, s,
+        hipLaunchKernelGGL(mask_period_kernel<decltype(net)::value>,
+                           dim3(gx, (unsigned)m.n_channels, (unsigned)(m.n_batch > 0 ? m.n_batch : 1)), dim3(256), 0, s,
                            m, period_dev, period_host);
     });
     return hipGetLastError();

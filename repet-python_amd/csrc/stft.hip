@@ -75,9 +75,16 @@ __global__ __launch_bounds__(kFftThreads) void stft_kernel(StftArgs a) {
 
     const int tid = threadIdx.x;
     const int64_t t = blockIdx.x;
+    const int64_t b = blockIdx.y;
     const int C = a.n_channels;
     const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
     const int64_t row = t * a.FS;
+    a.sample_offset += b * a.batch_sample_stride;
+    a.X += b * a.batch_spec_stride;
+    a.V += b * a.batch_spec_stride;
+    if (a.Vm) a.Vm += b * a.batch_mean_stride;
+    if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.P) a.P += b * a.batch_mean_stride;
 
     float acc[SLOTS];
 #pragma unroll
@@ -205,6 +212,101 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(OlaArgs a) {
     }
 }
 
+// K9 fused: masked spectrum -> inverse FFT -> overlap-add -> interleaved output, hop H = W/2.
+// One workgroup produces RUN consecutive hops of every channel: hop h = second half of frame h-1 + first
+// half of frame h, so it inverts frames h0-1 .. h0+RUN-1 and carries each channel's tail in LDS. The
+// time-domain frames never touch HBM and every output sample is written exactly once, coalesced over
+// the interleaved channels.
+constexpr int kOlaRun = 8;
+template <int W>
+__device__ __forceinline__ const float2* inverse_frame(const float2* __restrict__ Y, const float2* __restrict__ tw,
+                                                       float2* buf0, float2* buf1) {
+    constexpr int N = W / 2;
+    for (int k = threadIdx.x; k < N; k += kFftThreads) {
+        const float2 xk = Y[k];
+        const float2 xc = cconj(Y[N - k]);
+        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+        const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+        const float2 o = cmul(d, cconj(tw[k]));
+        buf0[k] = make_float2(e.x - o.y, e.y + o.x);
+    }
+    __syncthreads();
+    return fft_lds<N, true>(buf0, buf1, tw, W);
+}
+
+template <int W>
+__global__ __launch_bounds__(kFftThreads) void istft_ola_kernel(IstftOlaArgs a) {
+    constexpr int N = W / 2;          // complex points per frame = samples per hop (H = W/2)
+    constexpr int HP = N / 2;         // float2 per half frame
+    __shared__ float2 buf0[N];
+    __shared__ float2 buf1[N];
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    const int C = a.n_channels;
+    float2* tails = reinterpret_cast<float2*>(dyn);            // [C][HP] second half of the previous frame
+    float* stage = dyn + (size_t)C * N;                        // [N samples][C] one hop, interleaved
+    const int tid = threadIdx.x;
+    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * kOlaRun;
+    const float inv_n = 1.0f / (float)N;
+    if (a.n_batch > 0) {
+        const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
+        a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        a.out_offset += (int64_t)j * a.batch_out_stride;
+        a.fade_in = j > 0 ? a.overlap : 0;
+        a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
+    }
+
+    for (int c = 0; c < C; ++c) {                              // tails of frame h0-1
+        const int64_t t = h0 - 1;
+        if (t >= 0 && t < a.T) {
+            const float2* z = inverse_frame<W>(a.Y + c * a.chan_stride + t * a.FS, a.twiddle, buf0, buf1);
+            for (int m = tid; m < HP; m += kFftThreads) tails[c * HP + m] = z[HP + m];
+        } else {
+            for (int m = tid; m < HP; m += kFftThreads) tails[c * HP + m] = make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+    }
+    for (int r = 0; r < kOlaRun; ++r) {
+        const int64_t h = h0 + r;
+        if (h > a.last_hop) break;
+        for (int c = 0; c < C; ++c) {
+            if (h < a.T) {
+                const float2* z = inverse_frame<W>(a.Y + c * a.chan_stride + h * a.FS, a.twiddle, buf0, buf1);
+                for (int m = tid; m < HP; m += kFftThreads) {
+                    const float2 head = z[m], tail = tails[c * HP + m];
+                    stage[(2 * m) * C + c] = (head.x + tail.x) * inv_n;
+                    stage[(2 * m + 1) * C + c] = (head.y + tail.y) * inv_n;
+                    tails[c * HP + m] = z[HP + m];
+                }
+            } else {                                           // past the last frame: only the tail remains
+                for (int m = tid; m < HP; m += kFftThreads) {
+                    const float2 tail = tails[c * HP + m];
+                    stage[(2 * m) * C + c] = tail.x * inv_n;
+                    stage[(2 * m + 1) * C + c] = tail.y * inv_n;
+                    tails[c * HP + m] = make_float2(0.f, 0.f);
+                }
+            }
+            __syncthreads();
+        }
+        // hop h covers padded samples [h*N, (h+1)*N); output sample n = padded - trim
+        const int64_t n_base = h * N - a.trim;
+        for (int i = tid; i < N * C; i += kFftThreads) {
+            const int64_t n = n_base + i / C;
+            if (n < 0 || n >= a.n_out) continue;
+            float v = stage[i] * a.scale;
+            float* dst = a.out + (a.out_offset + n) * C + (i % C);
+            if (a.accumulate_weighted) {
+                float w = 1.f;
+                if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
+                else if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w = (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
+                *dst += w * v;
+            } else {
+                *dst = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename Fn>
 static hipError_t dispatch_window(int W, Fn&& fn) {
     switch (W) {
@@ -224,7 +326,8 @@ static hipError_t dispatch_window(int W, Fn&& fn) {
 hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
     if (a.T <= 0) return hipSuccess;
     return dispatch_window(a.W, [&](auto w) {
-        hipLaunchKernelGGL(stft_kernel<decltype(w)::value>, dim3((unsigned)a.T), dim3(kFftThreads), 0, s, a);
+        hipLaunchKernelGGL(stft_kernel<decltype(w)::value>, dim3((unsigned)a.T, (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
+                           dim3(kFftThreads), 0, s, a);
     });
 }
 
@@ -233,6 +336,27 @@ hipError_t launch_istft_frames(const IstftArgs& a, hipStream_t s) {
     return dispatch_window(a.W, [&](auto w) {
         hipLaunchKernelGGL(istft_frames_kernel<decltype(w)::value>, dim3((unsigned)a.T, (unsigned)a.n_channels),
                            dim3(kFftThreads), 0, s, a);
+    });
+}
+
+hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
+    IstftOlaArgs a = a0;
+    if (a.T <= 0 || a.n_out <= 0) return hipSuccess;
+    // hops that intersect [trim, trim + n_out): first = floor(trim / N), last = floor((trim + n_out - 1) / N)
+    const int N = a.W / 2;
+    a.first_hop = a.trim / N;
+    a.last_hop = (a.trim + a.n_out - 1) / N;
+    if (a.last_hop > a.T) a.last_hop = a.T;                  // hop T holds the last frame's tail, later hops are empty
+    const int64_t hops = a.last_hop - a.first_hop + 1;
+    if (hops <= 0) return hipSuccess;
+    const size_t dyn = (size_t)a.n_channels * N * sizeof(float) * 2;   // tails [C][N/2] float2 + stage [N][C]
+    if (dyn > 96 * 1024) return hipErrorInvalidValue;
+    return dispatch_window(a.W, [&](auto w) {
+        constexpr int Wc = decltype(w)::value;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, kOlaRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
+                           dim3(kFftThreads), dyn, s, a);
     });
 }
 
