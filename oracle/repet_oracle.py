@@ -383,8 +383,9 @@ def adaptive(x, fs, p=None, trace=None):
     return _finish(lambda v: adaptivemask(v, per, p.filter_order), spec, mag, window, h, n, cut, trace)
 
 
-def sim(x, fs, p=None, trace=None):
-    """repet.py:571-709."""
+def sim(x, fs, p=None, trace=None, override_indices=None):
+    """repet.py:571-709. ``override_indices`` (tests only) replaces the peak-picking result, to separate
+    discrete near-tie decisions from numerical error when checking an fp32 implementation."""
     p = p or Params()
     n, _ = np.shape(x)
     w, window, h = stft_geometry(fs)
@@ -392,6 +393,8 @@ def sim(x, fs, p=None, trace=None):
     s = selfsimilaritymatrix(np.mean(mag, axis=2))
     dist = int(round(p.similarity_distance * fs / h))
     idx = indices(s, p.similarity_threshold, dist, p.similarity_number)
+    if override_indices is not None:
+        idx = [np.asarray(ix, dtype=int) for ix in override_indices]
     cut = cutoff_bins(p, fs, w)
     if trace is not None:
         trace.put("similarity_matrix", s)
@@ -404,7 +407,7 @@ def online_frame_count(n, w, h):
     return int(np.ceil((n - w) / h + 1))
 
 
-def simonline(x, fs, p=None, trace=None):
+def simonline(x, fs, p=None, trace=None, override_indices=None):
     """repet.py:712-911, evaluated frame-parallel.
 
     The circular buffer at step j holds frames j-B+1..j; buffer column c holds frame
@@ -440,6 +443,10 @@ def simonline(x, fs, p=None, trace=None):
         simvec = unit[in_col] @ unit[j]
         _, peaks = localmaxima(simvec, p.similarity_threshold, dist, p.similarity_number)
         similar = in_col[peaks]
+        if override_indices is not None:
+            similar = np.asarray(override_indices[j - (b - 1)], dtype=int)
+        if trace is not None:
+            trace.items.setdefault("similarity_vectors", []).append((in_col, simvec))
         all_idx.append(similar)
         for c in range(ch):
             cur = mag[c, j]

@@ -117,19 +117,21 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
     REPET_STORE_TILE(p, 0)
     if (nk > 1) REPET_LOAD_TILE(q, 1)
     __syncthreads();
-    // iteration kt: LDS[kt&1] holds tile kt, one register set holds tile kt+1, the other receives kt+2
-    for (int kt = 0; kt < nk; kt += 2) {
+    // iteration kt: LDS[kt&1] holds tile kt, one register set holds tile kt+1, the other receives kt+2.
+    // The MFMA blocks are unconditional inside the loop (an odd last tile is peeled) so the accumulators
+    // stay in AGPRs across iterations instead of being copied around the control flow.
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
         if (kt + 2 < nk) REPET_LOAD_TILE(p, kt + 2)
         REPET_COMPUTE(0)
-        if (kt + 1 < nk) REPET_STORE_TILE(q, 1)
+        REPET_STORE_TILE(q, 1)
         __syncthreads();
-        if (kt + 1 < nk) {
-            if (kt + 3 < nk) REPET_LOAD_TILE(q, kt + 3)
-            REPET_COMPUTE(1)
-            if (kt + 2 < nk) REPET_STORE_TILE(p, 0)
-            __syncthreads();
-        }
+        if (kt + 3 < nk) REPET_LOAD_TILE(q, kt + 3)
+        REPET_COMPUTE(1)
+        if (kt + 2 < nk) REPET_STORE_TILE(p, 0)
+        __syncthreads();
     }
+    if (kt < nk) REPET_COMPUTE(0)
 #undef REPET_LOAD_TILE
 #undef REPET_STORE_TILE
 #undef REPET_MFMA4

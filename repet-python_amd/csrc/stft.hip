@@ -7,6 +7,9 @@
 // :158,:162,:667 and the column normalisation of :1220.
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace repet {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -307,6 +310,262 @@ __global__ __launch_bounds__(kFftThreads) void istft_ola_kernel(IstftOlaArgs a) 
     }
 }
 
+// =====================================================================================================
+// Wave-synchronous variants (default for W <= 4096): ONE 64-lane wavefront owns one transform in LDS, so
+// the radix-4 stages need no workgroup barrier -- LDS instructions of a wave execute in order, a stage
+// reads all its operands into registers before it writes, and a compiler-level fence between stages keeps
+// hipcc from caching LDS values across the cross-lane exchange. The twiddle table exp(-2 pi i m / W) and the
+// window sit in LDS, four transforms (frames x channels) are in flight per 256-thread workgroup.
+// =====================================================================================================
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// In-place Stockham FFT of N points in `buf` (LDS) by one wave. tw[m] = exp(-2 pi i m / (2N)), m < 2N (LDS).
+template <int N, bool INVERSE>
+__device__ __forceinline__ void wave_fft(float2* buf, const float2* tw, int lane) {
+    constexpr int Q4 = (N / 4 + 63) / 64;       // radix-4 butterflies per lane and stage
+    constexpr int Q2 = (N / 2 + 63) / 64;
+    for (int p = 1; p < N;) {
+        if (N / p >= 4) {
+            const int tstep = 2 * (N / (p * 4));        // table has 2N entries
+            float2 u[Q4][4];
+#pragma unroll
+            for (int b = 0; b < Q4; ++b) {
+                const int i = lane + 64 * b;
+                if (i < N / 4) { u[b][0] = buf[i]; u[b][1] = buf[i + N / 4]; u[b][2] = buf[i + N / 2]; u[b][3] = buf[i + 3 * N / 4]; }
+            }
+            wave_sync();
+#pragma unroll
+            for (int b = 0; b < Q4; ++b) {
+                const int i = lane + 64 * b;
+                if (i < N / 4) {
+                    const int k = i & (p - 1);
+                    const int j = ((i - k) << 2) + k;
+                    float2 u0 = u[b][0], u1 = u[b][1], u2 = u[b][2], u3 = u[b][3];
+                    if (p > 1) {
+                        float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                        if (INVERSE) { w1 = cconj(w1); w2 = cconj(w2); w3 = cconj(w3); }
+                        u1 = cmul(u1, w1); u2 = cmul(u2, w2); u3 = cmul(u3, w3);
+                    }
+                    const float2 t0 = cadd(u0, u2), t1 = csub(u0, u2), t2 = cadd(u1, u3);
+                    const float2 d = csub(u1, u3);
+                    const float2 t3 = INVERSE ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                    buf[j] = cadd(t0, t2);
+                    buf[j + p] = cadd(t1, t3);
+                    buf[j + 2 * p] = csub(t0, t2);
+                    buf[j + 3 * p] = csub(t1, t3);
+                }
+            }
+            p *= 4;
+        } else {
+            const int tstep = 2 * (N / (p * 2));
+            float2 u[Q2][2];
+#pragma unroll
+            for (int b = 0; b < Q2; ++b) {
+                const int i = lane + 64 * b;
+                if (i < N / 2) { u[b][0] = buf[i]; u[b][1] = buf[i + N / 2]; }
+            }
+            wave_sync();
+#pragma unroll
+            for (int b = 0; b < Q2; ++b) {
+                const int i = lane + 64 * b;
+                if (i < N / 2) {
+                    const int k = i & (p - 1);
+                    const int j = ((i - k) << 1) + k;
+                    float2 w1 = tw[k * tstep];
+                    if (INVERSE) w1 = cconj(w1);
+                    const float2 u1 = cmul(u[b][1], w1);
+                    buf[j] = cadd(u[b][0], u1);
+                    buf[j + p] = csub(u[b][0], u1);
+                }
+            }
+            p *= 2;
+        }
+        wave_sync();
+    }
+}
+
+// LDS layout of the wave kernels (float2 units): tw[W] | win[N] (w[2n], w[2n+1]) | buf[4][N] | extra
+template <int W>
+__global__ __launch_bounds__(256) void stft_wave_kernel(StftArgs a, int frames_per_wg) {
+    constexpr int N = W / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    float2* tw = lds2;
+    float2* win = lds2 + W;
+    float2* bufs = win + N;
+    float* vst = reinterpret_cast<float*>(bufs + 4 * N);     // [jobs per round][FS] magnitudes
+    __shared__ float red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.n_channels;
+    const int64_t b = blockIdx.y;
+    a.sample_offset += b * a.batch_sample_stride;
+    a.X += b * a.batch_spec_stride;
+    a.V += b * a.batch_spec_stride;
+    if (a.Vm) a.Vm += b * a.batch_mean_stride;
+    if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.P) a.P += b * a.batch_mean_stride;
+
+    for (int i = tid; i < W; i += 256) tw[i] = a.twiddle[i];
+    for (int i = tid; i < N; i += 256) win[i] = make_float2(a.window[2 * i], a.window[2 * i + 1]);
+    __syncthreads();
+
+    const int FI = C >= 4 ? 1 : 4 / C;          // frames per round (C = 3: one frame, three waves busy)
+    const int JR = FI * C;                      // transforms per round (<= 8)
+    const int64_t t_begin = (int64_t)blockIdx.x * frames_per_wg;
+    const int64_t t_end = (t_begin + frames_per_wg < a.T) ? t_begin + frames_per_wg : a.T;
+    float2* buf = bufs + wave * N;
+    const bool want_mean = a.Vm || a.Vn || a.P;
+
+    for (int64_t t0 = t_begin; t0 < t_end; t0 += FI) {
+        for (int job = wave; job < JR; job += 4) {
+            const int df = job / C, c = job - df * C;
+            const int64_t t = t0 + df;
+            if (t >= t_end) continue;
+            const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
+            for (int n = lane; n < N; n += 64) {
+                const int64_t s0 = start + 2 * n, s1 = s0 + 1;
+                float x0 = 0.f, x1 = 0.f;
+                if (s0 >= 0 && s0 < a.n_samples) x0 = a.audio[(a.sample_offset + s0) * C + c];
+                if (s1 >= 0 && s1 < a.n_samples) x1 = a.audio[(a.sample_offset + s1) * C + c];
+                const float2 w = win[n];
+                buf[n] = make_float2(x0 * w.x, x1 * w.y);
+            }
+            wave_sync();
+            wave_fft<N, false>(buf, tw, lane);
+            const int64_t row = t * a.FS;
+            float2* Xrow = a.X + c * a.chan_stride + row;
+            float* Vrow = a.V + c * a.chan_stride + row;
+            float* vrow = vst + job * a.FS;
+            for (int k = lane; k <= N; k += 64) {
+                const float2 zk = buf[k & (N - 1)];
+                const float2 zc = cconj(buf[(N - k) & (N - 1)]);
+                const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+                const float2 d = csub(zk, zc);
+                const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);   // (zk - zc) / (2i)
+                const float2 x = cadd(e, cmul(tw[k], o));
+                const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                Xrow[k] = x;
+                Vrow[k] = mag;
+                vrow[k] = mag;
+            }
+            if (lane < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
+                Xrow[N + 1 + lane] = make_float2(0.f, 0.f);
+                Vrow[N + 1 + lane] = 0.f;
+            }
+            wave_sync();                      // buf is refilled by this wave's next job
+        }
+        if (!want_mean) continue;
+        __syncthreads();
+        for (int df = 0; df < FI; ++df) {
+            const int64_t t = t0 + df;
+            if (t >= t_end) break;
+            const int64_t row = t * a.FS;
+            // channel mean (repet.py:162,:667) and its L2 norm over frequency (repet.py:1220)
+            float ss = 0.f;
+            for (int k = tid; k <= N; k += 256) {
+                float m = 0.f;
+                for (int c = 0; c < C; ++c) m += vst[(df * C + c) * a.FS + k];
+                if (C > 1) m *= 1.0f / (float)C;
+                vst[(df * C) * a.FS + k] = m;                 // channel 0's slot now holds the mean
+                ss += m * m;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));   // 0 for a silent frame: NaN row
+            for (int k = tid; k < a.FS; k += 256) {
+                const float m = (k <= N) ? vst[(df * C) * a.FS + k] : 0.f;
+                if (a.Vm) a.Vm[row + k] = m;
+                if (a.Vn) a.Vn[row + k] = (k <= N) ? m / norm : 0.f;
+                if (a.P) a.P[row + k] = m * m;
+            }
+            __syncthreads();                  // red[] and vst are reused
+        }
+    }
+}
+
+// Fused inverse: RUN hops per workgroup, FI frames x C channels inverted per round by the four waves,
+// then all threads add heads and tails and write whole hops, interleaved over the channels.
+template <int W>
+__global__ __launch_bounds__(256) void istft_ola_wave_kernel(IstftOlaArgs a, int run) {
+    constexpr int N = W / 2;          // samples per hop
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    float2* tw = lds2;
+    float2* bufs = lds2 + W;                                        // [4][N] complex = [4][W] samples
+    float* tails = reinterpret_cast<float*>(bufs + 4 * N);          // [C][N] second half of the previous frame
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.n_channels;
+    if (a.n_batch > 0) {
+        const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
+        a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        a.out_offset += (int64_t)j * a.batch_out_stride;
+        a.fade_in = j > 0 ? a.overlap : 0;
+        a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
+    }
+    for (int i = tid; i < W; i += 256) tw[i] = a.twiddle[i];
+    for (int i = tid; i < C * N; i += 256) tails[i] = 0.f;
+    __syncthreads();
+
+    const int FI = 4 / C;                       // frames per round (C <= 4)
+    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * run;
+    int64_t h1 = h0 + run - 1;
+    if (h1 > a.last_hop) h1 = a.last_hop;
+    float2* buf = bufs + wave * N;
+    const float inv_n = a.scale / (float)N;
+    // frames h0-1 .. h1 ; frame t feeds hop t (first half) and hop t+1 (second half)
+    for (int64_t t0 = h0 - 1; t0 <= h1; t0 += FI) {
+        if (wave < FI * C) {
+            const int df = wave / C, c = wave - df * C;
+            const int64_t t = t0 + df;
+            if (t >= 0 && t < a.T && t <= h1) {
+                const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
+                for (int k = lane; k < N; k += 64) {
+                    const float2 xk = Y[k];
+                    const float2 xc = cconj(Y[N - k]);
+                    const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+                    const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+                    const float2 o = cmul(d, cconj(tw[k]));
+                    buf[k] = make_float2(e.x - o.y, e.y + o.x);
+                }
+                wave_sync();
+                wave_fft<N, true>(buf, tw, lane);
+            } else {
+                for (int k = lane; k < N; k += 64) buf[k] = make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        const float* samples = reinterpret_cast<const float*>(bufs);   // [4][W]
+        for (int i = tid; i < N * C; i += 256) {
+            const int sidx = i / C, c = i - sidx * C;
+            float prev = tails[c * N + sidx];
+            for (int df = 0; df < FI; ++df) {
+                const int64_t h = t0 + df;                     // hop fed by the first half of frame t0+df
+                const float* fr = samples + (df * C + c) * W;
+                const float v = (prev + fr[sidx]) * inv_n;
+                prev = fr[N + sidx];
+                if (h < h0 || h > h1) continue;
+                const int64_t n = h * N - a.trim + sidx;
+                if (n < 0 || n >= a.n_out) continue;
+                float* dst = a.out + (a.out_offset + n) * C + c;
+                if (a.accumulate_weighted) {
+                    float w = 1.f;
+                    if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
+                    else if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w = (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
+                    *dst += w * v;
+                } else {
+                    *dst = v;
+                }
+            }
+            tails[c * N + sidx] = prev;
+        }
+        __syncthreads();
+    }
+}
+
 template <typename Fn>
 static hipError_t dispatch_window(int W, Fn&& fn) {
     switch (W) {
@@ -323,8 +582,30 @@ static hipError_t dispatch_window(int W, Fn&& fn) {
     return hipGetLastError();
 }
 
+static bool use_wave_kernels() {
+    static const bool on = [] { const char* e = getenv("REPET_FFT_PATH"); return e && e[0] == 'w'; }();   // "wave" selects the wave-synchronous kernels (slower today: see DESIGN.md)
+    return on;
+}
+constexpr int kStftFramesPerWg = 8;
+constexpr int kOlaWaveRun = 15;      // + the frame before = 16 frames per workgroup
+
 hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
     if (a.T <= 0) return hipSuccess;
+    if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 8) {
+        const int C = a.n_channels, N = a.W / 2;
+        const int FI = C >= 4 ? 1 : 4 / C;
+        const size_t dyn = (size_t)(a.W + N + 4 * N) * sizeof(float2) + (size_t)FI * C * a.FS * sizeof(float);
+        const int fpw = (int)round_up(kStftFramesPerWg, FI);
+        return dispatch_window(a.W, [&](auto w) {
+            constexpr int Wc = decltype(w)::value;
+            if constexpr (Wc <= 4096) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_wave_kernel<Wc>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                hipLaunchKernelGGL(stft_wave_kernel<Wc>, dim3((unsigned)ceil_div(a.T, fpw), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
+                                   dim3(256), dyn, s, a, fpw);
+            }
+        });
+    }
     return dispatch_window(a.W, [&](auto w) {
         hipLaunchKernelGGL(stft_kernel<decltype(w)::value>, dim3((unsigned)a.T, (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
                            dim3(kFftThreads), 0, s, a);
@@ -349,6 +630,21 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     if (a.last_hop > a.T) a.last_hop = a.T;                  // hop T holds the last frame's tail, later hops are empty
     const int64_t hops = a.last_hop - a.first_hop + 1;
     if (hops <= 0) return hipSuccess;
+    if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 4 && a.n_channels != 3) {
+        const int C = a.n_channels;
+        const int FI = 4 / C;
+        const int run = (int)round_up(kOlaWaveRun + 1, FI) - 1;
+        const size_t dynw = (size_t)(a.W + 4 * N) * sizeof(float2) + (size_t)C * N * sizeof(float);
+        return dispatch_window(a.W, [&](auto w) {
+            constexpr int Wc = decltype(w)::value;
+            if constexpr (Wc <= 4096) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_wave_kernel<Wc>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw);
+                hipLaunchKernelGGL(istft_ola_wave_kernel<Wc>, dim3((unsigned)ceil_div(hops, run), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
+                                   dim3(256), dynw, s, a, run);
+            }
+        });
+    }
     const size_t dyn = (size_t)a.n_channels * N * sizeof(float) * 2;   // tails [C][N/2] float2 + stage [N][C]
     if (dyn > 96 * 1024) return hipErrorInvalidValue;
     return dispatch_window(a.W, [&](auto w) {

@@ -6,7 +6,7 @@ import pytest
 
 import repet
 from repet import _native, parallel
-from helpers import golden_input, load_edge_cases, load_golden, rms_err
+from helpers import assert_parity_modulo_near_ties, golden_input, load_edge_cases, load_golden, rms_err
 from oracle import repet_oracle as orc
 from repet_synth import synth
 
@@ -189,3 +189,55 @@ def test_sim_headline_config_properties():
     # the soft mask never amplifies: background energy <= mixture energy per second (COLA-exact STFT)
     mix = np.sqrt(np.mean(np.array(x[:n]).reshape(-1, fs, 2) ** 2, axis=1))
     assert np.all(per_s <= mix * 1.001 + 1e-6)
+
+
+@pytest.mark.parametrize("fs,channels,seconds", [(4000, 1, 24), (8000, 3, 14), (22050, 4, 13), (96000, 1, 11),
+                                                  (48000, 2, 12), (11025, 5, 12)])
+@pytest.mark.parametrize("algo", ALGOS)
+def test_other_rates_and_channel_counts(algo, fs, channels, seconds):
+    """Window lengths 256..4096, 1-5 channels (block and per-channel kernel paths), every variant."""
+    x = synth(seconds, fs, channels, 40 + channels)
+    if algo in ("sim", "simonline"):
+        assert_parity_modulo_near_ties(algo, x, fs)
+        return
+    got = getattr(repet, algo)(x, fs)
+    want = orc.ALGORITHMS[algo](x, fs)
+    assert got.shape == x.shape
+    assert rms_err(got, want) <= RMS_TOL, f"rms {rms_err(got, want):.3e}"
+
+
+def test_wave_fft_path_matches_block_path():
+    """REPET_FFT_PATH=wave selects the wave-synchronous STFT/iSTFT kernels; both paths must agree."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "x = synth(6, 44100, 2, 3); y = repet.original(x, 44100); z = repet.sim(x, 44100); "
+            "np.save(sys.argv[1], np.stack([y, z]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for path in ("block", "wave"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_fft_{path}_{os.getpid()}.npy")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_FFT_PATH=path))
+        outs.append(np.load(out))
+        os.remove(out)
+    assert rms_err(outs[0], outs[1]) < 2e-6
+
+
+def test_long_similarity_number_uses_bisection_path():
+    """similarity_number > 128 takes the bisection median (no sorting network of that size)."""
+    x, fs = golden_input("small_stereo")
+    saved = (repet.similarity_number, repet.similarity_distance)
+    try:
+        repet.similarity_number = 300
+        repet.similarity_distance = 0.005         # 0 frames: every frame is a candidate, the 300 most similar are kept
+        assert_parity_modulo_near_ties("sim", x, fs, dict(similarity_number=300, similarity_distance=0.005))
+        ctx = repet.Context(0)
+        ctx.upload(x)
+        ctx.execute("sim", repet.derive_params(fs))
+        _, cnt = ctx.last_sim_indices(ctx.last_frame_count(), 300)
+        ctx.close()
+        assert cnt.max() > 128                    # the bisection median really ran
+    finally:
+        repet.similarity_number, repet.similarity_distance = saved
