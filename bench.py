@@ -44,9 +44,9 @@ def cpu_baseline(fs, channels, seconds):
     except Exception:  # noqa: BLE001
         blas = os.cpu_count() or 1
     return {"value": round(seconds / dt, 4), "unit": "audio-seconds/sec", "cores": int(blas), "kind": "port",
-            "sample": f"oracle.sim (NumPy float64 port of repet.py) on one {seconds}-s {fs} Hz {channels}-ch synth clip, "
-                      f"{dt:.1f} s wall; single-threaded except the similarity matmul ({blas} BLAS threads); "
-                      f"host has {os.cpu_count()} logical cores. sim is O(T^2): the 180-s clip is slower per audio-second"}
+            "sample": f"oracle.sim (NumPy float64 port of repet.py) on one {seconds:g}-s {fs} Hz {channels}-ch synth clip "
+                      f"(the bench workload itself when 180 s), {dt:.1f} s wall; single-threaded except the similarity "
+                      f"matmul ({blas} BLAS threads); host has {os.cpu_count()} logical cores"}
 
 
 def main():
@@ -63,7 +63,8 @@ def main():
                     help="BASELINE.json configs[i-1]: 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz mono, "
                          "5 simonline 30-s clips (64 over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="length of the CPU-baseline sample clip")
+    ap.add_argument("--cpu-seconds", type=float, default=180.0,
+                    help="length of the CPU-baseline clip (default: the whole config-2 clip, ~25 s of host time)")
     args = ap.parse_args()
 
     if args.config == 3:
@@ -148,6 +149,15 @@ def main():
             ach = meta["bytes"] / (dom["ms"] * 1e-3) / 1e9
             roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        # HBM bytes per launch from the committed PMC pass of this same workload (profiles/), if it is this workload
+        try:
+            if args.config == 2 and args.algo == "sim" and args.duration == 180.0:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                    pmc = json.load(fh)["stages"][dom["name"]]
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["traffic_note"] = "FETCH_SIZE*1024*k + WRITE_SIZE*1024 per launch, fetch correction " + pmc["fetch_correction"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof["ms_per_launch"] = dom["ms"]
         roof["algorithmic_per_launch"] = meta["flops"] if roof["bound"] == "mfma" else meta["bytes"]
         line = {
