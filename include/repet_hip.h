@@ -96,6 +96,11 @@ int repet_ctx_destroy(repet_ctx* ctx);
 int repet_ctx_upload(repet_ctx* ctx, const void* audio, int dtype, int64_t n_samples, int32_t n_channels);
 int repet_ctx_execute(repet_ctx* ctx, int algo, const repet_params* p, repet_timing* timing /* nullable */);
 int repet_ctx_download(repet_ctx* ctx, double* out);
+/* Non-blocking form of execute: enqueues the whole run on the context's stream and returns; contexts have
+ * their own streams, so runs of different contexts overlap on the device. Errors detected at enqueue time are
+ * returned here, device-side failures by repet_ctx_synchronize (or the next blocking call). */
+int repet_ctx_execute_async(repet_ctx* ctx, int algo, const repet_params* p);
+int repet_ctx_synchronize(repet_ctx* ctx);
 
 /* extended only (repet.py:205-419): the segment plan of an n_samples clip (repet.py:271-281), and a run
  * restricted to segments [first, first+n_segments). Contributions of the other segments stay zero, and

@@ -604,6 +604,32 @@ int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timin
     return rc;
 }
 
+int repet_ctx_execute_async(repet_ctx* c, int algo, const repet_params* p) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    RP_TRY(check_params(p));
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    DeviceGuard guard(c->device);
+    c->timing = nullptr;
+    c->last_algo = algo;
+    c->last_n_periods = 0;
+    c->last_idx_rows = 0;
+    switch (algo) {
+        case REPET_ORIGINAL: return exec_original(c, p);
+        case REPET_EXTENDED: return exec_extended(c, p);
+        case REPET_ADAPTIVE: return exec_adaptive(c, p);
+        case REPET_SIM: return exec_sim(c, p);
+        case REPET_SIMONLINE: return exec_simonline(c, p);
+        default: return fail(REPET_ERR_BAD_ARG, "unknown algorithm");
+    }
+}
+
+int repet_ctx_synchronize(repet_ctx* c) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
 int64_t repet_extended_segment_count(int64_t n_samples, const repet_params* p) {
     if (!p) return -1;
     return extended_segment_count(n_samples, p);

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "repet_ctx_upload": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int32]),
     "repet_ctx_execute": (C.c_int, [_P, C.c_int, C.POINTER(Params), C.POINTER(Timing)]),
     "repet_ctx_download": (C.c_int, [_P, _P]),
+    "repet_ctx_execute_async": (C.c_int, [_P, C.c_int, C.POINTER(Params)]),
+    "repet_ctx_synchronize": (C.c_int, [_P]),
     "repet_extended_segment_count": (C.c_int64, [C.c_int64, C.POINTER(Params)]),
     "repet_ctx_execute_extended_range": (C.c_int, [_P, C.POINTER(Params), C.c_int64, C.c_int64, C.POINTER(Timing)]),
     "repet_run": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int32, C.POINTER(Params), _P, C.c_int,
@@ -160,6 +162,12 @@ class Context:
         check(lib().repet_ctx_execute(self._h, ALGO_IDS[algo] if isinstance(algo, str) else algo,
                                       C.byref(params), C.byref(t) if timing else None))
         return t.as_dict() if timing else None
+
+    def execute_async(self, algo, params):
+        check(lib().repet_ctx_execute_async(self._h, ALGO_IDS[algo] if isinstance(algo, str) else algo, C.byref(params)))
+
+    def synchronize(self):
+        check(lib().repet_ctx_synchronize(self._h))
 
     def execute_extended_range(self, params, first, n_segments):
         check(lib().repet_ctx_execute_extended_range(self._h, C.byref(params), int(first), int(n_segments), None))
