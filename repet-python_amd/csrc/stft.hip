@@ -68,20 +68,115 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const float2* _
 
 constexpr int kFftThreads = 256;
 
+// Same Stockham FFT with the per-thread stage twiddles held in registers. Thread `tid` always owns the
+// butterflies i = tid + 256*q (q < BPT), whose twiddle exponent k = i & (p-1) depends only on the stage, so
+// the 3 twiddles per butterfly and stage are loaded ONCE per workgroup (fft_twiddles) and reused for every
+// transform the workgroup performs -- the global twiddle fetch leaves the per-stage critical path.
+template <int N> struct FftPlan {
+    static constexpr int kRadix4Stages = []() { int s = 0; for (int p = 1; N / p >= 4; p *= 4) ++s; return s; }();
+    static constexpr bool kFinalRadix2 = (N >> (2 * kRadix4Stages)) == 2;
+    static constexpr int kBpt4 = (N / 4 + kFftThreads - 1) / kFftThreads;     // radix-4 butterflies per thread
+    static constexpr int kBpt2 = (N / 2 + kFftThreads - 1) / kFftThreads;
+};
+
+template <int N>
+struct FftTwiddles {
+    float2 w4[FftPlan<N>::kRadix4Stages > 0 ? FftPlan<N>::kRadix4Stages : 1][FftPlan<N>::kBpt4][3];
+    float2 w2[FftPlan<N>::kBpt2];
+};
+
+template <int N, bool INVERSE>
+__device__ __forceinline__ void fft_twiddles(FftTwiddles<N>& t, const float2* __restrict__ tw, int TW) {
+    using P = FftPlan<N>;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < P::kRadix4Stages; ++s) {
+        const int p = 1 << (2 * s);
+        const int tstep = TW / (p * 4);
+#pragma unroll
+        for (int q = 0; q < P::kBpt4; ++q) {
+            const int i = tid + kFftThreads * q;
+            const int k = i & (p - 1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float2 w = (i < N / 4) ? tw[(r + 1) * k * tstep] : make_float2(1.f, 0.f);
+                t.w4[s][q][r] = INVERSE ? cconj(w) : w;
+            }
+        }
+    }
+    if (P::kFinalRadix2) {
+        const int p = N / 2;
+        const int tstep = TW / (p * 2);
+#pragma unroll
+        for (int q = 0; q < P::kBpt2; ++q) {
+            const int i = tid + kFftThreads * q;
+            float2 w = (i < N / 2) ? tw[(i & (p - 1)) * tstep] : make_float2(1.f, 0.f);
+            t.w2[q] = INVERSE ? cconj(w) : w;
+        }
+    }
+}
+
+template <int N, bool INVERSE>
+__device__ __forceinline__ float2* fft_lds_regs(float2* a, float2* b, const FftTwiddles<N>& t) {
+    using P = FftPlan<N>;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < P::kRadix4Stages; ++s) {
+        const int p = 1 << (2 * s);
+#pragma unroll
+        for (int q = 0; q < P::kBpt4; ++q) {
+            const int i = tid + kFftThreads * q;
+            if (i < N / 4) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 2) + k;
+                float2 u0 = a[i], u1 = a[i + N / 4], u2 = a[i + N / 2], u3 = a[i + 3 * N / 4];
+                if (s > 0) { u1 = cmul(u1, t.w4[s][q][0]); u2 = cmul(u2, t.w4[s][q][1]); u3 = cmul(u3, t.w4[s][q][2]); }
+                const float2 t0 = cadd(u0, u2), t1 = csub(u0, u2), t2 = cadd(u1, u3);
+                const float2 d = csub(u1, u3);
+                const float2 t3 = INVERSE ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                b[j] = cadd(t0, t2);
+                b[j + p] = cadd(t1, t3);
+                b[j + 2 * p] = csub(t0, t2);
+                b[j + 3 * p] = csub(t1, t3);
+            }
+        }
+        __syncthreads();
+        float2* tmp = a; a = b; b = tmp;
+    }
+    if (P::kFinalRadix2) {
+        const int p = N / 2;
+#pragma unroll
+        for (int q = 0; q < P::kBpt2; ++q) {
+            const int i = tid + kFftThreads * q;
+            if (i < N / 2) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 1) + k;
+                const float2 u0 = a[i];
+                const float2 u1 = cmul(a[i + N / 2], t.w2[q]);
+                b[j] = cadd(u0, u1);
+                b[j + p] = csub(u0, u1);
+            }
+        }
+        __syncthreads();
+        float2* tmp = a; a = b; b = tmp;
+    }
+    return a;
+}
+
+constexpr int kStftFrameRun = 4;     // frames per workgroup: the register tables are loaded once per run
+
 template <int W>
-__global__ __launch_bounds__(kFftThreads) void stft_kernel(StftArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? 4 : 1, 8))) void stft_kernel(StftArgs a) {
     constexpr int N = W / 2;                       // complex FFT length; also the Nyquist bin index
     constexpr int SLOTS = N / kFftThreads + 1;     // bins k = tid + 256*i, k <= N
+    constexpr int LOADS = (N + kFftThreads - 1) / kFftThreads;
     __shared__ float2 buf0[N];
     __shared__ float2 buf1[N];
     __shared__ float red[kFftThreads / kWave];
 
     const int tid = threadIdx.x;
-    const int64_t t = blockIdx.x;
     const int64_t b = blockIdx.y;
     const int C = a.n_channels;
-    const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
-    const int64_t row = t * a.FS;
     a.sample_offset += b * a.batch_sample_stride;
     a.X += b * a.batch_spec_stride;
     a.V += b * a.batch_spec_stride;
@@ -89,77 +184,92 @@ __global__ __launch_bounds__(kFftThreads) void stft_kernel(StftArgs a) {
     if (a.Vn) a.Vn += b * a.batch_mean_stride;
     if (a.P) a.P += b * a.batch_mean_stride;
 
-    float acc[SLOTS];
+    // per-thread stage twiddles, loaded once (window and split twiddles stay in L1/L2: registers buy occupancy)
+    FftTwiddles<N> ft;
+    fft_twiddles<N, false>(ft, a.twiddle, W);
+    const int64_t t_begin = (int64_t)blockIdx.x * kStftFrameRun;
+    const int64_t t_end = (t_begin + kStftFrameRun < a.T) ? t_begin + kStftFrameRun : a.T;
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
+        const int64_t row = t * a.FS;
+        float acc[SLOTS];
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) acc[i] = 0.f;
+        for (int i = 0; i < SLOTS; ++i) acc[i] = 0.f;
 
-    for (int c = 0; c < C; ++c) {
-        for (int n = tid; n < N; n += kFftThreads) {
-            const int64_t s0 = start + 2 * n, s1 = s0 + 1;
-            float x0 = 0.f, x1 = 0.f;
-            if (s0 >= 0 && s0 < a.n_samples) x0 = a.audio[(a.sample_offset + s0) * C + c];
-            if (s1 >= 0 && s1 < a.n_samples) x1 = a.audio[(a.sample_offset + s1) * C + c];
-            buf0[n] = make_float2(x0 * a.window[2 * n], x1 * a.window[2 * n + 1]);
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int n = tid + kFftThreads * i;
+                if (n < N) {
+                    const int64_t s0 = start + 2 * n, s1 = s0 + 1;
+                    float x0 = 0.f, x1 = 0.f;
+                    if (s0 >= 0 && s0 < a.n_samples) x0 = a.audio[(a.sample_offset + s0) * C + c];
+                    if (s1 >= 0 && s1 < a.n_samples) x1 = a.audio[(a.sample_offset + s1) * C + c];
+                    const float2 w = *reinterpret_cast<const float2*>(a.window + 2 * n);
+                    buf0[n] = make_float2(x0 * w.x, x1 * w.y);
+                }
+            }
+            __syncthreads();
+            const float2* Z = fft_lds_regs<N, false>(buf0, buf1, ft);
+            float2* Xrow = a.X + c * a.chan_stride + row;
+            float* Vrow = a.V + c * a.chan_stride + row;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int k = tid + kFftThreads * i;
+                if (k <= N) {
+                    const float2 zk = Z[k & (N - 1)];
+                    const float2 zc = cconj(Z[(N - k) & (N - 1)]);
+                    const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+                    const float2 d = csub(zk, zc);
+                    const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);   // (zk - zc) / (2i)
+                    const float2 x = cadd(e, cmul(a.twiddle[k], o));
+                    const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                    Xrow[k] = x;
+                    Vrow[k] = mag;
+                    acc[i] += mag;
+                }
+            }
+            if (tid < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
+                Xrow[N + 1 + tid] = make_float2(0.f, 0.f);
+                Vrow[N + 1 + tid] = 0.f;
+            }
+            __syncthreads();                 // Z (buf0/buf1) is re-filled by the next channel / frame
         }
+
+        if (a.Vm == nullptr && a.Vn == nullptr && a.P == nullptr) continue;
+
+        // channel mean (repet.py:162,:667 np.mean(axis=2)) and its squared L2 norm over frequency
+        const float inv_c = 1.0f / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int k = tid + kFftThreads * i;
+            acc[i] = (C == 1) ? acc[i] : acc[i] * inv_c;
+            if (k <= N) ss += acc[i] * acc[i];
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) ss += __shfl_down(ss, off);
+        if ((tid & (kWave - 1)) == 0) red[tid / kWave] = ss;
         __syncthreads();
-        const float2* Z = fft_lds<N, false>(buf0, buf1, a.twiddle, W);
-        float2* Xrow = a.X + c * a.chan_stride + row;
-        float* Vrow = a.V + c * a.chan_stride + row;
+        float total = 0.f;
+#pragma unroll
+        for (int w = 0; w < kFftThreads / kWave; ++w) total += red[w];
+        const float norm = sqrtf(total);     // 0 for a silent frame: 0/0 = NaN like repet.py:1220
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int k = tid + kFftThreads * i;
             if (k <= N) {
-                const float2 zk = Z[k & (N - 1)];
-                const float2 zc = cconj(Z[(N - k) & (N - 1)]);
-                const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
-                const float2 d = csub(zk, zc);
-                const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);   // (zk - zc) / (2i)
-                const float2 x = cadd(e, cmul(a.twiddle[k], o));
-                const float mag = sqrtf(x.x * x.x + x.y * x.y);
-                Xrow[k] = x;
-                Vrow[k] = mag;
-                acc[i] += mag;
+                if (a.Vm) a.Vm[row + k] = acc[i];
+                if (a.Vn) a.Vn[row + k] = acc[i] / norm;
+                if (a.P) a.P[row + k] = acc[i] * acc[i];
             }
         }
-        if (tid < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
-            Xrow[N + 1 + tid] = make_float2(0.f, 0.f);
-            Vrow[N + 1 + tid] = 0.f;
+        if (tid < a.FS - (N + 1)) {
+            if (a.Vm) a.Vm[row + N + 1 + tid] = 0.f;
+            if (a.Vn) a.Vn[row + N + 1 + tid] = 0.f;
+            if (a.P) a.P[row + N + 1 + tid] = 0.f;
         }
-        __syncthreads();                 // Z (buf0/buf1) is re-filled by the next channel
-    }
-
-    if (a.Vm == nullptr && a.Vn == nullptr && a.P == nullptr) return;
-
-    // channel mean (repet.py:162,:667 np.mean(axis=2)) and its squared L2 norm over frequency
-    const float inv_c = 1.0f / (float)C;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-        const int k = tid + kFftThreads * i;
-        acc[i] = (C == 1) ? acc[i] : acc[i] * inv_c;
-        if (k <= N) ss += acc[i] * acc[i];
-    }
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) ss += __shfl_down(ss, off);
-    if ((tid & (kWave - 1)) == 0) red[tid / kWave] = ss;
-    __syncthreads();
-    float total = 0.f;
-#pragma unroll
-    for (int w = 0; w < kFftThreads / kWave; ++w) total += red[w];
-    const float norm = sqrtf(total);     // 0 for a silent frame: 0/0 = NaN like repet.py:1220
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-        const int k = tid + kFftThreads * i;
-        if (k <= N) {
-            if (a.Vm) a.Vm[row + k] = acc[i];
-            if (a.Vn) a.Vn[row + k] = acc[i] / norm;
-            if (a.P) a.P[row + k] = acc[i] * acc[i];
-        }
-    }
-    if (tid < a.FS - (N + 1)) {
-        if (a.Vm) a.Vm[row + N + 1 + tid] = 0.f;
-        if (a.Vn) a.Vn[row + N + 1 + tid] = 0.f;
-        if (a.P) a.P[row + N + 1 + tid] = 0.f;
+        __syncthreads();                     // red[] is reused by the next frame
     }
 }
 
@@ -222,19 +332,55 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(OlaArgs a) {
 // the interleaved channels.
 constexpr int kOlaRun = 8;
 template <int W>
-__device__ __forceinline__ const float2* inverse_frame(const float2* __restrict__ Y, const float2* __restrict__ tw,
+struct InverseTables {
+    FftTwiddles<W / 2> ft;
+    float2 wk[(W / 2 + kFftThreads - 1) / kFftThreads];      // conj(exp(-2 pi i k / W)) for k = tid + 256*i
+};
+
+template <int W>
+__device__ __forceinline__ void inverse_tables(InverseTables<W>& t, const float2* __restrict__ tw) {
+    constexpr int N = W / 2;
+    fft_twiddles<N, true>(t.ft, tw, W);
+#pragma unroll
+    for (int i = 0; i < (N + kFftThreads - 1) / kFftThreads; ++i) {
+        const int k = threadIdx.x + kFftThreads * i;
+        t.wk[i] = (k < N) ? cconj(tw[k]) : make_float2(0.f, 0.f);
+    }
+}
+
+template <int W>
+struct SpectrumRegs { float2 xk[(W / 2 + kFftThreads - 1) / kFftThreads], xc[(W / 2 + kFftThreads - 1) / kFftThreads]; };
+
+template <int W>
+__device__ __forceinline__ void fetch_spectrum(SpectrumRegs<W>& r, const float2* __restrict__ Y) {
+    constexpr int N = W / 2;
+#pragma unroll
+    for (int i = 0; i < (N + kFftThreads - 1) / kFftThreads; ++i) {
+        const int k = threadIdx.x + kFftThreads * i;
+        if (k < N) { r.xk[i] = Y[k]; r.xc[i] = Y[N - k]; }
+    }
+}
+
+// Hermitian repack of a fetched (masked) spectrum + inverse W/2-point FFT; returns the LDS buffer holding
+// the W time samples (unscaled).
+template <int W>
+__device__ __forceinline__ const float2* inverse_frame(const SpectrumRegs<W>& r, const InverseTables<W>& t,
                                                        float2* buf0, float2* buf1) {
     constexpr int N = W / 2;
-    for (int k = threadIdx.x; k < N; k += kFftThreads) {
-        const float2 xk = Y[k];
-        const float2 xc = cconj(Y[N - k]);
-        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
-        const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
-        const float2 o = cmul(d, cconj(tw[k]));
-        buf0[k] = make_float2(e.x - o.y, e.y + o.x);
+#pragma unroll
+    for (int i = 0; i < (N + kFftThreads - 1) / kFftThreads; ++i) {
+        const int k = threadIdx.x + kFftThreads * i;
+        if (k < N) {
+            const float2 xk = r.xk[i];
+            const float2 xc = cconj(r.xc[i]);
+            const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+            const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+            const float2 o = cmul(d, t.wk[i]);
+            buf0[k] = make_float2(e.x - o.y, e.y + o.x);
+        }
     }
     __syncthreads();
-    return fft_lds<N, true>(buf0, buf1, tw, W);
+    return fft_lds_regs<N, true>(buf0, buf1, t.ft);
 }
 
 template <int W>
@@ -250,6 +396,8 @@ __global__ __launch_bounds__(kFftThreads) void istft_ola_kernel(IstftOlaArgs a) 
     const int tid = threadIdx.x;
     const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * kOlaRun;
     const float inv_n = 1.0f / (float)N;
+    InverseTables<W> tables;
+    inverse_tables<W>(tables, a.twiddle);
     if (a.n_batch > 0) {
         const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
@@ -258,10 +406,12 @@ __global__ __launch_bounds__(kFftThreads) void istft_ola_kernel(IstftOlaArgs a) 
         a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
     }
 
+    SpectrumRegs<W> spec;
     for (int c = 0; c < C; ++c) {                              // tails of frame h0-1
         const int64_t t = h0 - 1;
         if (t >= 0 && t < a.T) {
-            const float2* z = inverse_frame<W>(a.Y + c * a.chan_stride + t * a.FS, a.twiddle, buf0, buf1);
+            fetch_spectrum<W>(spec, a.Y + c * a.chan_stride + t * a.FS);
+            const float2* z = inverse_frame<W>(spec, tables, buf0, buf1);
             for (int m = tid; m < HP; m += kFftThreads) tails[c * HP + m] = z[HP + m];
         } else {
             for (int m = tid; m < HP; m += kFftThreads) tails[c * HP + m] = make_float2(0.f, 0.f);
@@ -273,7 +423,8 @@ __global__ __launch_bounds__(kFftThreads) void istft_ola_kernel(IstftOlaArgs a) 
         if (h > a.last_hop) break;
         for (int c = 0; c < C; ++c) {
             if (h < a.T) {
-                const float2* z = inverse_frame<W>(a.Y + c * a.chan_stride + h * a.FS, a.twiddle, buf0, buf1);
+                fetch_spectrum<W>(spec, a.Y + c * a.chan_stride + h * a.FS);
+                const float2* z = inverse_frame<W>(spec, tables, buf0, buf1);
                 for (int m = tid; m < HP; m += kFftThreads) {
                     const float2 head = z[m], tail = tails[c * HP + m];
                     stage[(2 * m) * C + c] = (head.x + tail.x) * inv_n;
@@ -607,7 +758,8 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
         });
     }
     return dispatch_window(a.W, [&](auto w) {
-        hipLaunchKernelGGL(stft_kernel<decltype(w)::value>, dim3((unsigned)a.T, (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
+        hipLaunchKernelGGL(stft_kernel<decltype(w)::value>,
+                           dim3((unsigned)ceil_div(a.T, kStftFrameRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
                            dim3(kFftThreads), 0, s, a);
     });
 }
