@@ -22,6 +22,13 @@
 
 namespace repet {
 
+#ifdef REPET_PEAK_STAMPS
+__device__ unsigned long long g_peak_stamps[8 * 64];
+#define STAMP(k) if (threadIdx.x == 0 && (blockIdx.x % 997) == 5 && blockIdx.x / 997 < 8) g_peak_stamps[(blockIdx.x / 997) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(k)
+#endif
+
 __device__ __forceinline__ int wave_prefix_slot(bool flag, int* counter, int lane) {
     // returns the list slot of this lane if flag, using one LDS atomic per wave
     const unsigned long long ballot = __ballot(flag);
@@ -48,7 +55,6 @@ template <int QMAX>
 __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* M4 = reinterpret_cast<float4*>(smem);              // groups float4 (row, then window maxima)
-    float* M = smem;
     float* pval = smem + 4 * a.groups;                         // peak_cap (multiple of 4)
     int* pidx = reinterpret_cast<int*>(pval + a.peak_cap);     // peak_cap
     __shared__ int n_peak;
@@ -58,6 +64,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
     const int64_t r = blockIdx.x;           // row within this launch
     const int64_t j = a.row0 + r;           // absolute row (mode 1: current frame)
     if (tid == 0) n_peak = 0;
+    STAMP(0)
 
     auto fetch = [&](int i) -> float {      // element i of the row, -inf outside [0, n)
         if (i < 0 || i >= n) return -INFINITY;
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
         }
     }
     __syncthreads();
+    STAMP(1)
 
     int w = 1;
     while (2 * w <= d) w *= 2;              // w = 2^floor(log2 d) (1 when d <= 1)
@@ -132,32 +140,63 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
         }
     }
 
-    // strict local-maximum test; survivors are compacted with one LDS atomic per wave and element slot
+    STAMP(2)
+    // strict local-maximum test; survivors are compacted with one LDS atomic per wave and element slot.
+    // The four window maxima of a thread's 4 consecutive elements are fetched as aligned float4 (two per
+    // unaligned offset, shifted in registers): ds_read_b32 at a 16-byte lane stride would be 4-way conflicted.
+    auto read4 = [&](int g, int off) -> float4 {              // M[4g+off .. 4g+off+3]
+        const int q = off >> 2, r = off & 3;                  // floor division, wave-uniform remainder
+        const float4 x = M4[g + q];
+        if (r == 0) return x;
+        const float4 y = M4[g + q + 1];
+        if (r == 1) return make_float4(x.y, x.z, x.w, y.x);
+        if (r == 2) return make_float4(x.z, x.w, y.x, y.y);
+        return make_float4(x.w, y.x, y.y, y.z);
+    };
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
         const int g = tid + 256 * q;
         if (256 * q < groups) {             // wave-uniform guard
+            const int i0 = 4 * g - dl;      // dl is a multiple of 4: a group is all pad or starts on a real element
+            const bool real = (g < groups) && i0 >= 0 && i0 < n;
+            float4 left = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), right = left;
+            if (real && d > 0) {
+                left = max4(read4(g, -d), read4(g, -w));
+                right = max4(read4(g, 1), read4(g, d - w + 1));
+            }
             const float vals[4] = {own[q].x, own[q].y, own[q].z, own[q].w};
+            const float lefts[4] = {left.x, left.y, left.z, left.w};
+            const float rights[4] = {right.x, right.y, right.z, right.w};
+            bool oks[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int p = 4 * g + e;
-                const int i = p - dl;
                 const float v = vals[e];
-                bool ok = (g < groups) && i >= 0 && i < n && (v >= a.min_value) && (v < INFINITY);
-                if (d > 0 && ok) {
-                    const float left = fmaxf(M[p - d], M[p - w]);
-                    const float right = fmaxf(M[p + 1], M[p + d - w + 1]);
-                    ok = (v > left) && (v > right);
-                }
-                if (__any(ok)) {            // peaks are rare: most (wave, slot) pairs skip the compaction
+                oks[e] = real && i0 + e < n && (v >= a.min_value) && (v < INFINITY) && (v > lefts[e]) && (v > rights[e]);
+            }
+            if (d >= 3) {
+                // peaks are more than d >= 3 apart: at most one of the 4 consecutive elements survives,
+                // so one compaction per group (8 per row and thread) instead of one per element
+                const bool ok = oks[0] || oks[1] || oks[2] || oks[3];
+                const int e = oks[0] ? 0 : (oks[1] ? 1 : (oks[2] ? 2 : 3));
+                if (__any(ok)) {
                     const int slot = wave_prefix_slot(ok, &n_peak, lane);
-                    if (ok && slot < a.peak_cap) { pval[slot] = v; pidx[slot] = i; }
+                    const float vsel = oks[0] ? vals[0] : (oks[1] ? vals[1] : (oks[2] ? vals[2] : vals[3]));
+                    if (ok && slot < a.peak_cap) { pval[slot] = vsel; pidx[slot] = i0 + e; }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (__any(oks[e])) {
+                        const int slot = wave_prefix_slot(oks[e], &n_peak, lane);
+                        if (oks[e] && slot < a.peak_cap) { pval[slot] = vals[e]; pidx[slot] = i0 + e; }
+                    }
                 }
             }
         }
     }
     __syncthreads();
 
+    STAMP(3)
     // rank by counting: value descending, higher index first on ties (np.argsort(...)[::-1])
     int np_ = n_peak;
     if (np_ > a.peak_cap) np_ = a.peak_cap;
@@ -170,6 +209,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
         const float v = pval[p];
         const int i = pidx[p];
         int rank = 0;
+#pragma unroll 4
         for (int q4 = 0; 4 * q4 < np_; ++q4) {
             const float4 u = pv4[q4];
             rank += (u.x > v) + (u.y > v) + (u.z > v) + (u.w > v);
@@ -188,6 +228,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
             out[rank] = o;
         }
     }
+    STAMP(4)
     for (int k = kept + tid; k < a.number; k += 256) out[k] = -1;
     if (tid == 0) a.count[r] = kept;
 }
@@ -210,7 +251,7 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
     a.M = M; a.row0 = row0; a.n = n_cols; a.pitch = pitch; a.mode = mode; a.min_value = min_value; a.d = d;
     a.number = number; a.idx = idx; a.idx_pitch = idx_pitch; a.count = count;
     a.dl = (int)round_up(d, 4);
-    a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 1);
+    a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 3);      // slack for the aligned window reads past the end
     a.peak_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart
     const size_t bytes = (size_t)(4 * a.groups + 2 * a.peak_cap) * 4;
     const int per_thread = (int)ceil_div(a.groups, 256);
@@ -222,5 +263,11 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
     if (per_thread <= 16) return launch_one<16>(a, n_rows, bytes, s);
     return launch_one<32>(a, n_rows, bytes, s);
 }
+
+#ifdef REPET_PEAK_STAMPS
+extern "C" int repet_debug_peak_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_peak_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 }  // namespace repet
