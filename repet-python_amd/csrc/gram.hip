@@ -17,6 +17,10 @@ namespace repet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifdef REPET_GRAM_TRACE
+__device__ unsigned long long g_gram_trace[4096 * 3];
+#endif
+
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;                     // LDS row pitch in floats
 constexpr int TILE_FLOATS = kTile * LDP;        // one operand tile in LDS
@@ -38,6 +42,14 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
     const int2 tile = tiles[blockIdx.x];
     const int bi = tile.x, bj = tile.y;
     if (bi < 0) return;
+#ifdef REPET_GRAM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_gram_trace[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        g_gram_trace[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -184,6 +196,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
                     if (gi < T && gj < T && lag >= 0 && lag < n_lags) out[gi * pitch + lag] = acc[m][n][r];
                 }
     }
+#ifdef REPET_GRAM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gram_trace[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 static hipError_t set_lds(const void* fn) {
@@ -338,5 +353,11 @@ hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, i
                        n_windows, step, T, lo, frame_period);
     return hipGetLastError();
 }
+
+#ifdef REPET_GRAM_TRACE
+extern "C" int repet_debug_gram_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gram_trace), sizeof(unsigned long long) * 4096 * 3);
+}
+#endif
 
 }  // namespace repet

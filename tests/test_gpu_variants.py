@@ -241,3 +241,71 @@ def test_long_similarity_number_uses_bisection_path():
         assert cnt.max() > 128                    # the bisection median really ran
     finally:
         repet.similarity_number, repet.similarity_distance = saved
+
+
+def test_two_host_threads_with_their_own_contexts():
+    """A repet_ctx serialises its own work; different contexts may run from different host threads
+    (ctypes releases the GIL during the call)."""
+    import threading
+    fs = 16000
+    clips = [synth(9, fs, 2, 70 + i) for i in range(4)]
+    want = [repet.sim(x, fs) for x in clips]
+    got = [None] * 4
+    errors = []
+
+    def work(ids):
+        try:
+            ctx = repet.Context(0)
+            p = repet.derive_params(fs)
+            for _ in range(3):
+                for i in ids:
+                    ctx.upload(clips[i])
+                    ctx.execute("sim", p)
+                    got[i] = ctx.download()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(ids,)) for ids in ([0, 2], [1, 3])]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+def test_size_limits_and_bad_arguments_raise():
+    fs = 44100
+    # peak-picking kernel keeps one similarity row in LDS: ~32.6 k frames is the documented limit for sim
+    too_long = np.zeros((34_000 * 1024, 1), dtype=np.float32)
+    too_long[::997] = 0.1
+    with pytest.raises(RuntimeError, match="too many frames"):
+        repet.sim(too_long, fs)
+    del too_long
+    x = synth(4, fs, 2, 1)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    p = repet.derive_params(fs)
+    bad = repet.derive_params(fs)
+    bad.window_length = 3000                                  # not a power of two
+    with pytest.raises(RuntimeError):
+        ctx.execute("sim", bad)
+    bad = repet.derive_params(fs)
+    bad.step_length = 512                                     # must be W/2
+    with pytest.raises(ValueError):
+        ctx.execute("sim", bad)
+    with pytest.raises(ValueError):
+        _native.check(_native.lib().repet_ctx_execute(ctx.handle, 17, p, None))   # unknown algorithm
+    with pytest.raises(ValueError):
+        repet.Context(99)                                                         # no such device
+    ctx.execute("sim", p)                                     # the context is still usable afterwards
+    assert np.all(np.isfinite(ctx.download()))
+    ctx.close()
+    # empty clip, as the reference behaves: sim/adaptive return an empty array, the period-based ones raise
+    assert repet.sim(np.zeros((0, 2)), fs).shape == (0, 2)
+    assert repet.adaptive(np.zeros((0, 2)), fs).shape == (0, 2)
+    for algo in ("original", "extended", "simonline"):
+        with pytest.raises(ValueError):
+            getattr(repet, algo)(np.zeros((0, 2)), fs)
