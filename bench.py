@@ -187,6 +187,18 @@ def main():
             "stages": stages,
             "device_ms_per_step": round(sum(s["ms"] for s in stages), 4),
         }
+        if world == 1:
+            # PCIe-inclusive drop-in call (float64 NumPy in host RAM -> float64 NumPy out): reported beside `value`,
+            # never as `value`. Includes upload, f64->f32, the run, f32->f64 and download.
+            repet.set_device(local_rank)
+            wall = []
+            for _ in range(4):
+                t1 = time.perf_counter()
+                getattr(repet, args.algo)(clip, fs)
+                wall.append(time.perf_counter() - t1)
+            line["array_in_array_out"] = {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
+                                          "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2),
+                                          "note": "repet.%s(audio_signal, fs) wall time, pageable float64 host arrays both ways" % args.algo}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
         print(json.dumps(line), flush=True)

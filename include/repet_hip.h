@@ -137,6 +137,14 @@ int repet_istft(repet_ctx* ctx, const float* spec, int64_t n_frames, const float
 /* _selfsimilaritymatrix, repet.py:1209-1225. v[T][F] (frame-major magnitudes) -> s[T][T]. */
 int repet_selfsim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, float* s_out);
 
+/* _similaritymatrix, repet.py:1228-1246 (the online variant's frame-vs-buffer similarity):
+ * a[TA][F], b[TB][F] frame-major magnitudes -> s[TA][TB] cosine similarities. */
+int repet_similarity(repet_ctx* ctx, const float* a, int64_t n_a, const float* b, int64_t n_b, int32_t n_freq,
+                     float* s_out);
+
+/* _acorr, repet.py:1108-1139: x[n_rows][n_cols] -> unbiased autocorrelation of every column, ac[lag][col]. */
+int repet_acorr(repet_ctx* ctx, const float* x, int32_t n_rows, int32_t n_cols, float* ac_out);
+
 /* _beatspectrum, repet.py:1142-1158 (input already squared by the caller, as in the reference):
  * p[T][F] -> beat[n_lags], n_lags <= T. */
 int repet_beat_spectrum(repet_ctx* ctx, const float* p, int64_t n_frames, int32_t n_freq,

@@ -77,6 +77,11 @@ hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, 
                             const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t a_batch_stride,
                             int64_t band_batch_stride, hipStream_t s);
 
+// Stage exports only: out = A B^T (cosine similarity of two column sets) and the per-column autocorrelation.
+hipError_t launch_matmul_nt(const float* A, int64_t TA, const float* B, int64_t TB, int32_t FS, float* out,
+                            int64_t pitch, hipStream_t s);
+hipError_t launch_acorr(const float* x, int32_t R, int32_t n_cols, int32_t pitch, float* ac, hipStream_t s);
+
 // Windowed diagonal sums of the band: beat[w][l] = sum_{t=lo_w}^{hi_w - l} band[t][l] / ((len - l) * F)
 //   window w covers frames [start0 + w*step, start0 + w*step + len) clipped to [0,T).
 hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,

@@ -802,6 +802,40 @@ int repet_selfsim(repet_ctx* c, const float* v, int64_t T, int32_t F, float* s_o
     return d2h_pitched(c, s_out, c->S.as<float>(), TS, T, T);
 }
 
+int repet_similarity(repet_ctx* c, const float* a, int64_t TA, const float* b, int64_t TB, int32_t F, float* s_out) {
+    if (!c || !a || !b || !s_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (TA < 1 || TB < 1 || F < 1) return fail(REPET_ERR_BAD_ARG, "bad size");
+    DeviceGuard guard(c->device);
+    const int FS = (int)round_up(F, kFreqAlign);
+    const int64_t TApad = round_up(TA, kTile), TBpad = round_up(TB, kTile), pitch = round_up(TB, 4);
+    HIP_TRY(c->tmp_a.ensure((size_t)std::max(TA, TB) * F * sizeof(float)));
+    HIP_TRY(c->Vn.ensure((size_t)TApad * FS * sizeof(float)));
+    HIP_TRY(c->P.ensure((size_t)TBpad * FS * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->Vn.p, 0, (size_t)TApad * FS * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->P.p, 0, (size_t)TBpad * FS * sizeof(float), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tmp_a.p, a, (size_t)TA * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_unit_rows(c->tmp_a.as<float>(), c->Vn.as<float>(), TA, F, FS, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tmp_a.p, b, (size_t)TB * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_unit_rows(c->tmp_a.as<float>(), c->P.as<float>(), TB, F, FS, c->stream));
+    HIP_TRY(c->S.ensure((size_t)TA * pitch * sizeof(float)));
+    HIP_TRY(launch_matmul_nt(c->Vn.as<float>(), TA, c->P.as<float>(), TB, FS, c->S.as<float>(), pitch, c->stream));
+    return d2h_pitched(c, s_out, c->S.as<float>(), pitch, TA, TB);
+}
+
+int repet_acorr(repet_ctx* c, const float* x, int32_t n_rows, int32_t n_cols, float* ac_out) {
+    if (!c || !x || !ac_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n_rows < 1 || n_cols < 1) return fail(REPET_ERR_BAD_ARG, "bad size");
+    DeviceGuard guard(c->device);
+    const size_t bytes = (size_t)n_rows * n_cols * sizeof(float);
+    HIP_TRY(c->tmp_a.ensure(bytes));
+    HIP_TRY(c->tmp_c.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(c->tmp_a.p, x, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_acorr(c->tmp_a.as<float>(), n_rows, n_cols, n_cols, c->tmp_c.as<float>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(ac_out, c->tmp_c.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
 int repet_beat_spectrum(repet_ctx* c, const float* p, int64_t T, int32_t F, float* beat_out, int32_t n_lags) {
     if (!c || !p || !beat_out) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (n_lags < 1 || n_lags > T) return fail(REPET_ERR_BAD_ARG, "n_lags must be in [1, T]");

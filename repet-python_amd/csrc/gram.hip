@@ -26,7 +26,7 @@ constexpr int LDP = BK + 4;                     // LDS row pitch in floats
 constexpr int TILE_FLOATS = kTile * LDP;        // one operand tile in LDS
 constexpr int kGramLds = 4 * TILE_FLOATS * 4;   // 2 operands x 2 buffers, bytes (73,728)
 
-enum GramMode { GRAM_FULL = 0, GRAM_BAND = 1 };
+enum GramMode { GRAM_FULL = 0, GRAM_BAND = 1, GRAM_CROSS = 2 };   // CROSS: out = A B^T, two different matrices
 
 // tiles[blockIdx.x] = (bi, bj) with bj >= bi, or (-1,-1) for a filler slot. The host orders the list so
 // that the blocks resident together on one XCD (ids congruent mod 8 under round-robin dispatch) walk one
@@ -35,7 +35,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, int64_t T, int FS,
                                                       float* __restrict__ out, int64_t pitch, int n_lags,
                                                       const int2* __restrict__ tiles, int64_t a_batch_stride,
-                                                      int64_t out_batch_stride) {
+                                                      int64_t out_batch_stride, const float* __restrict__ B,
+                                                      int64_t TB) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     A += blockIdx.y * a_batch_stride;           // batch of equal-shape matrices (segments of `extended`)
     out += blockIdx.y * out_batch_stride;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
     const int lr = lane & 31, lh = lane >> 5;
 
     const float* Ag = A + (int64_t)bi * kTile * FS;
-    const float* Bg = A + (int64_t)bj * kTile * FS;
+    const float* Bg = (MODE == GRAM_CROSS ? B : A) + (int64_t)bj * kTile * FS;
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
     // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
     const int64_t gi0 = (int64_t)bi * kTile + wr * 64;
     const int64_t gj0 = (int64_t)bj * kTile + wc * 64;
-    if (MODE == GRAM_FULL) {
+    if (MODE == GRAM_FULL || MODE == GRAM_CROSS) {
+        const int64_t TJ = (MODE == GRAM_CROSS) ? TB : T;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
                 for (int r = 0; r < 16; ++r) {
                     const int64_t gi = gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const int64_t gj = gj0 + n * 32 + lr;
-                    if (gi < T && gj < T) out[gi * pitch + gj] = acc[m][n][r];
+                    if (gi < T && gj < TJ) out[gi * pitch + gj] = acc[m][n][r];
                 }
-        if (bi != bj) {
+        if (MODE == GRAM_FULL && bi != bj) {
             // mirror: transpose this wave's 64x64 block through a private LDS patch (pitch 65)
             float* patch = lds + wave * (64 * 65);
 #pragma unroll
@@ -232,7 +234,7 @@ hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int
     hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_FULL>));
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_kernel<GRAM_FULL>, dim3((unsigned)n_tiles), dim3(256), kGramLds, s, A, T, FS, S, TS, 0, tiles,
-                       (int64_t)0, (int64_t)0);
+                       (int64_t)0, (int64_t)0, (const float*)nullptr, (int64_t)0);
     return hipGetLastError();
 }
 
@@ -243,7 +245,51 @@ hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, 
     hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_BAND>));
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_kernel<GRAM_BAND>, dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
-                       kGramLds, s, A, T, FS, band, (int64_t)LP, n_lags, tiles, a_batch_stride, band_batch_stride);
+                       kGramLds, s, A, T, FS, band, (int64_t)LP, n_lags, tiles, a_batch_stride, band_batch_stride,
+                       (const float*)nullptr, (int64_t)0);
+    return hipGetLastError();
+}
+
+// out[TA][pitch] = A B^T for A[TApad][FS], B[TBpad][FS] (rows beyond TA / TB zero): every tile, no mirror.
+hipError_t launch_matmul_nt(const float* A, int64_t TA, const float* B, int64_t TB, int32_t FS, float* out,
+                            int64_t pitch, hipStream_t s) {
+    if (TA <= 0 || TB <= 0) return hipSuccess;
+    hipError_t attr = set_lds(reinterpret_cast<const void*>(&gram_kernel<GRAM_CROSS>));
+    if (attr != hipSuccess) return attr;
+    const int na = (int)ceil_div(TA, kTile), nbt = (int)ceil_div(TB, kTile);
+    std::vector<int2> host;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nbt; ++j) host.push_back(make_int2(i, j));
+    int2* tiles = nullptr;
+    hipError_t e = hipMalloc(&tiles, host.size() * sizeof(int2));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(tiles, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gram_kernel<GRAM_CROSS>, dim3((unsigned)host.size()), dim3(256), kGramLds, s, A, TA, FS, out, pitch, 0,
+                           tiles, (int64_t)0, (int64_t)0, B, TB);
+        e = hipGetLastError();
+    }
+    (void)hipStreamSynchronize(s);      // stage export only: the temporary tile list is freed here
+    (void)hipFree(tiles);
+    return e;
+}
+
+// _acorr (repet.py:1108-1139) as its own stage: ac[l][c] = sum_t x[t][c] x[t+l][c] / (R - l), x[R][pitch].
+// (The pipelines never form it: the beat spectrum takes the mean over c first, as diagonal sums of a Gram band.)
+__global__ __launch_bounds__(256) void acorr_kernel(const float* __restrict__ x, int R, int n_cols, int pitch,
+                                                    float* __restrict__ ac) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int l = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= n_cols || l >= R) return;
+    float sum = 0.f;
+    for (int t = 0; t + l < R; ++t) sum += x[(int64_t)t * pitch + c] * x[(int64_t)(t + l) * pitch + c];
+    ac[(int64_t)l * pitch + c] = sum / (float)(R - l);
+}
+
+hipError_t launch_acorr(const float* x, int32_t R, int32_t n_cols, int32_t pitch, float* ac, hipStream_t s) {
+    if (R <= 0 || n_cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(acorr_kernel, dim3((unsigned)ceil_div(n_cols, 64), (unsigned)ceil_div(R, 4)), dim3(256), 0, s, x, R,
+                       n_cols, pitch, ac);
     return hipGetLastError();
 }
 

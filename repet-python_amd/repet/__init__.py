@@ -186,6 +186,25 @@ def _selfsimilaritymatrix(data_matrix):
     return s.astype(np.float64)
 
 
+def _similaritymatrix(data_matrix1, data_matrix2):
+    """Cosine similarity between the columns of two matrices (repet.py:1228-1246)."""
+    a = _f32(np.asarray(data_matrix1).T)
+    b = _f32(np.asarray(data_matrix2).T)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float32)
+    _native.check(_native.lib().repet_similarity(_native.default_context(_device).handle, _native.ptr(a), a.shape[0],
+                                                 _native.ptr(b), b.shape[0], a.shape[1], _native.ptr(out)))
+    return out.astype(np.float64)
+
+
+def _acorr(data_matrix):
+    """Unbiased autocorrelation of every column (repet.py:1108-1139)."""
+    x = _f32(data_matrix)
+    out = np.empty_like(x)
+    _native.check(_native.lib().repet_acorr(_native.default_context(_device).handle, _native.ptr(x), x.shape[0],
+                                            x.shape[1], _native.ptr(out)))
+    return out.astype(np.float64)
+
+
 def _beatspectrum(audio_spectrogram):
     """Beat spectrum of an (already squared) spectrogram (repet.py:1142-1158)."""
     rows = _f32(np.asarray(audio_spectrogram).T)

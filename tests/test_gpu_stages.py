@@ -160,3 +160,23 @@ def test_masks(clip):
     assert np.array_equal(np.isnan(got), np.isnan(want))
     ok = ~np.isnan(want)
     assert np.max(np.abs(got[ok] - want[ok])) < 1e-6
+
+
+def test_similaritymatrix_and_acorr_helpers(clip):
+    x, fs = clip
+    w, window, h = orc.stft_geometry(fs)
+    _, mag = orc.spectrogram_channels(x[:5 * fs], window, h)
+    v = np.mean(mag, axis=2).astype(np.float32).astype(np.float64)            # (F, T)
+    a, b = v[:, :150], v[:, 37:38]                                             # buffer vs one frame, as in simonline
+    got = repet._similaritymatrix(a, b)
+    want = orc.similaritymatrix(a, b)
+    assert got.shape == want.shape == (150, 1)
+    assert np.max(np.abs(got - want)) < 2e-6
+    got = repet._similaritymatrix(v[:, :70], v[:, 20:150])
+    assert np.max(np.abs(got - orc.similaritymatrix(v[:, :70], v[:, 20:150]))) < 2e-6
+    p = np.power(v, 2).T[:120, :200]                                           # (rows = time, cols)
+    got = repet._acorr(p)
+    want = orc.acorr(p)
+    assert got.shape == want.shape
+    assert _rel(got, want) < 2e-5
+    assert np.allclose(np.mean(got, axis=1), repet._beatspectrum(p.T), rtol=2e-5, atol=0)
