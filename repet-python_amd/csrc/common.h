@@ -118,8 +118,10 @@ constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest 
 hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
                                 hipStream_t s);
 // max_count / min_period bound the list length so the launcher can pick the smallest compiled network.
+// side/fork/join (nullable): second stream and two events to run the Nyquist-bin kernel beside the main one.
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
-                           int64_t first_frame, int32_t max_count, hipStream_t s);
+                           int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
+                           hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
                               int32_t min_period, hipStream_t s);

@@ -68,6 +68,8 @@ struct Tables {
 struct repet_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // short independent kernels run beside the main stream
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
     // resident clip
     DevBuf staging, audio, out, out64;
     int64_t n_samples = 0;
@@ -434,7 +436,8 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
     // peaks are more than d frames apart: at most ceil(T/(d+1)) of them, whatever similarity_number says
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream));
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
+                            c->fork_event, c->join_event));
     mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = KP; c->last_idx_number = K;
@@ -468,7 +471,8 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     HIP_TRY(e);
     mark(c, "local_maxima", 4.0 * rows * B + 4.0 * K * rows, 0);
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream));
+    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream, c->side_stream,
+                            c->fork_event, c->join_event));
     mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
     RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = KP; c->last_idx_number = K;
@@ -538,6 +542,9 @@ int repet_ctx_create(int device, repet_ctx** out) {
     auto* c = new repet_ctx();
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming);
     if (e != hipSuccess) { delete c; return fail(REPET_ERR_HIP, hipGetErrorString(e)); }
     *out = c;
     return REPET_OK;
@@ -552,6 +559,9 @@ int repet_ctx_destroy(repet_ctx* c) {
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->fork_event) (void)hipEventDestroy(c->fork_event);
+    if (c->join_event) (void)hipEventDestroy(c->join_event);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return REPET_OK;
