@@ -102,6 +102,13 @@ int repet_ctx_download(repet_ctx* ctx, double* out);
 int repet_ctx_execute_async(repet_ctx* ctx, int algo, const repet_params* p);
 int repet_ctx_synchronize(repet_ctx* ctx);
 
+/* The steps either side of the path in every README example (README.md:64-98), kept on the device:
+ * foreground_signal = audio_signal - background_signal (README.md:69) of the last run, float64 [n][C];
+ * and the magnitude spectrogram abs(_stft(mean over channels of the signal)[0:F]) (README.md:79-81) of the
+ * mixture (which = 0), the background (1) or the foreground (2) as spec[T][F] fp32, T = repet_frame_count(n, W, W/2, 1). */
+int repet_ctx_download_foreground(repet_ctx* ctx, double* out);
+int repet_ctx_spectrogram(repet_ctx* ctx, int which, int32_t window_length, float* spec_out, int64_t n_frames);
+
 /* extended only (repet.py:205-419): the segment plan of an n_samples clip (repet.py:271-281), and a run
  * restricted to segments [first, first+n_segments). Contributions of the other segments stay zero, and
  * the cross-fade is linear in the segments, so the outputs of disjoint ranges (e.g. one range per GPU)

@@ -129,6 +129,9 @@ hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int3
 // elementwise helpers
 hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);
 hipError_t launch_convert_out(const float* src, double* dst, int64_t count, hipStream_t s);
+hipError_t launch_foreground(const float* audio, const float* background, double* dst, int64_t count, hipStream_t s);
+hipError_t launch_channel_mean(const float* audio, const float* background, int which, int n_channels, float* dst,
+                               int64_t n_samples, hipStream_t s);
 hipError_t launch_square(const float* src, float* dst, int64_t count, hipStream_t s);
 hipError_t launch_unit_rows(const float* src, float* dst, int64_t T, int32_t F, int32_t FS, hipStream_t s);
 

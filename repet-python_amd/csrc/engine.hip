@@ -675,6 +675,44 @@ int repet_ctx_download(repet_ctx* c, double* out) {
     return REPET_OK;
 }
 
+int repet_ctx_download_foreground(repet_ctx* c, double* out) {
+    if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (c->last_algo < 0) return fail(REPET_ERR_BAD_ARG, "no separation has been run on this context");
+    DeviceGuard guard(c->device);
+    const int64_t count = c->n_samples * c->n_channels;
+    if (count == 0) return REPET_OK;
+    HIP_TRY(c->out64.ensure((size_t)count * sizeof(double)));
+    HIP_TRY(launch_foreground(c->audio.as<float>(), c->out.as<float>(), c->out64.as<double>(), count, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->out64.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+int repet_ctx_spectrogram(repet_ctx* c, int which, int32_t window_length, float* out, int64_t n_frames) {
+    if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (which < 0 || which > 2) return fail(REPET_ERR_BAD_ARG, "which must be 0 (mixture), 1 (background) or 2 (foreground)");
+    if (which != 0 && c->last_algo < 0) return fail(REPET_ERR_BAD_ARG, "no separation has been run on this context");
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    DeviceGuard guard(c->device);
+    Tables* tb = nullptr;
+    RP_TRY(get_tables(c, window_length, &tb));
+    const int W = window_length, H = W / 2;
+    const int64_t N = c->n_samples, T = repet_frame_count(N, W, H, 1);
+    if (T != n_frames) return fail(REPET_ERR_BAD_ARG, "n_frames does not match repet_frame_count");
+    const Geo g = make_geo(W, H, T, 1);
+    HIP_TRY(c->tmp_a.ensure(std::max<size_t>((size_t)N * sizeof(float), 256)));
+    HIP_TRY(launch_channel_mean(c->audio.as<float>(), c->out.as<float>(), which, c->n_channels, c->tmp_a.as<float>(), N, c->stream));
+    // the spectra workspaces are reused: a later execute() recomputes them anyway
+    HIP_TRY(c->X.ensure((size_t)g.chan_stride * sizeof(float2)));
+    HIP_TRY(c->V.ensure((size_t)g.chan_stride * sizeof(float)));
+    StftArgs a{};
+    a.audio = c->tmp_a.as<float>(); a.n_samples = N; a.n_channels = 1; a.sample_offset = 0;
+    a.window = tb->window.as<float>(); a.twiddle = tb->twiddle.as<float2>(); a.W = W; a.H = H; a.T = T; a.FS = g.FS; a.centred = 1;
+    a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
+    HIP_TRY(launch_stft(a, c->stream));
+    return d2h_pitched(c, out, c->V.as<float>(), g.FS, T, g.F);
+}
+
 static int thread_ctx(int device, repet_ctx** out) {
     auto it = g_thread_ctx.find(device);
     if (it != g_thread_ctx.end()) { *out = it->second; return REPET_OK; }

@@ -846,6 +846,26 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const float* src, float*
     for (int k = tid; k < FS; k += 256) dst[t * FS + k] = (k < F) ? src[t * F + k] / norm : 0.f;
 }
 
+// foreground = audio - background (README.md:69), as float64, and the channel mean of a signal (README.md:79)
+__global__ void foreground_kernel(const float* audio, const float* background, double* dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (double)audio[i] - (double)background[i];
+}
+// which: 0 mixture, 1 background, 2 foreground
+__global__ void channel_mean_kernel(const float* audio, const float* background, int which, int C, float* dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float a = audio[i * C + c], b = background[i * C + c];
+            acc += which == 0 ? a : (which == 1 ? b : a - b);
+        }
+        dst[i] = acc / (float)C;
+    }
+}
+
 static unsigned stream_grid(int64_t n) {
     int64_t g = ceil_div(n, 256);
     return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -864,6 +884,17 @@ hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t n, 
 hipError_t launch_convert_out(const float* src, double* dst, int64_t n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(convert_out_kernel, dim3(stream_grid(n)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_foreground(const float* audio, const float* background, double* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(foreground_kernel, dim3(stream_grid(n)), dim3(256), 0, s, audio, background, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_channel_mean(const float* audio, const float* background, int which, int C, float* dst, int64_t n,
+                               hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(channel_mean_kernel, dim3(stream_grid(n)), dim3(256), 0, s, audio, background, which, C, dst, n);
     return hipGetLastError();
 }
 hipError_t launch_square(const float* src, float* dst, int64_t n, hipStream_t s) {

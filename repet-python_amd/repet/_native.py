@@ -51,6 +51,8 @@ _SIGNATURES = {
     "repet_ctx_download": (C.c_int, [_P, _P]),
     "repet_ctx_execute_async": (C.c_int, [_P, C.c_int, C.POINTER(Params)]),
     "repet_ctx_synchronize": (C.c_int, [_P]),
+    "repet_ctx_download_foreground": (C.c_int, [_P, _P]),
+    "repet_ctx_spectrogram": (C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_int64]),
     "repet_extended_segment_count": (C.c_int64, [C.c_int64, C.POINTER(Params)]),
     "repet_ctx_execute_extended_range": (C.c_int, [_P, C.POINTER(Params), C.c_int64, C.c_int64, C.POINTER(Timing)]),
     "repet_run": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int32, C.POINTER(Params), _P, C.c_int,
@@ -178,6 +180,20 @@ class Context:
         out = np.empty(self.shape, dtype=np.float64)
         check(lib().repet_ctx_download(self._h, ptr(out)))
         return out
+
+    def foreground(self):
+        """audio_signal - background_signal of the last run (float64, computed on the device)."""
+        out = np.empty(self.shape, dtype=np.float64)
+        check(lib().repet_ctx_download_foreground(self._h, ptr(out)))
+        return out
+
+    def spectrogram(self, which, window_length):
+        """(F, T) magnitude spectrogram of the channel-mean mixture / background / foreground signal."""
+        code = {"mixture": 0, "background": 1, "foreground": 2}[which] if isinstance(which, str) else int(which)
+        t = lib().repet_frame_count(self.shape[0], window_length, window_length // 2, 1)
+        spec = np.empty((t, window_length // 2 + 1), dtype=np.float32)
+        check(lib().repet_ctx_spectrogram(self._h, code, window_length, ptr(spec), t))
+        return spec.T.astype(np.float64)
 
     def last_periods(self, capacity):
         out = np.empty(max(capacity, 1), dtype=np.int32)

@@ -309,3 +309,24 @@ def test_size_limits_and_bad_arguments_raise():
     for algo in ("original", "extended", "simonline"):
         with pytest.raises(ValueError):
             getattr(repet, algo)(np.zeros((0, 2)), fs)
+
+
+def test_foreground_and_spectrograms_on_device():
+    """README.md:64-98 workflow kept on the device: foreground = audio - background, and the three
+    spectrograms abs(_stft(mean over channels)) for specshow."""
+    x, fs = golden_input("small_stereo")
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute("original", p)
+    bg = ctx.download()
+    fg = ctx.foreground()
+    assert rms_err(fg, np.asarray(x, dtype=np.float32).astype(np.float64) - bg) < 1e-7
+    w, window, h = orc.stft_geometry(fs)
+    f = w // 2 + 1
+    for which, sig in (("mixture", np.array(x)), ("background", bg), ("foreground", fg)):
+        got = ctx.spectrogram(which, w)
+        want = np.abs(orc.stft(np.mean(sig, axis=1), window, h)[:f])
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, want.max())
+    ctx.close()
