@@ -186,6 +186,22 @@ int repet_ctx_last_sim_indices(repet_ctx* ctx, int32_t* idx_out, int32_t* count_
                                int32_t number);
 int repet_ctx_last_frame_count(repet_ctx* ctx, int64_t* n_frames);
 
+/* ---- streaming online REPET-SIM (the reference's simonline needs the whole signal, repet.py:712-911) ------
+ * open  : state for one stream of n_channels (1, 2 or 4) with the parameters of derive_params(fs);
+ * push  : feed n_samples more samples (NumPy C order); every frame that is now complete is processed and the
+ *         newly final background samples (whole hops of W/2) are written to out (float64, interleaved,
+ *         `capacity` samples per channel; n_samples + window_length always suffices), their count to *n_written;
+ * finish: end of stream -- the zero-padded last frame (repet.py:781,813) and the tail; afterwards the total
+ *         written equals the total pushed. REPET_ERR_TOO_SHORT if fewer samples were pushed than the reference's
+ *         warm-up needs (repet.py:795-810).
+ * The concatenated output equals repet.simonline(whole signal) bit for bit (same kernels, same order). */
+typedef struct repet_online repet_online;
+int repet_online_open(int device, int32_t n_channels, const repet_params* p, repet_online** out);
+int repet_online_push(repet_online* h, const void* audio, int dtype, int64_t n_samples, double* out, int64_t capacity,
+                      int64_t* n_written);
+int repet_online_finish(repet_online* h, double* out, int64_t capacity, int64_t* n_written);
+int repet_online_close(repet_online* h);
+
 #ifdef __cplusplus
 }
 #endif

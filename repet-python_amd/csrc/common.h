@@ -101,9 +101,10 @@ hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, i
 //   mode 0: row r is M[r][0..n_cols); indices are column numbers.
 //   mode 1 (simonline): "row" j is the circular-buffer view of the band: element c is
 //           band[j-l][l], l = (j-c) mod B, for c < B = n_cols; indices are FRAME numbers j-l.
+//           `shift` (streaming): band row of frame f is f - shift, and the indices written are band rows.
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
-                               int32_t idx_pitch, int32_t* count, hipStream_t s);
+                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0);
 
 // K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
 // multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).
@@ -112,6 +113,7 @@ struct MaskArgs {
     float2* X; float* mask; int32_t cutoff;
     int64_t pad_row;   // rows pad_row / pad_row+1 of every channel of V hold -1.0f / +inf (median pads)
     int32_t n_batch; int64_t batch_stride;   // mask_period only: blockIdx.z = clip, elements between clips
+    int64_t frame0;                          // mask_sim only: first frame row handled by this launch (streaming window)
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size

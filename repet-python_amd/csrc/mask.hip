@@ -134,7 +134,7 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
 template <int NET, bool SPLIT>
 __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                        const int* __restrict__ count, int64_t first_frame) {
-    const int64_t t = blockIdx.x;
+    const int64_t t = a.frame0 + blockIdx.x;
     const int c = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nbins = SPLIT ? a.F - 1 : a.F;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const 
                                                               const int* __restrict__ count, int64_t first_frame) {
     const int c = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t n_rows = a.T - first_frame;
+    const int64_t n_rows = a.T - first_frame;       // first_frame >= frame0: rows before it are warm-up frames
     const bool active = r0 < n_rows;
     const int64_t r = active ? r0 : n_rows - 1;
     const int64_t t = first_frame + r;
@@ -189,11 +189,12 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const 
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side,
                            hipEvent_t fork, hipEvent_t join) {
-    if (m.T <= 0) return hipSuccess;
+    if (m.T - m.frame0 <= 0) return hipSuccess;
     // the Nyquist-bin kernel (a few hundred latency-bound waves) runs on `side` next to the main kernel
     const bool forked = side != nullptr && fork != nullptr && join != nullptr;
     const bool split = m.F > 64 && ((m.F - 1) & 63) == 0;
     const int64_t rows = m.T - first_frame;
+    const unsigned n_launch = (unsigned)(m.T - m.frame0);   // frames [frame0, T) are processed (frame0 > 0: streaming window)
     dispatch_net(max_count, [&](auto net) {
         constexpr int NET = decltype(net)::value;
         if (split) {
@@ -203,11 +204,11 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                                    dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
                 if (forked) (void)hipEventRecord(join, side);
             }
-            hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3((unsigned)m.T, (unsigned)m.n_channels), dim3(256), 0, s,
+            hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
                                m, idx, idx_pitch, count, first_frame);
             if (forked && rows > 0) (void)hipStreamWaitEvent(s, join, 0);
         } else {
-            hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3((unsigned)m.T, (unsigned)m.n_channels), dim3(256), 0, s,
+            hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
                                m, idx, idx_pitch, count, first_frame);
         }
     });

@@ -40,7 +40,7 @@ __device__ __forceinline__ int wave_prefix_slot(bool flag, int* counter, int lan
 
 struct PeakArgs {
     const float* M; int64_t row0; int n; int64_t pitch; int mode; float min_value; int d; int number;
-    int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap;
+    int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap; int64_t shift;
 };
 
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
         // circular-buffer order of the online variant: column c holds frame j - ((j - c) mod B)
         int l = (int)(j - i) % n;
         if (l < 0) l += n;
-        return nan_to_inf(a.M[(j - l) * a.pitch + l]);
+        return nan_to_inf(a.M[(j - l - a.shift) * a.pitch + l]);
     };
 
     const bool vec_ok = (a.mode == 0) && ((a.pitch & 3) == 0);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
             if (a.mode == 1) {
                 int l = (int)(j - i) % n;
                 if (l < 0) l += n;
-                o = (int)(j - l);
+                o = (int)(j - l - a.shift);
             }
             out[rank] = o;
         }
@@ -244,12 +244,12 @@ static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, size_t bytes, hi
 
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
-                               int32_t idx_pitch, int32_t* count, hipStream_t s) {
+                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift) {
     if (n_rows <= 0) return hipSuccess;
     if (d > n_cols) d = n_cols;                                       // a wider window changes nothing
     PeakArgs a{};
     a.M = M; a.row0 = row0; a.n = n_cols; a.pitch = pitch; a.mode = mode; a.min_value = min_value; a.d = d;
-    a.number = number; a.idx = idx; a.idx_pitch = idx_pitch; a.count = count;
+    a.number = number; a.idx = idx; a.idx_pitch = idx_pitch; a.count = count; a.shift = shift;
     a.dl = (int)round_up(d, 4);
     a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 3);      // slack for the aligned window reads past the end
     a.peak_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart

@@ -20,6 +20,7 @@ import numpy as np
 
 from . import _native
 from ._native import Context  # noqa: F401  (device-resident API used by bench.py)
+from ._native import OnlineSeparator as _OnlineSeparator
 
 # ---- public parameters (repet.py:42-63) ----------------------------------------------------------------
 cutoff_frequency = 100
@@ -110,6 +111,13 @@ def sim(audio_signal, sampling_frequency):
 def simonline(audio_signal, sampling_frequency):
     """Online REPET-SIM over a circular buffer of past frames (repet.py:712-911)."""
     return _separate("simonline", audio_signal, sampling_frequency)
+
+
+def online(sampling_frequency, number_channels):
+    """Streaming form of :func:`simonline` (the reference needs the whole signal up front): returns an object with
+    ``push(chunk) -> newly final background samples`` and ``finish() -> the remaining ones``. The module parameters are
+    snapshotted now; the concatenated output equals ``simonline`` of the concatenated input."""
+    return _OnlineSeparator(derive_params(sampling_frequency), number_channels, _device)
 
 
 def run_batch(algo, audio_signals, sampling_frequency, n_devices=1):

@@ -75,6 +75,10 @@ _SIGNATURES = {
     "repet_ctx_last_periods": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "repet_ctx_last_sim_indices": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "repet_ctx_last_frame_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "repet_online_open": (C.c_int, [C.c_int, C.c_int32, C.POINTER(Params), C.POINTER(_P)]),
+    "repet_online_push": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "repet_online_finish": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "repet_online_close": (C.c_int, [_P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -221,3 +225,50 @@ def default_context(device=0):
     if ctx is None:
         ctx = _default_ctx[device] = Context(device)
     return ctx
+
+
+class OnlineSeparator:
+    """Streaming online REPET-SIM: ``push(chunk)`` returns the background samples that became final,
+    ``finish()`` the rest; the concatenation equals ``repet.simonline`` of the whole signal."""
+
+    def __init__(self, params, n_channels, device=0):
+        self._h = C.c_void_p()
+        self._channels = int(n_channels)
+        self._window = int(params.window_length)
+        if lib().repet_device_count() < 1:
+            raise RuntimeError("no HIP device visible: the REPET engine has no CPU fallback")
+        check(lib().repet_online_open(int(device), self._channels, C.byref(params), C.byref(self._h)))
+
+    def push(self, audio_chunk):
+        n, c = np.shape(audio_chunk)
+        if c != self._channels:
+            raise ValueError("chunk has %d channels, the stream %d" % (c, self._channels))
+        a, code = as_input(audio_chunk)
+        cap = n + self._window
+        out = np.empty((cap, c), dtype=np.float64)
+        written = C.c_int64()
+        check(lib().repet_online_push(self._h, ptr(a), code, n, ptr(out), cap, C.byref(written)))
+        return out[:written.value].copy()
+
+    def finish(self):
+        cap = 4 * self._window + 16
+        while True:
+            out = np.empty((cap, self._channels), dtype=np.float64)
+            written = C.c_int64()
+            rc = lib().repet_online_finish(self._h, ptr(out), cap, C.byref(written))
+            if rc == ERR_BAD_ARG and b"capacity" in lib().repet_last_error():
+                cap *= 4
+                continue
+            check(rc)
+            return out[:written.value].copy()
+
+    def close(self):
+        if self._h:
+            lib().repet_online_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -330,3 +330,43 @@ def test_foreground_and_spectrograms_on_device():
         assert got.shape == want.shape
         assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, want.max())
     ctx.close()
+
+
+@pytest.mark.parametrize("fs,channels,seconds,seed", [(8000, 2, 16, 2), (16000, 1, 14, 8), (44100, 2, 13, 4)])
+def test_streaming_online_equals_offline_simonline(fs, channels, seconds, seed):
+    """push() in arbitrary chunks + finish() reproduces repet.simonline of the whole signal exactly."""
+    x = synth(seconds, fs, channels, seed)
+    want = repet.simonline(x, fs)
+    rs = np.random.RandomState(seed)
+    stream = repet.online(fs, channels)
+    pieces, pos = [], 0
+    sizes = [1, 7, 255, 256, 257, 4096, 1000, 30000]
+    while pos < len(x):
+        n = min(int(sizes[rs.randint(len(sizes))] * (1 + rs.rand())), len(x) - pos)
+        pieces.append(stream.push(x[pos:pos + n]))
+        pos += n
+        # a hop is only emitted once its frame is complete: never ahead of the input
+        assert sum(len(p) for p in pieces) <= pos
+    pieces.append(stream.finish())
+    stream.close()
+    got = np.concatenate(pieces, axis=0)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    # and against the oracle, like every other variant
+    assert_parity_modulo_near_ties("simonline", x, fs)
+
+
+def test_streaming_online_errors():
+    fs = 8000
+    x = synth(5, fs, 2, 3)                       # shorter than the 10-s buffer
+    stream = repet.online(fs, 2)
+    assert len(stream.push(x)) == 0 or np.all(stream.push(x[:0]) == 0)
+    with pytest.raises(ValueError):
+        stream.finish()                          # the reference raises for such a clip (repet.py:802)
+    stream.close()
+    with pytest.raises(RuntimeError):
+        repet.online(fs, 3)                      # 1, 2 or 4 channels
+    stream = repet.online(fs, 1)
+    with pytest.raises(ValueError):
+        stream.push(np.zeros((10, 2)))
+    stream.close()
