@@ -114,6 +114,7 @@ struct MaskArgs {
     int64_t pad_row;   // rows pad_row / pad_row+1 of every channel of V hold -1.0f / +inf (median pads)
     int32_t n_batch; int64_t batch_stride;   // mask_period only: blockIdx.z = clip, elements between clips
     int64_t frame0;                          // mask_sim only: first frame row handled by this launch (streaming window)
+    int64_t frame_end;                       // mask_sim only: one past the last frame row of this launch (0 = T)
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
@@ -121,9 +122,10 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
                                 hipStream_t s);
 // max_count / min_period bound the list length so the launcher can pick the smallest compiled network.
 // side/fork/join (nullable): second stream and two events to run the Nyquist-bin kernel beside the main one.
+// parts: 1 = main kernel only, 2 = Nyquist-bin kernel only, 3 = both (chunked pipelines launch them separately).
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
-                           hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
+                           hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
                               int32_t min_period, hipStream_t s);

@@ -70,6 +70,7 @@ struct repet_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // short independent kernels run beside the main stream
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    std::vector<hipEvent_t> chunk_events;
     // resident clip
     DevBuf staging, audio, out, out64;
     int64_t n_samples = 0;
@@ -413,6 +414,23 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     return REPET_OK;
 }
 
+int ensure_chunk_events(repet_ctx* c, int n) {
+    while ((int)c->chunk_events.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chunk_events.push_back(e);
+    }
+    return REPET_OK;
+}
+
+// Row chunks of the experimental peaks -> mask two-stream pipeline (REPET_SIM_CHUNKS=n enables it). Measured on
+// MI355X at cfg 2 it LOSES: 1.09 ms unchunked vs 1.17 / 1.24 / 1.43 ms at 4 / 8 / 16 chunks -- four mask waves per
+// SIMD leave no registers for a co-resident peak-picking wave and every chunk adds a partial-occupancy tail.
+int sim_chunks(int64_t) {
+    static const int forced = [] { const char* e = getenv("REPET_SIM_CHUNKS"); return e ? atoi(e) : 0; }();
+    return forced > 1 ? forced : 1;
+}
+
 int exec_sim(repet_ctx* c, const repet_params* p) {
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, p->window_length, &tb));
@@ -429,16 +447,50 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
-    hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
-                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream);
-    if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
-    HIP_TRY(e);
-    mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
     // peaks are more than d frames apart: at most ceil(T/(d+1)) of them, whatever similarity_number says
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
-                            c->fork_event, c->join_event));
-    mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
+    const int n_chunks = sim_chunks(T);
+    if (n_chunks <= 1) {
+        hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
+                                           p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream);
+        if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
+        HIP_TRY(e);
+        mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
+        HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
+                                c->fork_event, c->join_event));
+        mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
+    } else {
+        // Peak picking is LDS/latency-bound, the median mask VALU-bound: run them as a two-stage pipeline over
+        // row chunks -- chunk k+1 is picked on the side stream while chunk k is masked on the main stream.
+        RP_TRY(ensure_chunk_events(c, n_chunks));
+        HIP_TRY(hipEventRecord(c->fork_event, c->stream));              // S is complete here
+        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
+        const int64_t step = round_up(ceil_div(T, n_chunks), 4);
+        for (int k = 0; k < n_chunks; ++k) {
+            const int64_t a0 = k * step, a1 = std::min<int64_t>(T, a0 + step);
+            if (a0 >= a1) break;
+            hipError_t e = launch_local_maxima(c->S.as<float>(), a1 - a0, a0, (int)T, TS, 0, (float)p->sim_threshold,
+                                               p->sim_distance_frames, K, c->idx.as<int32_t>() + a0 * KP, KP,
+                                               c->cnt.as<int32_t>() + a0, c->side_stream);
+            if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
+            HIP_TRY(e);
+            HIP_TRY(hipEventRecord(c->chunk_events[k], c->side_stream));
+        }
+        MaskArgs m = mask_args(c, g, p->cutoff_bins);
+        for (int k = 0; k < n_chunks; ++k) {
+            const int64_t a0 = k * step, a1 = std::min<int64_t>(T, a0 + step);
+            if (a0 >= a1) break;
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_events[k], 0));
+            m.frame0 = a0; m.frame_end = a1;
+            HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, nullptr, nullptr, nullptr, 1));
+        }
+        // the Nyquist bins of every frame, beside the last mask chunks
+        m.frame0 = 0; m.frame_end = 0;
+        HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->side_stream, nullptr, nullptr, nullptr, 2));
+        HIP_TRY(hipEventRecord(c->join_event, c->side_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->join_event, 0));
+        mark(c, "peaks+mask", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
+    }
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = KP; c->last_idx_number = K;
     return REPET_OK;
@@ -560,6 +612,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    for (hipEvent_t e : c->chunk_events) (void)hipEventDestroy(e);
     if (c->fork_event) (void)hipEventDestroy(c->fork_event);
     if (c->join_event) (void)hipEventDestroy(c->join_event);
     (void)hipStreamDestroy(c->stream);

@@ -188,26 +188,28 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const 
 
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side,
-                           hipEvent_t fork, hipEvent_t join) {
-    if (m.T - m.frame0 <= 0) return hipSuccess;
+                           hipEvent_t fork, hipEvent_t join, int parts) {
+    const int64_t t_end = m.frame_end > 0 ? m.frame_end : m.T;
+    if (t_end - m.frame0 <= 0) return hipSuccess;
     // the Nyquist-bin kernel (a few hundred latency-bound waves) runs on `side` next to the main kernel
-    const bool forked = side != nullptr && fork != nullptr && join != nullptr;
+    const bool forked = side != nullptr && fork != nullptr && join != nullptr && parts == 3;
     const bool split = m.F > 64 && ((m.F - 1) & 63) == 0;
     const int64_t rows = m.T - first_frame;
-    const unsigned n_launch = (unsigned)(m.T - m.frame0);   // frames [frame0, T) are processed (frame0 > 0: streaming window)
+    const unsigned n_launch = (unsigned)(t_end - m.frame0);   // frames [frame0, t_end) are processed
     dispatch_net(max_count, [&](auto net) {
         constexpr int NET = decltype(net)::value;
         if (split) {
-            if (rows > 0) {
+            if (rows > 0 && (parts & 2)) {
                 if (forked) { (void)hipEventRecord(fork, s); (void)hipStreamWaitEvent(side, fork, 0); }
                 hipLaunchKernelGGL(mask_sim_nyquist_kernel<NET>, dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels),
                                    dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
                 if (forked) (void)hipEventRecord(join, side);
             }
-            hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
-                               m, idx, idx_pitch, count, first_frame);
+            if (parts & 1)
+                hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
+                                   m, idx, idx_pitch, count, first_frame);
             if (forked && rows > 0) (void)hipStreamWaitEvent(s, join, 0);
-        } else {
+        } else if (parts & 1) {
             hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
                                m, idx, idx_pitch, count, first_frame);
         }

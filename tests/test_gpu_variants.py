@@ -142,7 +142,8 @@ def test_integer_intermediates_through_the_context():
 
     timing = ctx.execute("sim", p, timing=True)
     names = [s["name"] for s in timing["stages"]]
-    assert names == ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"]
+    assert names in (["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"],
+                     ["stft", "similarity_gemm", "peaks+mask", "istft_ola"])
     assert timing["total_ms"] > 0
     ctx.close()
 
