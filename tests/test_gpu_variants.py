@@ -371,3 +371,48 @@ def test_streaming_online_errors():
     with pytest.raises(ValueError):
         stream.push(np.zeros((10, 2)))
     stream.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case,algo", [("cfg3_extended", "extended"), ("cfg4_adaptive", "adaptive"),
+                                        ("cfg5_simonline", "simonline"), ("cfg2_sim", "original")])
+def test_full_size_configs_against_reference_goldens(case, algo):
+    """BASELINE.json configs at full size: the HIP path against strided samples, per-second RMS and integer
+    intermediates of the reference itself (tests/golden/make_golden.py), plus size-independent properties."""
+    g = load_golden(case)
+    x, fs = golden_input(case)
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute(algo, p)
+    y = ctx.download()
+    stride = int(g["sample_stride"])
+    n = (len(y) // fs) * fs
+    per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, y.shape[1]) ** 2, axis=1))
+    if algo == "simonline":
+        # 30-s clips leave <= 10 similar frames per list, so ONE fp32 near-tie flip moves a frame's median visibly
+        # (measured: 4 of 861 frames flip, 5e-4 RMS, 0.04 peak). Require what can be required: every flip is a
+        # genuine tie in the oracle's float64 similarity and the outputs agree once the lists are the same.
+        differing = assert_parity_modulo_near_ties(algo, x, fs)
+        assert differing <= 0.02 * (ctx.last_frame_count() - p.buffer_frames + 1)
+        assert np.mean(np.abs(per_s - g[f"{algo}.rms_per_second"]) < 3e-4) >= 0.9
+    else:
+        assert rms_err(y[::stride], g[f"{algo}.samples"]) <= RMS_TOL
+        assert np.max(np.abs(per_s - g[f"{algo}.rms_per_second"])) < 3e-4
+    mix = np.sqrt(np.mean(np.array(x[:n]).reshape(-1, fs, y.shape[1]) ** 2, axis=1))
+    assert np.all(per_s <= mix * 1.001 + 1e-6)               # a soft mask in (0, 1] never adds energy
+    if algo == "extended":
+        periods = ctx.last_periods(256)
+        assert len(periods) == 119 and np.mean(periods != g["extended.periods"]) <= 0.02
+    if algo == "adaptive":
+        periods = ctx.last_periods(ctx.last_frame_count())
+        assert np.mean(periods != g["adaptive.periods"]) <= 0.01
+    if algo == "original":
+        assert ctx.last_periods(1)[0] == int(g["original.period"])
+    if algo == "simonline":
+        assert np.all(y[:(p.buffer_frames - 1) * p.step_length] == 0)     # first 10 s exactly zero (repet.py:834)
+    # linearity in the input scale (eps = 2^-52 only matters for exact zeros): f(2x) == 2 f(x)
+    ctx.upload(np.asarray(x) * 2.0)
+    ctx.execute(algo, p)
+    assert rms_err(ctx.download(), 2.0 * y) < 2e-6
+    ctx.close()
