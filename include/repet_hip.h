@@ -185,6 +185,10 @@ int repet_ctx_last_periods(repet_ctx* ctx, int32_t* out, int32_t capacity, int32
 int repet_ctx_last_sim_indices(repet_ctx* ctx, int32_t* idx_out, int32_t* count_out, int32_t n_rows,
                                int32_t number);
 int repet_ctx_last_frame_count(repet_ctx* ctx, int64_t* n_frames);
+/* sim / simonline: counters of the near-tie refinement of the last run's peak picking (_localmaxima,
+ * repet.py:1294-1345): out[0] rows with a decision inside the fp32 tolerance, out[1] near-tied elements
+ * re-decided from float64 similarities, out[2] decisions that changed, out[3] flat rows left to fp32. */
+int repet_ctx_last_refine_stats(repet_ctx* ctx, int64_t out[4]);
 
 /* ---- streaming online REPET-SIM (the reference's simonline needs the whole signal, repet.py:712-911) ------
  * open  : state for one stream of n_channels (1, 2 or 4) with the parameters of derive_params(fs);

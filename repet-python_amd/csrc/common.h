@@ -102,9 +102,16 @@ hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, i
 //   mode 1 (simonline): "row" j is the circular-buffer view of the band: element c is
 //           band[j-l][l], l = (j-c) mod B, for c < B = n_cols; indices are FRAME numbers j-l.
 //           `shift` (streaming): band row of frame f is f - shift, and the indices written are band rows.
+//   refine (nullable): near-tie refinement. M must then hold cosine similarities of the fp32 unit rows
+//           `unit_rows` (row of frame f at (f - shift) * pitch): every decision within `delta` of a tie is
+//           re-taken from float64 similarities of those rows, so the index lists do not depend on the fp32
+//           rounding of the Gram kernel. stats (nullable, 4 counters, added to): rows refined, near-tied
+//           elements, decisions changed, flat rows left to fp32.
+struct PeakRefine { const float* unit_rows; int32_t pitch; float delta; double min_value; unsigned int* stats; };
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
-                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0);
+                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0,
+                               const PeakRefine* refine = nullptr);
 
 // K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
 // multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).

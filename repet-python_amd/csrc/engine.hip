@@ -77,6 +77,7 @@ struct repet_ctx {
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
+    DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
     std::map<int, std::unique_ptr<Tables>> tables;
     DevBuf tiles;                 // Gram tile list of the last (nb, ndiag)
     int tiles_nb = -1, tiles_ndiag = -1, tiles_count = 0;
@@ -423,6 +424,28 @@ int ensure_chunk_events(repet_ctx* c, int n) {
     return REPET_OK;
 }
 
+// Near-tie refinement of the peak picking (peaks.hip): the tolerance inside which an fp32 similarity is not
+// trusted. The fp32 MFMA Gram accumulates FS products of unit-vector components, an error random walk of about
+// sqrt(FS) * 2^-24 (measured on MI355X at FS = 1056: rms 3.8e-7, largest 5.9e-6 of 3e6 entries). delta is 4x that
+// estimate (7.7e-6 at FS = 1056): on the probe clips of tools/refine_probe.py 4x, 8x and 16x give identical index
+// lists (0, 0, 0 and 1 rows of 8062 differ from the float64 oracle; plain fp32: 71, 31, 35, 110) and 2x loses one
+// more row, while the cost grows with delta (cfg 2: +0.10 ms at 4x, +0.26 ms at 16x).
+// REPET_PEAK_REFINE=0 turns the refinement off (plain fp32 decisions); REPET_PEAK_DELTA_SCALE overrides the 4.
+float peak_refine_delta(int FS, int d) {
+    static const int on = [] { const char* e = getenv("REPET_PEAK_REFINE"); return e ? atoi(e) : 1; }();
+    if (!on || d > 500) return 0.0f;     // the rival search assumes a window of fewer than 256 float4 groups
+    static const float scale = [] { const char* e = getenv("REPET_PEAK_DELTA_SCALE"); return e ? (float)atof(e) : 4.0f; }();
+    return scale * sqrtf((float)FS) * 5.9604645e-8f;
+}
+
+int make_refine(repet_ctx* c, const float* unit_rows, int FS, int d, double threshold, PeakRefine* rf) {
+    HIP_TRY(c->refine_stats.ensure(4 * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, 4 * sizeof(unsigned int), c->stream));
+    rf->unit_rows = unit_rows; rf->pitch = FS; rf->delta = peak_refine_delta(FS, d); rf->min_value = threshold;
+    rf->stats = c->refine_stats.as<unsigned int>();
+    return REPET_OK;
+}
+
 // Row chunks of the experimental peaks -> mask two-stream pipeline (REPET_SIM_CHUNKS=n enables it). Measured on
 // MI355X at cfg 2 it LOSES: 1.09 ms unchunked vs 1.17 / 1.24 / 1.43 ms at 4 / 8 / 16 chunks -- four mask waves per
 // SIMD leave no registers for a co-resident peak-picking wave and every chunk adds a partial-occupancy tail.
@@ -450,9 +473,11 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     // peaks are more than d frames apart: at most ceil(T/(d+1)) of them, whatever similarity_number says
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
     const int n_chunks = sim_chunks(T);
+    PeakRefine rf{};
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_distance_frames, p->sim_threshold, &rf));
     if (n_chunks <= 1) {
         hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
-                                           p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream);
+                                           p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
         mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
@@ -471,7 +496,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             if (a0 >= a1) break;
             hipError_t e = launch_local_maxima(c->S.as<float>(), a1 - a0, a0, (int)T, TS, 0, (float)p->sim_threshold,
                                                p->sim_distance_frames, K, c->idx.as<int32_t>() + a0 * KP, KP,
-                                               c->cnt.as<int32_t>() + a0, c->side_stream);
+                                               c->cnt.as<int32_t>() + a0, c->side_stream, 0, &rf);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
             HIP_TRY(e);
             HIP_TRY(hipEventRecord(c->chunk_events[k], c->side_stream));
@@ -517,8 +542,10 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int64_t rows = T >= B ? T - B + 1 : 0;
     HIP_TRY(c->idx.ensure((size_t)std::max<int64_t>(rows, 1) * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)std::max<int64_t>(rows, 1) * sizeof(int32_t)));
+    PeakRefine rf{};
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_distance_frames, p->sim_threshold, &rf));
     hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
-                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream);
+                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
     HIP_TRY(e);
     mark(c, "local_maxima", 4.0 * rows * B + 4.0 * K * rows, 0);
@@ -1093,6 +1120,18 @@ int repet_ctx_last_frame_count(repet_ctx* c, int64_t* n_frames) {
     return REPET_OK;
 }
 
+int repet_ctx_last_refine_stats(repet_ctx* c, int64_t out[4]) {
+    if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    for (int k = 0; k < 4; ++k) out[k] = 0;
+    if (!c->refine_stats.p) return REPET_OK;
+    DeviceGuard guard(c->device);
+    unsigned int host[4] = {0, 0, 0, 0};
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->refine_stats.p, sizeof(host), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) out[k] = host[k];
+    return REPET_OK;
+}
+
 }  // extern "C"
 
 // =====================================================================================================
@@ -1201,9 +1240,11 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
             RP_TRY(run_gram_band(c, Vnb, Tw, o->FS, o->band.as<float>(), o->B, o->LP));
             HIP_TRY(c->idx.ensure((size_t)n_active * KP * sizeof(int32_t)));
             HIP_TRY(c->cnt.ensure((size_t)n_active * sizeof(int32_t)));
+            PeakRefine rf{};
+            RP_TRY(make_refine(c, Vnb, o->FS, o->p.sim_distance_frames, o->p.sim_threshold, &rf));
             hipError_t e = launch_local_maxima(o->band.as<float>(), n_active, first_active, o->B, o->LP, 1, (float)o->p.sim_threshold,
                                                o->p.sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream,
-                                               first_global);
+                                               first_global, &rf);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "online: buffer too long for the peak-picking kernel");
             HIP_TRY(e);
         }

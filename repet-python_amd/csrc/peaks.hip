@@ -41,7 +41,55 @@ __device__ __forceinline__ int wave_prefix_slot(bool flag, int* counter, int lan
 struct PeakArgs {
     const float* M; int64_t row0; int n; int64_t pitch; int mode; float min_value; int d; int number;
     int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap; int64_t shift;
+    // near-tie refinement (see below): unit rows the similarities were computed from, or null
+    const float* unit; int unit_pitch; float delta; double min_value64; unsigned int* stats;
 };
+
+constexpr int kAmbCap = 96;    // near-tied elements refined per row; a row with more keeps its fp32 decisions
+constexpr int kRivalCap = 96;  // (near-tied element, rival) pairs per row, same fallback
+
+// float64 cosine similarity of two fp32 rows (one wave, result in every lane). The rows are unit vectors up
+// to fp32 rounding, so their float64 norms are divided out again: the value then depends on the fp32
+// spectra alone, not on how the fp32 Gram kernel accumulated them.
+__device__ __forceinline__ void exact_similarity2(const float* __restrict__ x, const float* __restrict__ y0,
+                                                  const float* __restrict__ y1, int len4, int lane, double* e0, double* e1) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* y04 = reinterpret_cast<const float4*>(y0);
+    const float4* y14 = reinterpret_cast<const float4*>(y1);
+    double xx = 0.0, xy0 = 0.0, yy0 = 0.0, xy1 = 0.0, yy1 = 0.0;
+    for (int k0 = 0; k0 < len4; k0 += 320) {        // 15 loads in flight per lane: one round trip up to 1280 bins
+        float4 p[5], q[5], r[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {                // clamped index: lanes past the row end are zeroed when consumed
+            const int k = min(k0 + 64 * u + lane, len4 - 1);
+            p[u] = x4[k];
+            q[u] = y04[k];
+            r[u] = y14[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const double live = (k0 + 64 * u + lane < len4) ? 1.0 : 0.0;
+            const double p0 = p[u].x * live, p1 = p[u].y * live, p2 = p[u].z * live, p3 = p[u].w * live;
+            const double q0 = q[u].x, q1 = q[u].y, q2 = q[u].z, q3 = q[u].w;
+            const double r0 = r[u].x, r1 = r[u].y, r2 = r[u].z, r3 = r[u].w;
+            xx += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+            xy0 += p0 * q0 + p1 * q1 + p2 * q2 + p3 * q3;
+            yy0 += live * (q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+            xy1 += p0 * r0 + p1 * r1 + p2 * r2 + p3 * r3;
+            yy1 += live * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xx += __shfl_xor(xx, o);
+        xy0 += __shfl_xor(xy0, o);
+        yy0 += __shfl_xor(yy0, o);
+        xy1 += __shfl_xor(xy1, o);
+        yy1 += __shfl_xor(yy1, o);
+    }
+    *e0 = xy0 / sqrt(xx * yy0);
+    *e1 = xy1 / sqrt(xx * yy1);
+}
 
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
@@ -52,18 +100,24 @@ __device__ __forceinline__ float nan_to_inf(float v) { return (v != v) ? INFINIT
 // "-inf" up to the end (at least d + 4 of them). Thread `tid` owns groups tid + 256*q, q < QMAX, and
 // keeps their original values in registers.
 template <int QMAX>
-__global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ? 4 : (QMAX <= 16 ? 2 : 1), QMAX <= 16 ? 8 : 1))) void local_maxima_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* M4 = reinterpret_cast<float4*>(smem);              // groups float4 (row, then window maxima)
     float* pval = smem + 4 * a.groups;                         // peak_cap (multiple of 4)
     int* pidx = reinterpret_cast<int*>(pval + a.peak_cap);     // peak_cap
-    __shared__ int n_peak;
+    __shared__ int n_peak, n_amb, n_riv, n_unl;
+    __shared__ double amb_exact[kAmbCap], riv_exact[kRivalCap];
+    __shared__ int amb_idx[kAmbCap], riv_idx[kRivalCap];
+    __shared__ float amb_val[kAmbCap];
+    __shared__ short riv_owner[kRivalCap], riv_ref[kRivalCap], unl_list[kRivalCap];
+    __shared__ unsigned char amb_ok[kAmbCap], amb_lose[kAmbCap];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = a.n, d = a.d, dl = a.dl, groups = a.groups;
     const int64_t r = blockIdx.x;           // row within this launch
     const int64_t j = a.row0 + r;           // absolute row (mode 1: current frame)
-    if (tid == 0) n_peak = 0;
+    if (tid == 0) { n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0; }
+    float dlt = a.delta;                    // 0: no refinement
     STAMP(0)
 
     auto fetch = [&](int i) -> float {      // element i of the row, -inf outside [0, n)
@@ -153,6 +207,7 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
         if (r == 2) return make_float4(x.z, x.w, y.x, y.y);
         return make_float4(x.w, y.x, y.y, y.z);
     };
+    for (;;) {
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
         const int g = tid + 256 * q;
@@ -167,11 +222,32 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
             const float vals[4] = {own[q].x, own[q].y, own[q].z, own[q].w};
             const float lefts[4] = {left.x, left.y, left.z, left.w};
             const float rights[4] = {right.x, right.y, right.z, right.w};
-            bool oks[4];
+            bool oks[4], nears[4], was_ok[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = vals[e];
-                oks[e] = real && i0 + e < n && (v >= a.min_value) && (v < INFINITY) && (v > lefts[e]) && (v > rights[e]);
+                const bool valid = real && i0 + e < n && (v < INFINITY);
+                oks[e] = valid && (v >= a.min_value) && (v > lefts[e]) && (v > rights[e]);
+                nears[e] = false;
+                was_ok[e] = oks[e];
+                if (dlt > 0.0f) {
+                    // decisions that an fp32 rounding error of the Gram kernel could flip are taken out of the
+                    // fp32 path here and settled in float64 below
+                    const float m = fmaxf(lefts[e], rights[e]);
+                    const bool sure_yes = (v >= a.min_value + dlt) && (v > m + dlt);
+                    const bool sure_no = (v < a.min_value - dlt) || (v < m - dlt);
+                    nears[e] = valid && !sure_yes && !sure_no;
+                    oks[e] = oks[e] && !nears[e];
+                }
+            }
+            if (dlt > 0.0f && __any(nears[0] || nears[1] || nears[2] || nears[3])) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (__any(nears[e])) {
+                        const int slot = wave_prefix_slot(nears[e], &n_amb, lane);
+                        if (nears[e] && slot < kAmbCap) { amb_idx[slot] = i0 + e; amb_val[slot] = vals[e]; amb_ok[slot] = was_ok[e]; }
+                    }
+                }
             }
             if (d >= 3) {
                 // peaks are more than d >= 3 apart: at most one of the 4 consecutive elements survives,
@@ -195,6 +271,109 @@ __global__ __launch_bounds__(256) void local_maxima_kernel(PeakArgs a) {
         }
     }
     __syncthreads();
+        bool redo = false;
+        if (dlt > 0.0f && n_amb > 0) {
+            if (n_amb > kAmbCap) redo = true;       // a flat row: more near-ties than the list holds
+            else {
+                // Rivals of the near-tied elements, found from the values every thread still holds in registers:
+                // element k is a rival of near-tied i when it lies in i's window and within delta below it
+                // (nothing in the window is more than delta above i, or i would have been a safe "no").
+                const int n_near = n_amb;
+                for (int k = tid; k < n_near; k += 256) amb_lose[k] = 0;
+                for (int s = 0; s < n_near; ++s) {
+                    const int i = amb_idx[s];
+                    // the window covers fewer than 256 groups (d <= 500), so at most one of this thread's
+                    const int g_lo = (i - d + dl) >> 2, g_hi = (i + d + dl) >> 2;
+                    const int g = g_lo + ((tid - g_lo) & 255);
+                    if (g > g_hi || g >= groups) continue;
+                    const int qsel = g >> 8;
+                    float4 v = own[0];
+#pragma unroll
+                    for (int q = 1; q < QMAX; ++q) if (qsel == q) v = own[q];
+                    const float vals[4] = {v.x, v.y, v.z, v.w};
+                    const int i0 = 4 * g - dl;
+                    const float lim = amb_val[s] - dlt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = i0 + e;
+                        if (k != i && k >= i - d && k <= i + d && k >= 0 && k < n && vals[e] >= lim) {
+                            const int entry = atomicAdd(&n_riv, 1);
+                            if (entry < kRivalCap) {
+                                int ref = -1;
+                                for (int t = 0; t < n_near; ++t) if (amb_idx[t] == k) ref = t;
+                                riv_owner[entry] = (short)s; riv_ref[entry] = (short)ref; riv_idx[entry] = k;
+                                if (ref < 0) unl_list[atomicAdd(&n_unl, 1)] = (short)entry;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (n_riv > kRivalCap) redo = true;
+            }
+        }
+        if (!redo) break;
+        // redo the test with the plain fp32 decisions
+        __syncthreads();
+        if (tid == 0) {
+            n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0;
+            if (a.stats) atomicAdd(&a.stats[3], 1u);
+        }
+        dlt = 0.0f;
+        __syncthreads();
+    }
+
+    if (dlt > 0.0f && n_amb > 0) {
+        // Near-tie refinement. An element within delta of its window maximum (or of the threshold) is decided
+        // from float64 similarities of the same fp32 spectra: it survives iff its value is >= the threshold
+        // and strictly above every rival (anything lower cannot win, anything higher would have made the
+        // fp32 decision safe).
+        const int n_near = n_amb, n_rival = n_riv, n_items = n_near + n_unl;
+        const int len4 = a.unit_pitch >> 2;
+        const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
+        auto item_row = [&](int it) -> const float* {          // unit row of the frame behind work item `it`
+            const int i = it < n_near ? amb_idx[it] : riv_idx[unl_list[it - n_near]];
+            int64_t fr = i;
+            if (a.mode == 1) {
+                int l = (int)(j - i) % n;
+                if (l < 0) l += n;
+                fr = j - l;
+            }
+            return a.unit + (fr - (a.mode == 1 ? a.shift : 0)) * (int64_t)a.unit_pitch;
+        };
+        // phase 1: float64 values, two work items per wave and memory round trip
+        for (int it = 2 * (tid >> 6); it < n_items; it += 8) {
+            const bool two = it + 1 < n_items;
+            double e0, e1;
+            exact_similarity2(self_row, item_row(it), item_row(two ? it + 1 : it), len4, lane, &e0, &e1);
+            if (lane == 0) {
+                if (it < n_near) amb_exact[it] = e0; else riv_exact[unl_list[it - n_near]] = e0;
+                if (two) { if (it + 1 < n_near) amb_exact[it + 1] = e1; else riv_exact[unl_list[it + 1 - n_near]] = e1; }
+            }
+        }
+        __syncthreads();
+        // phase 2: every rival pair, then the verdicts
+        for (int e = tid; e < n_rival; e += 256) {
+            const int s = riv_owner[e], ref = riv_ref[e];
+            const double er = ref >= 0 ? amb_exact[ref] : riv_exact[e];
+            if (!(amb_exact[s] > er)) amb_lose[s] = 1;
+        }
+        __syncthreads();
+        int changed = 0;
+        for (int k = tid; k < n_near; k += 256) {
+            const double ek = amb_exact[k];
+            const bool win = !amb_lose[k] && ek >= a.min_value64;
+            if (win) {
+                const int slot = atomicAdd(&n_peak, 1);
+                if (slot < a.peak_cap) { pval[slot] = (float)ek; pidx[slot] = amb_idx[k]; }
+            }
+            changed += (win != (amb_ok[k] != 0));
+        }
+        if (a.stats) {
+            if (tid == 0) { atomicAdd(&a.stats[0], 1u); atomicAdd(&a.stats[1], (unsigned)n_near); }
+            if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+        }
+        __syncthreads();
+    }
 
     STAMP(3)
     // rank by counting: value descending, higher index first on ties (np.argsort(...)[::-1])
@@ -244,12 +423,17 @@ static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, size_t bytes, hi
 
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
-                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift) {
+                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift, const PeakRefine* refine) {
     if (n_rows <= 0) return hipSuccess;
     if (d > n_cols) d = n_cols;                                       // a wider window changes nothing
     PeakArgs a{};
     a.M = M; a.row0 = row0; a.n = n_cols; a.pitch = pitch; a.mode = mode; a.min_value = min_value; a.d = d;
     a.number = number; a.idx = idx; a.idx_pitch = idx_pitch; a.count = count; a.shift = shift;
+    a.min_value64 = min_value;
+    if (refine && refine->unit_rows && refine->delta > 0.0f && (refine->pitch & 3) == 0) {
+        a.unit = refine->unit_rows; a.unit_pitch = refine->pitch; a.delta = refine->delta;
+        a.min_value64 = refine->min_value; a.stats = refine->stats;
+    }
     a.dl = (int)round_up(d, 4);
     a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 3);      // slack for the aligned window reads past the end
     a.peak_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart

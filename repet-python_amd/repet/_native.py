@@ -75,6 +75,7 @@ _SIGNATURES = {
     "repet_ctx_last_periods": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "repet_ctx_last_sim_indices": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "repet_ctx_last_frame_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "repet_ctx_last_refine_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "repet_online_open": (C.c_int, [C.c_int, C.c_int32, C.POINTER(Params), C.POINTER(_P)]),
     "repet_online_push": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "repet_online_finish": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -209,6 +210,12 @@ class Context:
         t = C.c_int64()
         check(lib().repet_ctx_last_frame_count(self._h, C.byref(t)))
         return t.value
+
+    def last_refine_stats(self):
+        """Near-tie refinement counters of the last sim/simonline run (see repet_ctx_last_refine_stats)."""
+        out = (C.c_int64 * 4)()
+        check(lib().repet_ctx_last_refine_stats(self._h, out))
+        return {"rows_refined": out[0], "elements_refined": out[1], "decisions_changed": out[2], "flat_rows": out[3]}
 
     def last_sim_indices(self, n_rows, number):
         idx = np.empty((max(n_rows, 1), number), dtype=np.int32)

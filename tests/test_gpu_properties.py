@@ -8,7 +8,7 @@ import repet
 from oracle import repet_oracle as orc
 
 pytestmark = pytest.mark.gpu
-SETTINGS = dict(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+SETTINGS = dict(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 
 
 @settings(**SETTINGS)
@@ -28,9 +28,10 @@ def test_local_maxima_random(n, d, k, seed, kind, thr):
     vals, idx = repet._localmaxima(v, thr, d, k)
     wv, wi = orc.localmaxima(v.astype(np.float64), thr, d, k)
     assert len(idx) == len(wi)
-    if len(np.unique(wv)) == len(wv):
+    all_v, _ = orc.localmaxima(v.astype(np.float64), thr, d, n)   # every peak, to see ties at the top-k cut
+    if len(np.unique(all_v)) == len(all_v):
         assert np.array_equal(idx, wi)
-    else:                                                       # ties at the top-k cut: same multiset of values
+    else:             # exact ties: numpy's (unstable) argsort decides the reference order; same multiset of values
         assert np.array_equal(np.sort(vals), np.sort(wv))
         assert len(set(idx.tolist())) == len(idx)
     # every reported index really is a strict local maximum above the threshold
@@ -77,7 +78,7 @@ def test_adaptive_mask_random(t, f, order, seed):
     assert np.max(np.abs(got - want)) < 1e-6
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(n=st.integers(1, 9000), logw=st.integers(6, 11), seed=st.integers(0, 2**31 - 1))
 def test_stft_istft_random_lengths(n, logw, seed):
     rs = np.random.RandomState(seed)

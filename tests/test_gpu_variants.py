@@ -133,12 +133,12 @@ def test_integer_intermediates_through_the_context():
     ctx.execute("sim", p)
     t = ctx.last_frame_count()
     idx, cnt = ctx.last_sim_indices(t, p.sim_number)
-    assert np.mean(cnt != g["sim.counts"]) <= 0.02
-    fstride = int(g["frame_stride"])
+    assert np.mean(cnt != g["sim.counts"]) <= 0.002
     differ = 0
     for row, frame in zip(g["sim.indices"], g["sim.index_frames"]):
         differ += set(idx[frame, :cnt[frame]]) != set(row[row >= 0])
-    assert differ / len(g["sim.index_frames"]) <= 0.10   # fp32 similarity can flip near-ties
+    # near-ties of the fp32 similarity are re-decided in float64 (peaks.hip), so the lists are the reference's
+    assert differ <= max(1, 0.005 * len(g["sim.index_frames"]))
 
     timing = ctx.execute("sim", p, timing=True)
     names = [s["name"] for s in timing["stages"]]
@@ -371,6 +371,32 @@ def test_streaming_online_errors():
     with pytest.raises(ValueError):
         stream.push(np.zeros((10, 2)))
     stream.close()
+
+
+@pytest.mark.parametrize("algo,seconds,fs,channels,seed", [("sim", 60, 22050, 2, 1), ("sim", 20, 96000, 1, 3),
+                                                           ("sim", 90, 16000, 2, 4), ("simonline", 45, 16000, 2, 5),
+                                                           ("simonline", 30, 44100, 1, 6)])
+def test_similar_frame_lists_are_the_float64_references(algo, seconds, fs, channels, seed):
+    """The discrete half of REPET-SIM: with plain fp32 similarities 2-4 % of the rows pick another frame at a
+    near-tie (tools/refine_probe.py); with the float64 near-tie refinement the lists match the oracle's."""
+    x = synth(seconds, fs, channels, seed)
+    tr = orc.Trace()
+    want = orc.ALGORITHMS[algo](x, fs, None, tr)
+    theirs = tr.items["similarity_indices"]
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute(algo, p)
+    got = ctx.download()
+    idx, cnt = ctx.last_sim_indices(len(theirs), p.sim_number)
+    stats = ctx.last_refine_stats()
+    ctx.close()
+    differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(len(theirs)))
+    assert differ <= max(1, 0.001 * len(theirs)), (differ, len(theirs), stats)
+    assert stats["elements_refined"] > 0 and stats["flat_rows"] == 0
+    if differ == 0:
+        ok = ~np.isnan(want)
+        assert rms_err(got[ok], want[ok]) <= 2e-5          # what is left is fp32 arithmetic, not decisions
 
 
 @pytest.mark.slow
