@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     float* pval = smem + 4 * a.groups;                         // peak_cap (multiple of 4)
     int* pidx = reinterpret_cast<int*>(pval + a.peak_cap);     // peak_cap
     __shared__ int n_peak, n_amb, n_riv, n_unl;
+    __shared__ float cutv[2];
     __shared__ double amb_exact[kAmbCap], riv_exact[kRivalCap];
     __shared__ int amb_idx[kAmbCap], riv_idx[kRivalCap];
     __shared__ float amb_val[kAmbCap];
@@ -322,6 +323,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
         __syncthreads();
     }
 
+    auto elem_row = [&](int i) -> const float* {               // unit row of the frame behind element i
+        int64_t fr = i;
+        if (a.mode == 1) {
+            int l = (int)(j - i) % n;
+            if (l < 0) l += n;
+            fr = j - l - a.shift;
+        }
+        return a.unit + fr * (int64_t)a.unit_pitch;
+    };
     if (dlt > 0.0f && n_amb > 0) {
         // Near-tie refinement. An element within delta of its window maximum (or of the threshold) is decided
         // from float64 similarities of the same fp32 spectra: it survives iff its value is >= the threshold
@@ -331,14 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
         const int len4 = a.unit_pitch >> 2;
         const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
         auto item_row = [&](int it) -> const float* {          // unit row of the frame behind work item `it`
-            const int i = it < n_near ? amb_idx[it] : riv_idx[unl_list[it - n_near]];
-            int64_t fr = i;
-            if (a.mode == 1) {
-                int l = (int)(j - i) % n;
-                if (l < 0) l += n;
-                fr = j - l;
-            }
-            return a.unit + (fr - (a.mode == 1 ? a.shift : 0)) * (int64_t)a.unit_pitch;
+            return elem_row(it < n_near ? amb_idx[it] : riv_idx[unl_list[it - n_near]]);
         };
         // phase 1: float64 values, two work items per wave and memory round trip
         for (int it = 2 * (tid >> 6); it < n_items; it += 8) {
@@ -384,6 +387,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     __syncthreads();
     int* out = a.idx + r * (int64_t)a.idx_pitch;
     const float4* pv4 = reinterpret_cast<const float4*>(pval);
+    auto out_index = [&](int i) -> int {                       // what the list holds for element i
+        if (a.mode == 0) return i;
+        int l = (int)(j - i) % n;
+        if (l < 0) l += n;
+        return (int)(j - l - a.shift);
+    };
+    const bool cut_check = dlt > 0.0f && np_ > a.number;
+    int* prank = reinterpret_cast<int*>(smem);                 // the window maxima are no longer needed
     for (int p = tid; p < np_; p += 256) {
         const float v = pval[p];
         const int i = pidx[p];
@@ -397,14 +408,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
                         (u.z == v && pidx[4 * q4 + 2] > i) + (u.w == v && pidx[4 * q4 + 3] > i);
             }
         }
-        if (rank < a.number) {
-            int o = i;
-            if (a.mode == 1) {
-                int l = (int)(j - i) % n;
-                if (l < 0) l += n;
-                o = (int)(j - l - a.shift);
+        if (rank < a.number) out[rank] = out_index(i);
+        if (cut_check) prank[p] = rank;
+    }
+    if (cut_check) {
+        // Top-`number` cut with more candidates than slots: if the last value kept and the first one dropped are
+        // within delta, every candidate within delta of that boundary is re-ranked by float64 similarity. The
+        // candidates above that band keep their places (they stay in the top `number` whatever the band's true
+        // order is), the band's members fill the remaining slots in float64 order.
+        __syncthreads();
+        if (tid == 0) { n_amb = 0; n_riv = 0; }
+        for (int p = tid; p < np_; p += 256) {
+            if (prank[p] == a.number - 1) cutv[0] = pval[p];
+            if (prank[p] == a.number) cutv[1] = pval[p];
+        }
+        __syncthreads();
+        const float c_in = cutv[0], c_out = cutv[1];
+        if (c_in - c_out <= dlt) {
+            const float lo = c_out - dlt, hi = c_in + dlt;
+            for (int p = tid; p < np_; p += 256) {
+                const float v = pval[p];
+                if (v > hi) atomicAdd(&n_riv, 1);                          // candidates safely above the band
+                else if (v >= lo) {
+                    const int slot = atomicAdd(&n_amb, 1);
+                    if (slot < kAmbCap) { amb_idx[slot] = pidx[p]; amb_ok[slot] = prank[p] < a.number; }
+                }
             }
-            out[rank] = o;
+            __syncthreads();
+            const int n_band = n_amb, n_above = n_riv;
+            if (n_band <= kAmbCap) {
+                const int len4 = a.unit_pitch >> 2;
+                const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
+                for (int it = 2 * (tid >> 6); it < n_band; it += 8) {
+                    const bool two = it + 1 < n_band;
+                    double e0, e1;
+                    exact_similarity2(self_row, elem_row(amb_idx[it]), elem_row(amb_idx[two ? it + 1 : it]), len4, lane, &e0, &e1);
+                    if (lane == 0) { amb_exact[it] = e0; if (two) amb_exact[it + 1] = e1; }
+                }
+                __syncthreads();
+                int changed = 0;
+                for (int k = tid; k < n_band; k += 256) {
+                    const double e = amb_exact[k];
+                    const int i = amb_idx[k];
+                    int crank = 0;
+                    for (int t = 0; t < n_band; ++t) crank += (amb_exact[t] > e) || (amb_exact[t] == e && amb_idx[t] > i);
+                    const bool keep = n_above + crank < a.number;
+                    if (keep) out[n_above + crank] = out_index(i);
+                    changed += (keep != (amb_ok[k] != 0));
+                }
+                if (a.stats) {
+                    if (tid == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
+                    if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+                }
+            } else if (a.stats && tid == 0) atomicAdd(&a.stats[3], 1u);
         }
     }
     STAMP(4)

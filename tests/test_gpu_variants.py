@@ -373,17 +373,20 @@ def test_streaming_online_errors():
     stream.close()
 
 
-@pytest.mark.parametrize("algo,seconds,fs,channels,seed", [("sim", 60, 22050, 2, 1), ("sim", 20, 96000, 1, 3),
-                                                           ("sim", 90, 16000, 2, 4), ("simonline", 45, 16000, 2, 5),
-                                                           ("simonline", 30, 44100, 1, 6)])
-def test_similar_frame_lists_are_the_float64_references(algo, seconds, fs, channels, seed):
+@pytest.mark.parametrize("algo,seconds,fs,channels,seed,number", [
+    ("sim", 60, 22050, 2, 1, 100), ("sim", 20, 96000, 1, 3, 100), ("sim", 90, 16000, 2, 4, 100),
+    ("simonline", 45, 16000, 2, 5, 100), ("simonline", 30, 44100, 1, 6, 100),
+    ("sim", 60, 22050, 2, 7, 12), ("sim", 50, 16000, 1, 8, 5), ("simonline", 40, 16000, 2, 9, 4)])   # top-k cut active
+def test_similar_frame_lists_are_the_float64_references(algo, seconds, fs, channels, seed, number, monkeypatch):
     """The discrete half of REPET-SIM: with plain fp32 similarities 2-4 % of the rows pick another frame at a
     near-tie (tools/refine_probe.py); with the float64 near-tie refinement the lists match the oracle's."""
+    monkeypatch.setattr(repet, "similarity_number", number)
     x = synth(seconds, fs, channels, seed)
     tr = orc.Trace()
-    want = orc.ALGORITHMS[algo](x, fs, None, tr)
+    want = orc.ALGORITHMS[algo](x, fs, orc.Params(similarity_number=number), tr)
     theirs = tr.items["similarity_indices"]
     p = repet.derive_params(fs)
+    assert p.sim_number == number
     ctx = repet.Context(0)
     ctx.upload(x)
     ctx.execute(algo, p)
