@@ -53,6 +53,10 @@ struct IstftOlaArgs {
     int32_t n_batch, batch_first, batch_step, batch_total, batch_local0; int64_t batch_spec_stride, batch_out_stride, overlap;
 };
 hipError_t launch_istft_ola(const IstftOlaArgs& a, hipStream_t s);
+// register-resident variants for W = 2048 (stft_reg.hip); launch_stft / launch_istft_ola pick them themselves
+bool reg_fft_supported(int W, int n_channels, bool inverse);
+hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s);
+hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t s);
 
 // Overlap-add of frames[c][t][W] at hop H into out[n][C] (interleaved), out sample n takes padded
 // position n + trim; multiplied by `scale` (1/sum(window[0:W:H])).

@@ -742,6 +742,7 @@ constexpr int kOlaWaveRun = 15;      // + the frame before = 16 frames per workg
 
 hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
     if (a.T <= 0) return hipSuccess;
+    if (reg_fft_supported(a.W, a.n_channels, false)) return launch_stft_reg(a, s);
     if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 8) {
         const int C = a.n_channels, N = a.W / 2;
         const int FI = C >= 4 ? 1 : 4 / C;
@@ -782,6 +783,7 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     if (a.last_hop > a.T) a.last_hop = a.T;                  // hop T holds the last frame's tail, later hops are empty
     const int64_t hops = a.last_hop - a.first_hop + 1;
     if (hops <= 0) return hipSuccess;
+    if (reg_fft_supported(a.W, a.n_channels, true)) return launch_istft_ola_reg(a, hops, s);
     if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 4 && a.n_channels != 3) {
         const int C = a.n_channels;
         const int FI = 4 / C;

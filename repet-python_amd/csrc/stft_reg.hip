@@ -1,0 +1,385 @@
+// K1r / K9r: register-resident STFT and inverse for the 2048-sample window (44.1 / 48 kHz), gfx950.
+//
+// One WAVEFRONT owns one transform: the 1024-point complex FFT behind a real 2048-sample frame lives in 16
+// float2 registers per lane and is computed as 16 x 16 x 4 (Cooley-Tukey, decimation in time):
+//   n = 64 n1 + n2,  k = k1 + 16 (j1 + 16 j2),  n2 = 4 m1 + m2
+//   A: lane n2 holds x[64 n1 + n2]            -> DFT16 over n1, times W_1024^(n2 k1)
+//   B: lane (k1, m2) holds those for n2 = 4 m1 + m2 -> DFT16 over m1, times W_64^(m2 j1)
+//   C: lane (u, k1) holds (k1, j1 = 4 i + u, m2)    -> DFT4 over m2
+// and lane l ends with X[l + 64 s], s < 16 -- the distribution it started with. The two transposes go through
+// a private 10 KB LDS region per wave with conflict-free pitches (68 and 80/20, see the bank rules in
+// MI355X_MICROARCH.md: ds_write_b64 = 16-lane groups mod 32 banks, ds_read_b64 = 32-lane groups mod 64), and
+// there is no workgroup barrier anywhere in the forward kernel: the block-wide Stockham version (stft.hip)
+// spends 7 barriers per transform. The Hermitian split needs Z[N-k], which sits in lane 64-l, slot 15-s:
+// one ds_bpermute per component. Same arithmetic contract as stft.hip (repet.py:1001-1105, :158, :1220).
+#include "common.h"
+
+#include <cstdlib>
+
+namespace repet {
+
+namespace {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+__device__ __forceinline__ void wave_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
+    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), e = csub(b, d);
+    const float2 t3 = INV ? make_float2(-e.y, e.x) : make_float2(e.y, -e.x);   // -i e (forward), +i e (inverse)
+    a = cadd(t0, t2); b = cadd(t1, t3); c = csub(t0, t2); d = csub(t1, t3);
+}
+
+// 16-point DFT in place: input v[n] natural (n = 4p + q); output X[k] in v[tr16(k)].
+__host__ __device__ constexpr int tr16(int k) { return (k >> 2) + 4 * (k & 3); }
+
+template <bool INV>
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dft4<INV>(v[q], v[q + 4], v[q + 8], v[q + 12]);      // v[q + 4r] = y[q][r]
+    // y[q][r] *= W_16^(q r)
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    auto mulw = [](float2 x, float wr, float wi) {      // x * (wr - i wi) forward, (wr + i wi) inverse
+        const float im = INV ? wi : -wi;
+        return make_float2(x.x * wr - x.y * im, x.x * im + x.y * wr);
+    };
+    v[1 + 4] = mulw(v[1 + 4], c1, s1);        // q r = 1
+    v[1 + 8] = mulw(v[1 + 8], h, h);          // 2
+    v[1 + 12] = mulw(v[1 + 12], s1, c1);      // 3
+    v[2 + 4] = mulw(v[2 + 4], h, h);          // 2
+    v[2 + 8] = mulw(v[2 + 8], 0.f, 1.f);      // 4: -i
+    v[2 + 12] = mulw(v[2 + 12], -h, h);       // 6
+    v[3 + 4] = mulw(v[3 + 4], s1, c1);        // 3
+    v[3 + 8] = mulw(v[3 + 8], -h, h);         // 6
+    v[3 + 12] = mulw(v[3 + 12], -c1, -s1);    // 9
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4<INV>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);   // v[s + 4r] = X[r + 4s]
+}
+
+constexpr int kRegN = 1024;          // complex FFT length
+constexpr int kExPitch = 1280;       // float2 per wave: max(16 * 68, 16 * 80)
+
+// Stage twiddles, shared by the four waves of a workgroup, in LDS: a[k1][lane] = W_1024^(lane k1) (lane-contiguous,
+// conflict-free) and b[m2][j1] = W_64^(m2 j1) (four addresses per read, broadcast). 8.2 KB.
+constexpr int kTwFloat2 = 16 * 64 + 64;
+struct RegTwiddles { const float2* a; const float2* b; };
+
+template <bool INV>
+__device__ __forceinline__ RegTwiddles load_reg_twiddles(float2* lds, const float2* __restrict__ tw2048, int tid) {
+    for (int i = tid; i < 16 * 64; i += 256) {
+        const int k1 = i >> 6, l = i & 63;
+        const float2 w = tw2048[2 * l * k1];                  // exp(-2 pi i l k1 / 1024)
+        lds[i] = INV ? cconj(w) : w;
+    }
+    if (tid < 64) {
+        const int m2 = tid >> 4, j1 = tid & 15;
+        const float2 w = tw2048[32 * m2 * j1];                // exp(-2 pi i m2 j1 / 64)
+        lds[16 * 64 + tid] = INV ? cconj(w) : w;
+    }
+    return RegTwiddles{lds, lds + 16 * 64};
+}
+
+// v[n1] = x[64 n1 + lane] in; v[s] = X[lane + 64 s] out (unscaled). `ex` is this wave's private LDS region.
+template <bool INV>
+__device__ __forceinline__ void wave_fft1024(float2 (&v)[16], float2* ex, const RegTwiddles& t, int lane) {
+    dft16<INV>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        const float2 x = v[tr16(k1)];
+        ex[68 * k1 + lane] = (k1 == 0) ? x : cmul(x, t.a[64 * k1 + lane]);
+    }
+    wave_fence();
+    {
+        const float2* src = ex + 68 * (lane >> 2) + (lane & 3);
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = src[4 * m1];
+    }
+    wave_fence();
+    dft16<INV>(v);
+    {
+        float2* dst = ex + (lane >> 2) + 20 * (lane & 3);
+#pragma unroll
+        for (int j1 = 0; j1 < 16; ++j1) {
+            const float2 x = v[tr16(j1)];
+            dst[80 * j1] = (j1 == 0) ? x : cmul(x, t.b[16 * (lane & 3) + j1]);
+        }
+    }
+    wave_fence();
+    {
+        const float2* src = ex + 80 * (lane >> 4) + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 c0 = src[320 * i], c1 = src[320 * i + 20], c2 = src[320 * i + 40], c3 = src[320 * i + 60];
+            dft4<INV>(c0, c1, c2, c3);
+            v[i] = c0; v[i + 4] = c1; v[i + 8] = c2; v[i + 12] = c3;       // slot s = i + 4 j2
+        }
+    }
+    wave_fence();
+}
+
+__device__ __forceinline__ float lane_fetch(float x, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(x)));
+}
+
+// ---- forward ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void stft_reg_kernel(StftArgs a, int frames_per_wave) {
+    constexpr int N = kRegN, W = 2 * kRegN;
+    __shared__ float2 ex_all[4 * kExPitch];
+    __shared__ float2 tw_lds[kTwFloat2];
+    const int tid = threadIdx.x, lane_id = tid & 63, wave = tid >> 6;
+    float2* ex = ex_all + wave * kExPitch;
+    const int C = a.n_channels;
+    const int64_t b = blockIdx.y;
+    a.sample_offset += b * a.batch_sample_stride;
+    a.X += b * a.batch_spec_stride;
+    a.V += b * a.batch_spec_stride;
+    if (a.Vm) a.Vm += b * a.batch_mean_stride;
+    if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.P) a.P += b * a.batch_mean_stride;
+
+    const RegTwiddles tw = load_reg_twiddles<false>(tw_lds, a.twiddle, tid);
+    __syncthreads();
+    const bool want_mean = a.Vm || a.Vn || a.P;
+    const int64_t t_first = ((int64_t)blockIdx.x * 4 + wave) * frames_per_wave;
+
+    for (int64_t t = t_first; t < t_first + frames_per_wave && t < a.T; ++t) {
+        const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
+        const int64_t row = t * a.FS;
+        float acc[17];
+#pragma unroll
+        for (int s = 0; s < 17; ++s) acc[s] = 0.f;
+
+        for (int c = 0; c < C; ++c) {
+            // the lane number, made opaque once per transform: otherwise the compiler hoists the ~50 per-slot
+            // addresses out of both loops and spills them
+            int lane = lane_id;
+            asm volatile("" : "+v"(lane));
+            const int partner = (64 - lane) & 63;
+            float2 v[16];
+            // may point before the clip for the leading frames: then only the guarded path dereferences it
+            const float* base = a.audio + ((a.sample_offset + start) * C + c);
+            if (start >= 0 && start + W <= a.n_samples) {          // wave-uniform: the frame lies inside the clip
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const int n = 64 * n1 + lane;
+                    const float x0 = base[2 * n * C], x1 = base[(2 * n + 1) * C];
+                    const float2 w = *reinterpret_cast<const float2*>(a.window + 2 * n);
+                    v[n1] = make_float2(x0 * w.x, x1 * w.y);
+                }
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const int n = 64 * n1 + lane;
+                    const int64_t s0 = start + 2 * n, s1 = s0 + 1;
+                    const float x0 = (s0 >= 0 && s0 < a.n_samples) ? base[2 * n * C] : 0.f;
+                    const float x1 = (s1 >= 0 && s1 < a.n_samples) ? base[(2 * n + 1) * C] : 0.f;
+                    const float2 w = *reinterpret_cast<const float2*>(a.window + 2 * n);
+                    v[n1] = make_float2(x0 * w.x, x1 * w.y);
+                }
+            }
+            wave_fft1024<false>(v, ex, tw, lane);
+
+            float2* Xrow = a.X + c * a.chan_stride + row;
+            float* Vrow = a.V + c * a.chan_stride + row;
+            // Hermitian split: X[k] = E + W_2048^k O with E = (Z[k] + conj Z[N-k]) / 2, O = (Z[k] - conj Z[N-k]) / 2i.
+            // Z[N-k] for k = lane + 64 s is slot 15 - s of lane 64 - lane (lane 0: its own slot (16 - s) & 15).
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = lane + 64 * s;
+                const float2 zk = v[s];
+                const float2 other = make_float2(lane_fetch(v[15 - s].x, partner), lane_fetch(v[15 - s].y, partner));
+                const float2 mine = v[(16 - s) & 15];
+                const float2 zn = (lane == 0) ? mine : other;
+                const float2 zc = cconj(zn);
+                const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+                const float2 d = csub(zk, zc);
+                const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
+                const float2 x = cadd(e, cmul(a.twiddle[k], o));
+                const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                Xrow[k] = x;
+                Vrow[k] = mag;
+                acc[s] += mag;
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four bins in flight, not sixteen
+            }
+            {   // k = N (Nyquist): Z[N & (N-1)] = Z[0] on both sides, W_2048^N = -1
+                const float z0x = __shfl(v[0].x, 0), z0y = __shfl(v[0].y, 0);
+                const float2 x = make_float2(z0x - z0y, 0.f);
+                const float mag = fabsf(x.x);
+                if (lane == 0) { Xrow[N] = x; Vrow[N] = mag; }
+                acc[16] += mag;
+            }
+            if (lane < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
+                Xrow[N + 1 + lane] = make_float2(0.f, 0.f);
+                Vrow[N + 1 + lane] = 0.f;
+            }
+        }
+        if (!want_mean) continue;
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+
+        // channel mean (repet.py:162,:667) and its L2 norm over frequency (repet.py:1220), all inside the wave
+        const float inv_c = 1.0f / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < 17; ++s) {
+            acc[s] = (C == 1) ? acc[s] : acc[s] * inv_c;
+            if (s < 16 || lane == 0) ss += acc[s] * acc[s];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float norm = sqrtf(ss);        // 0 for a silent frame: 0/0 = NaN like repet.py:1220
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = lane + 64 * s;
+            if (a.Vm) a.Vm[row + k] = acc[s];
+            if (a.Vn) a.Vn[row + k] = acc[s] / norm;
+            if (a.P) a.P[row + k] = acc[s] * acc[s];
+        }
+        if (lane == 0) {
+            if (a.Vm) a.Vm[row + N] = acc[16];
+            if (a.Vn) a.Vn[row + N] = acc[16] / norm;
+            if (a.P) a.P[row + N] = acc[16] * acc[16];
+        }
+        if (lane < a.FS - (N + 1)) {
+            if (a.Vm) a.Vm[row + N + 1 + lane] = 0.f;
+            if (a.Vn) a.Vn[row + N + 1 + lane] = 0.f;
+            if (a.P) a.P[row + N + 1 + lane] = 0.f;
+        }
+    }
+}
+
+// ---- inverse + overlap-add ---------------------------------------------------------------------------
+// `run` hops per workgroup; each round the four waves invert FI = 4 / C consecutive frames x C channels into
+// their LDS regions (natural order, as W real samples), then all threads add heads and tails and write whole
+// hops interleaved over the channels. tails[c][n] carries the second half of the previous frame.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void istft_ola_reg_kernel(IstftOlaArgs a, int run) {
+    constexpr int N = kRegN;          // samples per hop = complex FFT length
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    float2* ex_all = lds2;                                               // [4][kExPitch]
+    float2* tw_lds = ex_all + 4 * kExPitch;                              // [kTwFloat2]
+    float* tails = reinterpret_cast<float*>(tw_lds + kTwFloat2);         // [C][N]
+    const int tid = threadIdx.x, lane_id = tid & 63, wave = tid >> 6;
+    const int C = a.n_channels;
+    if (a.n_batch > 0) {
+        const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
+        a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        a.out_offset += (int64_t)j * a.batch_out_stride;
+        a.fade_in = j > 0 ? a.overlap : 0;
+        a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
+    }
+    for (int i = tid; i < C * N; i += 256) tails[i] = 0.f;
+    const RegTwiddles tw = load_reg_twiddles<true>(tw_lds, a.twiddle, tid);
+    __syncthreads();
+
+    const int FI = 4 / C;                       // frames per round (C in {1, 2, 4})
+    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * run;
+    int64_t h1 = h0 + run - 1;
+    if (h1 > a.last_hop) h1 = a.last_hop;
+    float2* ex = ex_all + wave * kExPitch;
+    const float inv_n = a.scale / (float)N;
+    // frames h0-1 .. h1 ; frame t feeds hop t (first half) and hop t+1 (second half)
+    for (int64_t t0 = h0 - 1; t0 <= h1; t0 += FI) {
+        {
+            const int df = wave / C, c = wave - df * C;
+            const int64_t t = t0 + df;
+            int lane = lane_id;
+            asm volatile("" : "+v"(lane));
+            float2 v[16];
+            if (t >= 0 && t < a.T && t <= h1) {
+                const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
+                // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const int k = 64 * n1 + lane;
+                    const float2 xk = Y[k];
+                    const float2 xc = cconj(Y[N - k]);
+                    const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+                    const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+                    const float2 o = cmul(d, cconj(a.twiddle[k]));
+                    v[n1] = make_float2(e.x - o.y, e.y + o.x);
+                    if ((n1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                wave_fft1024<true>(v, ex, tw, lane);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) v[s] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) ex[lane + 64 * s] = v[s];        // samples 2k, 2k+1 of the frame
+        }
+        __syncthreads();
+        for (int i = tid; i < N * C; i += 256) {
+            const int sidx = i / C, c = i - sidx * C;
+            float prev = tails[c * N + sidx];
+            for (int df = 0; df < FI; ++df) {
+                const int64_t h = t0 + df;                     // hop fed by the first half of frame t0+df
+                const float* fr = reinterpret_cast<const float*>(ex_all + (df * C + c) * kExPitch);
+                const float v = (prev + fr[sidx]) * inv_n;
+                prev = fr[N + sidx];
+                if (h < h0 || h > h1) continue;
+                const int64_t n = h * N - a.trim + sidx;
+                if (n < 0 || n >= a.n_out) continue;
+                float* dst = a.out + (a.out_offset + n) * C + c;
+                if (a.accumulate_weighted) {
+                    float w = 1.f;
+                    if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
+                    else if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w = (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
+                    *dst += w * v;
+                } else {
+                    *dst = v;
+                }
+            }
+            tails[c * N + sidx] = prev;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool reg_fft_supported(int W, int n_channels, bool inverse) {
+    static const int mode = [] {            // REPET_FFT_PATH=reg selects these kernels (default: the block Stockham ones)
+        const char* e = getenv("REPET_FFT_PATH");
+        return (e && e[0] == 'r') ? 1 : 0;
+    }();
+    if (!mode || W != 2 * kRegN) return false;
+    if (inverse) return n_channels == 1 || n_channels == 2 || n_channels == 4;
+    return n_channels >= 1;
+}
+
+// Both kernels keep 3 workgroups (12 wavefronts) per CU; the work per wave / per workgroup is sized so that the
+// whole launch is one well-filled round of those slots.
+constexpr int64_t kRegSlots = 256 * 3;
+
+hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s) {
+    const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
+    int64_t fpw = ceil_div(a.T * batches, 4 * kRegSlots);
+    fpw = fpw < 1 ? 1 : (fpw > 16 ? 16 : fpw);
+    const unsigned blocks = (unsigned)ceil_div(a.T, 4 * fpw);
+    hipLaunchKernelGGL(stft_reg_kernel, dim3(blocks, (unsigned)batches), dim3(256), 0, s, a, (int)fpw);
+    return hipGetLastError();
+}
+
+hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t s) {
+    const int C = a.n_channels, FI = 4 / C;
+    const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
+    int64_t want = ceil_div(hops * batches, kRegSlots);
+    want = want < 7 ? 7 : (want > 31 ? 31 : want);
+    const int run = (int)round_up(want + 1, FI) - 1;        // + the frame before = a whole number of rounds
+    const size_t dyn = (size_t)(4 * kExPitch + kTwFloat2) * sizeof(float2) + (size_t)C * kRegN * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_reg_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(istft_ola_reg_kernel, dim3((unsigned)ceil_div(hops, run), (unsigned)batches), dim3(256), dyn, s, a, run);
+    return hipGetLastError();
+}
+
+}  // namespace repet

@@ -222,23 +222,26 @@ def test_other_rates_and_channel_counts(algo, fs, channels, seconds):
     assert rms_err(got, want) <= RMS_TOL, f"rms {rms_err(got, want):.3e}"
 
 
-def test_wave_fft_path_matches_block_path():
-    """REPET_FFT_PATH=wave selects the wave-synchronous STFT/iSTFT kernels; both paths must agree."""
+def test_fft_paths_agree():
+    """REPET_FFT_PATH picks the STFT/iSTFT kernels: "reg" (default; one wavefront per transform, data in registers,
+    W = 2048 only), "block" (workgroup Stockham in LDS) and "wave" (wave-synchronous Stockham). All must agree."""
     import os
     import subprocess
     import sys
     code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
             "x = synth(6, 44100, 2, 3); y = repet.original(x, 44100); z = repet.sim(x, 44100); "
-            "np.save(sys.argv[1], np.stack([y, z]))")
+            "m = synth(6, 48000, 1, 4); u = repet.adaptive(m, 48000); q = synth(5, 44100, 4, 5); r = repet.extended(q, 44100);"
+            "np.save(sys.argv[1], np.concatenate([y.ravel(), z.ravel(), u.ravel(), r.ravel()]))")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "repet-python_amd"), root)
     outs = []
-    for path in ("block", "wave"):
+    for path in ("block", "wave", "reg"):
         out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_fft_{path}_{os.getpid()}.npy")
         subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_FFT_PATH=path))
         outs.append(np.load(out))
         os.remove(out)
     assert rms_err(outs[0], outs[1]) < 2e-6
+    assert rms_err(outs[0], outs[2]) < 2e-6
 
 
 def test_long_similarity_number_uses_bisection_path():
