@@ -59,15 +59,23 @@ def main():
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--clips", type=int, default=1, help="independent clips per rank and step (config 5: 64 in total)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
-                    help="BASELINE.json configs[i-1]: 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz mono, "
-                         "5 simonline 30-s clips (64 over all ranks)")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configs[i-1]: 1 original on the reference's 23-s example clip (replayed from the PCM "
+                         "fixture under tests/golden), 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz "
+                         "mono, 5 simonline 30-s clips (64 over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=180.0,
                     help="length of the CPU-baseline clip (default: the whole config-2 clip, ~25 s of host time)")
     args = ap.parse_args()
 
-    if args.config == 3:
+    example_clip = None
+    if args.config == 1:
+        import numpy
+        with numpy.load(os.path.join(ROOT, "tests", "golden", "cfg1_audio_pcm.npz")) as z:
+            pcm, args.fs = z["pcm"], int(z["fs"])
+        example_clip = pcm / pow(2, pcm.itemsize * 8 - 1)
+        args.algo, args.duration, args.channels = "original", len(pcm) / args.fs, pcm.shape[1]
+    elif args.config == 3:
         args.algo, args.duration = "extended", 600.0
     elif args.config == 4:
         args.algo, args.duration, args.fs, args.channels = "adaptive", 300.0, 48000, 1
@@ -97,7 +105,7 @@ def main():
     params = repet.derive_params(fs)
     ctxs = []
     for k in range(args.clips):           # inputs resident in HBM (fp32, interleaved) before timing starts
-        clip = synth(args.duration, fs, channels, seed=rank * args.clips + k)
+        clip = example_clip if example_clip is not None else synth(args.duration, fs, channels, seed=rank * args.clips + k)
         ctx = repet.Context(local_rank)
         ctx.upload(clip)
         ctxs.append(ctx)
@@ -178,8 +186,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch synthetic clip(s) per GPU "
+            "dtype": "f32", "data": "synthetic" if example_clip is None else "the reference's example clip (tests/golden/cfg1_audio_pcm.npz)",
+            "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
                                    f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
                        "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
                        "frames": int(ctx.last_frame_count()), "parallelism": f"clip-parallel x{world}, no collective"},

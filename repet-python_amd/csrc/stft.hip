@@ -165,8 +165,14 @@ __device__ __forceinline__ float2* fft_lds_regs(float2* a, float2* b, const FftT
 
 constexpr int kStftFrameRun = 4;     // frames per workgroup: the register tables are loaded once per run
 
+#ifndef REPET_STFT_MIN_WAVES
+#define REPET_STFT_MIN_WAVES 4
+#endif
+#ifndef REPET_ISTFT_MIN_WAVES
+#define REPET_ISTFT_MIN_WAVES 1
+#endif
 template <int W>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? 4 : 1, 8))) void stft_kernel(StftArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_STFT_MIN_WAVES : 1, 8))) void stft_kernel(StftArgs a) {
     constexpr int N = W / 2;                       // complex FFT length; also the Nyquist bin index
     constexpr int SLOTS = N / kFftThreads + 1;     // bins k = tid + 256*i, k <= N
     constexpr int LOADS = (N + kFftThreads - 1) / kFftThreads;
@@ -384,7 +390,7 @@ __device__ __forceinline__ const float2* inverse_frame(const SpectrumRegs<W>& r,
 }
 
 template <int W>
-__global__ __launch_bounds__(kFftThreads) void istft_ola_kernel(IstftOlaArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_ISTFT_MIN_WAVES : 1, 8))) void istft_ola_kernel(IstftOlaArgs a) {
     constexpr int N = W / 2;          // complex points per frame = samples per hop (H = W/2)
     constexpr int HP = N / 2;         // float2 per half frame
     __shared__ float2 buf0[N];

@@ -103,9 +103,9 @@ def per_second_rms(y, fs):
     return np.sqrt(np.mean(y[:n].reshape(-1, fs, y.shape[1]) ** 2, axis=1))
 
 
-def run_case(ref, name, spec, frame_stride):
+def run_case(ref, name, spec, frame_stride, clip=None):
     dur, fs, ch, seed, stride, algos = spec
-    x = synth(dur, fs, ch, seed)
+    x = synth(dur, fs, ch, seed) if clip is None else clip
     data = {"fs": fs, "duration": dur, "channels": ch, "seed": seed, "sample_stride": stride,
             "input_samples": x[::stride].copy(),
             "frame_stride": frame_stride}
@@ -223,6 +223,14 @@ def main():
     if "config" in want:
         for name, spec in CONFIG_CASES.items():
             run_case(ref, name, spec, 16)
+    if "cfg1" in want:
+        # BASELINE.json configs[0]: the reference's own example clip (README.md:62-75), read the way its wavread
+        # does (repet.py:914-931). The int16 PCM goes into the fixture as data so the GPU box can replay it.
+        import scipy.io.wavfile
+        fs, pcm = scipy.io.wavfile.read("/root/reference/audio_file.wav")
+        np.savez_compressed(os.path.join(HERE, "cfg1_audio_pcm.npz"), fs=fs, pcm=pcm)
+        clip = pcm / pow(2, pcm.itemsize * 8 - 1)
+        run_case(ref, "cfg1_audio_file", (len(pcm) / fs, fs, pcm.shape[1], -1, 211, ALGOS), 4, clip=clip)
 
 
 if __name__ == "__main__":

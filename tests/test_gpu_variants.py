@@ -391,6 +391,43 @@ def test_streaming_online_errors():
     stream.close()
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+def test_reference_example_clip(algo):
+    """BASELINE.json configs[0]: the reference's own example clip (real music, README.md:62-75), replayed from its
+    int16 PCM through wavread's normalisation, against the reference's outputs and integer intermediates."""
+    g = load_golden("cfg1_audio_file")
+    x, fs = golden_input("cfg1_audio_file")
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute(algo, p)
+    y = ctx.download()
+    stride = int(g["sample_stride"])
+    assert y.shape == (1014301, 2)
+    assert rms_err(y[::stride], g[f"{algo}.samples"]) <= RMS_TOL
+    n = (len(y) // fs) * fs
+    per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, 2) ** 2, axis=1))
+    assert np.max(np.abs(per_s - g[f"{algo}.rms_per_second"])) < 3e-4
+    if algo == "original":
+        assert ctx.last_periods(1)[0] == 286
+    if algo == "extended":
+        assert np.array_equal(ctx.last_periods(16), g["extended.periods"])
+    if algo == "adaptive":
+        assert np.mean(ctx.last_periods(ctx.last_frame_count()) != g["adaptive.periods"]) <= 0.01
+    if algo == "sim":
+        t = ctx.last_frame_count()
+        idx, cnt = ctx.last_sim_indices(t, p.sim_number)
+        assert t == 992 and np.array_equal(cnt, g["sim.counts"])
+        differ = sum(set(idx[f, :cnt[f]].tolist()) != set(row[row >= 0].tolist())
+                     for row, f in zip(g["sim.indices"], g["sim.index_frames"]))
+        assert differ <= 1
+    if algo == "simonline":
+        rows = ctx.last_frame_count() - p.buffer_frames + 1
+        idx, cnt = ctx.last_sim_indices(rows, p.sim_number)
+        assert np.array_equal(cnt, g["simonline.counts"])
+    ctx.close()
+
+
 @pytest.mark.parametrize("algo,seconds,fs,channels,seed,number", [
     ("sim", 60, 22050, 2, 1, 100), ("sim", 20, 96000, 1, 3, 100), ("sim", 90, 16000, 2, 4, 100),
     ("simonline", 45, 16000, 2, 5, 100), ("simonline", 30, 44100, 1, 6, 100),

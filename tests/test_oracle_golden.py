@@ -101,6 +101,27 @@ def test_localmaxima_matches_definition():
         assert np.array_equal(idx, want[order])
 
 
+# ---- BASELINE.json configs[0]: the reference's own example clip (real music, 23 s, 44.1 kHz stereo) ----
+@pytest.mark.parametrize("algo", ALGOS)
+def test_reference_example_clip(algo):
+    y, tr, g = _run("cfg1_audio_file", algo)
+    stride = int(g["sample_stride"])
+    assert y.shape == (1014301, 2)
+    assert np.max(np.abs(y[::stride] - g[f"{algo}.samples"])) <= TOL
+    if algo == "original":
+        assert tr["repeating_period"] == int(g["original.period"]) == 286        # arg-max lag 285
+    if algo == "extended":
+        assert np.array_equal(tr["segment_periods"], g["extended.periods"])
+    if algo == "adaptive":
+        assert np.array_equal(tr["repeating_periods"], g["adaptive.periods"])
+    if algo == "sim":
+        assert np.array_equal(np.array([len(ix) for ix in tr["similarity_indices"]]), g["sim.counts"])
+        for row, frame in zip(g["sim.indices"], g["sim.index_frames"]):
+            assert np.array_equal(tr["similarity_indices"][frame], row[row >= 0])
+    if algo == "simonline":
+        assert np.array_equal(np.array([len(ix) for ix in tr["similarity_indices"]]), g["simonline.counts"])
+
+
 # ---- BASELINE.json config sizes: oracle vs the reference's strided samples and integer intermediates ----
 CONFIG_CASES = [("cfg5_simonline", "simonline"), ("cfg4_adaptive", "adaptive"), ("cfg3_extended", "extended")]
 if __import__("os").environ.get("REPET_FULL_GOLDEN") == "1":      # 180-s sim: ~1.5 CPU-minutes for the oracle
