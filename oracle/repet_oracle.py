@@ -344,25 +344,37 @@ def extended(x, fs, p=None, trace=None):
     return out
 
 
+def segment_weights(j, segs, overlap):
+    """Weight every sample of segment j ends up with after the in-place cross-fade of repet.py:380-414: its own
+    rising half of triang(2*overlap) (j > 0) times the falling half that EVERY later segment applies to what lies
+    under its first ``overlap`` samples (one factor at the default 50 % overlap, several when step < overlap)."""
+    start, length = segs[j]
+    w = np.ones(length)
+    tri = scipy.signal.windows.triang(2 * overlap)
+    if j > 0:
+        w[:overlap] *= tri[:overlap]
+    for later_start, _ in segs[j + 1:]:
+        lo = later_start - start
+        hi = min(lo + overlap, length)
+        if lo < hi:
+            w[lo:hi] *= tri[overlap:overlap + hi - lo]
+    return w
+
+
 def extended_range(x, fs, first, count, p=None):
-    """Contribution of segments [first, first+count) to :func:`extended`: sum_j w_j * original(segment_j)
-    with w_j = [rising half | 1 | falling half] of triang(2*overlap) (repet.py:380-414, which is linear
-    in the segments). Used to check the multi-GPU segment sharding."""
+    """Contribution of segments [first, first+count) to :func:`extended`: sum_j w_j * original(segment_j) with
+    w_j = :func:`segment_weights` (the reference's cross-fade is linear in the segments). Used to check the
+    multi-GPU segment sharding."""
     p = p or Params()
     n, c = np.shape(x)
     segs, overlap = extended_plan(n, fs, p)
     out = np.zeros((n, c))
     if len(segs) == 1:
         return original(x, fs, p) if (first, count) == (0, 1) else out
-    tri = scipy.signal.windows.triang(2 * overlap)
     for j in range(first, first + count):
         start, length = segs[j]
         piece = original(x[start:start + length], fs, p)
-        if j > 0:
-            piece[:overlap] *= tri[:overlap, np.newaxis]
-        if j < len(segs) - 1:
-            piece[length - overlap:] *= tri[overlap:, np.newaxis]
-        out[start:start + length] += piece
+        out[start:start + length] += piece * segment_weights(j, segs, overlap)[:, np.newaxis]
     return out
 
 

@@ -34,6 +34,24 @@ struct StftArgs {
 };
 hipError_t launch_stft(const StftArgs& a, hipStream_t s);
 
+// Cross-fade weight of sample n of a segment of `extended` (repet.py:380-414). The reference fades IN PLACE: every
+// segment after the first multiplies what has been accumulated under its first `overlap` samples by the falling
+// half of triang(2*overlap), multiplies its own first `overlap` samples by the rising half, and adds. A sample of
+// segment j is therefore scaled by its own rise (n < fade_in) and by the fall of EVERY later segment q = 1..later
+// (starting q*step samples further on) whose overlap zone covers it -- one factor with the default 50 % overlap,
+// several when the step is shorter than the overlap.
+__host__ __device__ inline float segment_weight(int64_t n, int64_t fade_in, int64_t overlap, int64_t step, int later) {
+    float w = 1.f;
+    if (n < fade_in) w = (float)(2 * n + 1) / (float)(2 * fade_in);
+    if (overlap > 0 && step > 0) {
+        for (int64_t q = 1; q <= later && q * step <= n; ++q) {
+            const int64_t r = n - q * step;       // position inside later segment q
+            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) / (float)(2 * overlap);
+        }
+    }
+    return w;
+}
+
 // K9: masked spectrum -> inverse real FFT -> time frames yf[c][t][W] (scaled by 1/W like np.fft.ifft).
 struct IstftArgs {
     const float2* Y; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t FS; int32_t W;
@@ -46,6 +64,7 @@ struct IstftOlaArgs {
     const float2* Y; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t FS; int32_t W;
     const float2* twiddle; int64_t trim; float* out; int64_t n_out; int64_t out_offset; float scale;
     int32_t accumulate_weighted; int64_t fade_in, fade_out;
+    int64_t seg_step; int32_t later;   // cross-fade of `extended`, filled by the kernels from the batch fields
     int64_t first_hop, last_hop;   // filled by the launcher
     // batch of segments (extended): blockIdx.y = slot, segment j = batch_first + slot*batch_step reads its
     // spectra at j_local*batch_spec_stride, writes at out_offset + j*batch_out_stride, and fades in unless

@@ -319,12 +319,9 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(OlaArgs a) {
     sum *= a.scale;
     float* dst = a.out + (a.out_offset + n) * C + c;
     if (a.accumulate_weighted) {
-        float w = 1.f;
-        if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
-        else if (n >= a.n_out - a.fade_out && a.fade_out > 0) {
-            const int64_t q = a.n_out - 1 - n;   // mirrored index into the rising half
-            w = (float)(2 * q + 1) / (float)(2 * a.fade_out);
-        }
+        // stage export: a single segment, so only its own rise and (if asked for) one fall over its last samples
+        float w = segment_weight(n, a.fade_in, 0, 0, 0);
+        if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w *= (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
         *dst += w * sum;
     } else {
         *dst = sum;
@@ -409,7 +406,9 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
-        a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
+        a.fade_out = a.overlap;
+        a.seg_step = a.batch_out_stride;
+        a.later = a.batch_total - 1 - j;
     }
 
     SpectrumRegs<W> spec;
@@ -455,9 +454,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
             float v = stage[i] * a.scale;
             float* dst = a.out + (a.out_offset + n) * C + (i % C);
             if (a.accumulate_weighted) {
-                float w = 1.f;
-                if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
-                else if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w = (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
+                const float w = segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later);
                 *dst += w * v;
             } else {
                 *dst = v;
@@ -661,7 +658,9 @@ __global__ __launch_bounds__(256) void istft_ola_wave_kernel(IstftOlaArgs a, int
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
-        a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
+        a.fade_out = a.overlap;
+        a.seg_step = a.batch_out_stride;
+        a.later = a.batch_total - 1 - j;
     }
     for (int i = tid; i < W; i += 256) tw[i] = a.twiddle[i];
     for (int i = tid; i < C * N; i += 256) tails[i] = 0.f;
@@ -709,9 +708,7 @@ __global__ __launch_bounds__(256) void istft_ola_wave_kernel(IstftOlaArgs a, int
                 if (n < 0 || n >= a.n_out) continue;
                 float* dst = a.out + (a.out_offset + n) * C + c;
                 if (a.accumulate_weighted) {
-                    float w = 1.f;
-                    if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
-                    else if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w = (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
+                    const float w = segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later);
                     *dst += w * v;
                 } else {
                     *dst = v;

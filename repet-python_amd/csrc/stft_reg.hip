@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
-        a.fade_out = j < a.batch_total - 1 ? a.overlap : 0;
+        a.fade_out = a.overlap;
+        a.seg_step = a.batch_out_stride;
+        a.later = a.batch_total - 1 - j;
     }
     for (int i = tid; i < C * N; i += 256) tails[i] = 0.f;
     const RegTwiddles tw = load_reg_twiddles<true>(tw_lds, a.twiddle, tid);
@@ -330,9 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 if (n < 0 || n >= a.n_out) continue;
                 float* dst = a.out + (a.out_offset + n) * C + c;
                 if (a.accumulate_weighted) {
-                    float w = 1.f;
-                    if (n < a.fade_in) w = (float)(2 * n + 1) / (float)(2 * a.fade_in);
-                    else if (a.fade_out > 0 && n >= a.n_out - a.fade_out) w = (float)(2 * (a.n_out - 1 - n) + 1) / (float)(2 * a.fade_out);
+                    const float w = segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later);
                     *dst += w * v;
                 } else {
                     *dst = v;

@@ -82,6 +82,13 @@ def test_extended_is_the_sum_of_segment_ranges():
     full = orc.extended(x, FS)
     parts = sum(orc.extended_range(x, FS, first, count) for first, count in parallel.segment_ranges(n_seg, 3))
     assert np.max(np.abs(parts - full)) < 1e-12
+    # step shorter than the overlap: a sample lies under up to four segments and the in-place fades compound
+    p = orc.Params(segment_length=8, segment_step=2)
+    n_seg = len(orc.extended_plan(len(x), FS, p)[0])
+    assert n_seg == 10
+    full = orc.extended(x, FS, p)
+    parts = sum(orc.extended_range(x, FS, first, count, p) for first, count in parallel.segment_ranges(n_seg, 3))
+    assert np.max(np.abs(parts - full)) < 1e-12
 
 
 def test_scatter_separate_gather_two_ranks(tmp_path):

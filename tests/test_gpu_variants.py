@@ -168,6 +168,32 @@ def test_extended_segment_ranges_add_up():
         repet.Context(0).execute_extended_range(p, 0, 1)      # nothing uploaded
 
 
+@pytest.mark.parametrize("seg_len,seg_step,fs,channels,seconds", [(5.0, 1.25, 44100, 3, 24.65), (8.0, 2.0, 16000, 2, 31.0),
+                                                                  (10.0, 7.5, 22050, 1, 36.0), (6.0, 1.0, 8000, 2, 23.0)])
+def test_extended_with_other_overlaps(seg_len, seg_step, fs, channels, seconds, monkeypatch):
+    """The reference cross-fades in place, so with a step shorter than the overlap the fades of several later
+    segments compound on one sample (found by tools/fuzz_parity.py); a step longer than the overlap leaves gaps
+    of weight 1. Both against the oracle, and as the sum of segment ranges."""
+    monkeypatch.setattr(repet, "segment_length", seg_len)
+    monkeypatch.setattr(repet, "segment_step", seg_step)
+    x = synth(seconds, fs, channels, 77)
+    prm = orc.Params(segment_length=seg_len, segment_step=seg_step)
+    want = orc.extended(x, fs, prm)
+    got = repet.extended(x, fs)
+    assert rms_err(got, want) <= 2e-5
+    p = repet.derive_params(fs)
+    n_seg = _native.lib().repet_extended_segment_count(len(x), p)
+    assert n_seg == len(orc.extended_plan(len(x), fs, prm)[0]) and n_seg >= 3
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    total = np.zeros_like(want)
+    for first, count in parallel.segment_ranges(n_seg, 3):
+        ctx.execute_extended_range(p, first, count)
+        total += ctx.download()
+    ctx.close()
+    assert rms_err(total, want) <= 2e-5
+
+
 def test_batch_api_matches_single_calls():
     fs = 8000
     clips = [synth(d, fs, 2, s) for d, s in [(4, 1), (7, 2), (5, 3)]]
