@@ -343,8 +343,10 @@ int exec_original(repet_ctx* c, const repet_params* p) {
 
 int64_t extended_segment_count(int64_t N, const repet_params* p) {
     const int64_t L = p->seg_len_samples, Hs = p->seg_step_samples;
-    if (L <= 0 || Hs <= 0 || Hs > L) return -1;
-    return (N < L + Hs) ? 1 : 1 + (N - L) / Hs;          // repet.py:271-281
+    if (L <= 0 || Hs <= 0) return -1;
+    if (N < L + Hs) return 1;                             // repet.py:271-275: a single segment, whatever the step
+    if (Hs > L) return -1;                                // several segments with a negative overlap: triang() raises
+    return 1 + (N - L) / Hs;                              // repet.py:277-281
 }
 
 // segments [first, first+n_seg) of the resident clip; contributions of other segments are left zero,
@@ -353,8 +355,8 @@ int64_t extended_segment_count(int64_t N, const repet_params* p) {
 // (it absorbs the remainder, repet.py:320-322) runs on its own.
 int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_t n_seg = -1) {
     const int64_t N = c->n_samples, L = p->seg_len_samples, Hs = p->seg_step_samples;
-    if (L <= 0 || Hs <= 0 || Hs > L) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step");
     const int64_t count = extended_segment_count(N, p);
+    if (count < 0) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step (Window length M must be a non-negative integer)");
     if (n_seg < 0) n_seg = count - first;
     if (first < 0 || n_seg < 0 || first + n_seg > count) return fail(REPET_ERR_BAD_ARG, "extended: segment range outside the plan");
     if (count == 1) {                                               // repet.py:271
