@@ -435,7 +435,8 @@ int ensure_chunk_events(repet_ctx* c, int n) {
 // REPET_PEAK_REFINE=0 turns the refinement off (plain fp32 decisions); REPET_PEAK_DELTA_SCALE overrides the 4.
 float peak_refine_delta(int FS, int d) {
     static const int on = [] { const char* e = getenv("REPET_PEAK_REFINE"); return e ? atoi(e) : 1; }();
-    if (!on || d > 500) return 0.0f;     // the rival search assumes a window of fewer than 256 float4 groups
+    (void)d;
+    if (!on) return 0.0f;
     static const float scale = [] { const char* e = getenv("REPET_PEAK_DELTA_SCALE"); return e ? (float)atof(e) : 4.0f; }();
     return scale * sqrtf((float)FS) * 5.9604645e-8f;
 }

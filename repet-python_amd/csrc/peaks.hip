@@ -283,27 +283,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
                 for (int k = tid; k < n_near; k += 256) amb_lose[k] = 0;
                 for (int s = 0; s < n_near; ++s) {
                     const int i = amb_idx[s];
-                    // the window covers fewer than 256 groups (d <= 500), so at most one of this thread's
+                    // this thread's groups inside the window: one when the window spans fewer than 256 groups
                     const int g_lo = (i - d + dl) >> 2, g_hi = (i + d + dl) >> 2;
-                    const int g = g_lo + ((tid - g_lo) & 255);
-                    if (g > g_hi || g >= groups) continue;
-                    const int qsel = g >> 8;
-                    float4 v = own[0];
-#pragma unroll
-                    for (int q = 1; q < QMAX; ++q) if (qsel == q) v = own[q];
-                    const float vals[4] = {v.x, v.y, v.z, v.w};
-                    const int i0 = 4 * g - dl;
                     const float lim = amb_val[s] - dlt;
+                    for (int g = g_lo + ((tid - g_lo) & 255); g <= g_hi && g < groups; g += 256) {
+                        const int qsel = g >> 8;
+                        float4 v = own[0];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = i0 + e;
-                        if (k != i && k >= i - d && k <= i + d && k >= 0 && k < n && vals[e] >= lim) {
-                            const int entry = atomicAdd(&n_riv, 1);
-                            if (entry < kRivalCap) {
-                                int ref = -1;
-                                for (int t = 0; t < n_near; ++t) if (amb_idx[t] == k) ref = t;
-                                riv_owner[entry] = (short)s; riv_ref[entry] = (short)ref; riv_idx[entry] = k;
-                                if (ref < 0) unl_list[atomicAdd(&n_unl, 1)] = (short)entry;
+                        for (int q = 1; q < QMAX; ++q) if (qsel == q) v = own[q];
+                        const float vals[4] = {v.x, v.y, v.z, v.w};
+                        const int i0 = 4 * g - dl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = i0 + e;
+                            if (k != i && k >= i - d && k <= i + d && k >= 0 && k < n && vals[e] >= lim) {
+                                const int entry = atomicAdd(&n_riv, 1);
+                                if (entry < kRivalCap) {
+                                    int ref = -1;
+                                    for (int t = 0; t < n_near; ++t) if (amb_idx[t] == k) ref = t;
+                                    riv_owner[entry] = (short)s; riv_ref[entry] = (short)ref; riv_idx[entry] = k;
+                                    if (ref < 0) unl_list[atomicAdd(&n_unl, 1)] = (short)entry;
+                                }
                             }
                         }
                     }

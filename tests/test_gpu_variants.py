@@ -483,6 +483,29 @@ def test_similar_frame_lists_are_the_float64_references(algo, seconds, fs, chann
         assert rms_err(got[ok], want[ok]) <= 2e-5          # what is left is fp32 arithmetic, not decisions
 
 
+def test_similar_frame_lists_with_a_wide_window(monkeypatch):
+    """similarity_distance = 12 s: a +-517-frame window spans more than 256 float4 groups of the row, so a thread
+    owns several groups of one rival window in the near-tie refinement."""
+    monkeypatch.setattr(repet, "similarity_distance", 12.0)
+    monkeypatch.setattr(repet, "similarity_number", 128)
+    fs = 22050
+    x = synth(26.4, fs, 2, 1078)
+    tr = orc.Trace()
+    want = orc.sim(x, fs, orc.Params(similarity_distance=12.0, similarity_number=128), tr)
+    theirs = tr.items["similarity_indices"]
+    p = repet.derive_params(fs)
+    assert p.sim_distance_frames > 500
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute("sim", p)
+    got = ctx.download()
+    idx, cnt = ctx.last_sim_indices(len(theirs), p.sim_number)
+    ctx.close()
+    differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(len(theirs)))
+    assert differ <= 1, differ
+    assert rms_err(got, want) <= 1e-4
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("case,algo", [("cfg3_extended", "extended"), ("cfg4_adaptive", "adaptive"),
                                         ("cfg5_simonline", "simonline"), ("cfg2_sim", "original")])
