@@ -128,7 +128,7 @@ def test_integer_intermediates_through_the_context():
     ctx.execute("adaptive", p)
     t = ctx.last_frame_count()
     got = ctx.last_periods(t)
-    assert np.mean(got != g["adaptive.periods"]) <= 0.01
+    assert np.sum(got != g["adaptive.periods"]) <= 2             # measured: 0 of 626
 
     ctx.execute("sim", p)
     t = ctx.last_frame_count()
@@ -439,7 +439,7 @@ def test_reference_example_clip(algo):
     if algo == "extended":
         assert np.array_equal(ctx.last_periods(16), g["extended.periods"])
     if algo == "adaptive":
-        assert np.mean(ctx.last_periods(ctx.last_frame_count()) != g["adaptive.periods"]) <= 0.01
+        assert np.sum(ctx.last_periods(ctx.last_frame_count()) != g["adaptive.periods"]) <= 2      # measured: 0 of 992
     if algo == "sim":
         t = ctx.last_frame_count()
         idx, cnt = ctx.last_sim_indices(t, p.sim_number)
@@ -536,10 +536,10 @@ def test_full_size_configs_against_reference_goldens(case, algo):
     assert np.all(per_s <= mix * 1.001 + 1e-6)               # a soft mask in (0, 1] never adds energy
     if algo == "extended":
         periods = ctx.last_periods(256)
-        assert len(periods) == 119 and np.mean(periods != g["extended.periods"]) <= 0.02
+        assert len(periods) == 119 and np.array_equal(periods, g["extended.periods"])
     if algo == "adaptive":
         periods = ctx.last_periods(ctx.last_frame_count())
-        assert np.mean(periods != g["adaptive.periods"]) <= 0.01
+        assert np.sum(periods != g["adaptive.periods"]) <= 4                    # measured: 0 of 14 064 frames
     if algo == "original":
         assert ctx.last_periods(1)[0] == int(g["original.period"])
     if algo == "simonline":
