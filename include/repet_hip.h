@@ -94,6 +94,13 @@ int repet_ctx_destroy(repet_ctx* ctx);
  * execute : runs the whole algorithm on the resident clip; blocks until the stream is idle
  * download: background_signal as float64 [n_samples][n_channels]                                  */
 int repet_ctx_upload(repet_ctx* ctx, const void* audio, int dtype, int64_t n_samples, int32_t n_channels);
+/* n_clips equal-shape clips back to back, audio[n_clips][n_samples][n_channels] (a Python loop over
+ * repet.simonline(clip, fs), BASELINE.json configs[4]). execute then separates every clip: simonline runs each
+ * stage ONCE over all clips (one launch per stage instead of one per clip and stage), the other variants work
+ * through the resident clips one after the other. download / download_foreground return
+ * [n_clips][n_samples][n_channels]; the integer intermediates are those of the last clip. */
+int repet_ctx_upload_batch(repet_ctx* ctx, const void* audio, int dtype, int64_t n_samples, int32_t n_channels,
+                           int32_t n_clips);
 int repet_ctx_execute(repet_ctx* ctx, int algo, const repet_params* p, repet_timing* timing /* nullable */);
 int repet_ctx_download(repet_ctx* ctx, double* out);
 /* Non-blocking form of execute: enqueues the whole run on the context's stream and returns; contexts have

@@ -131,10 +131,12 @@ hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, i
 //           rounding of the Gram kernel. stats (nullable, 4 counters, added to): rows refined, near-tied
 //           elements, decisions changed, flat rows left to fp32.
 struct PeakRefine { const float* unit_rows; int32_t pitch; float delta; double min_value; unsigned int* stats; };
+// batch (nullable): blockIdx.y = clip of a batch of equal-shape matrices; element strides between the clips
+struct PeakBatch { int32_t n_batch; int64_t m_stride, idx_stride, cnt_stride, unit_stride; };
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0,
-                               const PeakRefine* refine = nullptr);
+                               const PeakRefine* refine = nullptr, const PeakBatch* batch = nullptr);
 
 // K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
 // multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).
@@ -142,7 +144,8 @@ struct MaskArgs {
     const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t F, FS;
     float2* X; float* mask; int32_t cutoff;
     int64_t pad_row;   // rows pad_row / pad_row+1 of every channel of V hold -1.0f / +inf (median pads)
-    int32_t n_batch; int64_t batch_stride;   // mask_period only: blockIdx.z = clip, elements between clips
+    int32_t n_batch; int64_t batch_stride;   // mask_period / mask_sim: blockIdx.z = clip, elements between clips in V and X
+    int64_t idx_batch_stride, cnt_batch_stride;   // mask_sim: elements between the clips' index lists / list lengths
     int64_t frame0;                          // mask_sim only: first frame row handled by this launch (streaming window)
     int64_t frame_end;                       // mask_sim only: one past the last frame row of this launch (0 = T)
 };

@@ -73,7 +73,9 @@ struct repet_ctx {
     std::vector<hipEvent_t> chunk_events;
     // resident clip
     DevBuf staging, audio, out, out64;
-    int64_t n_samples = 0;
+    int64_t n_samples = 0;        // per clip
+    int32_t n_clips = 1;          // equal-shape clips back to back in `audio` / `out` (repet_ctx_upload_batch)
+    int64_t clip_base = 0;        // first sample of the clip the single-clip pipelines currently work on
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
@@ -228,8 +230,10 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     const size_t mean_elems = (size_t)g.Tpad * g.FS;
     if (want_vn) {
         HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
-        for (int b = 0; b < B; ++b)
-            HIP_TRY(hipMemsetAsync(c->Vn.as<float>() + b * mean_elems + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), c->stream));
+        // rows [T, Tpad) of every clip must read as zero for the Gram tiles: one strided fill for the whole batch
+        if (g.Tpad > g.T)
+            HIP_TRY(hipMemset2DAsync(c->Vn.as<float>() + g.T * g.FS, mean_elems * sizeof(float), 0,
+                                     (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), (size_t)B, c->stream));
     }
     if (want_p) {
         HIP_TRY(c->P.ensure(B * mean_elems * sizeof(float)));
@@ -242,7 +246,7 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
 int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64_t n, int centred, bool vn, bool p,
              int B = 1, int64_t batch_sample_stride = 0) {
     StftArgs a{};
-    a.audio = c->audio.as<float>(); a.n_samples = n; a.n_channels = g.C; a.sample_offset = offset;
+    a.audio = c->audio.as<float>(); a.n_samples = n; a.n_channels = g.C; a.sample_offset = c->clip_base + offset;
     a.window = tb->window.as<float>(); a.twiddle = tb->twiddle.as<float2>();
     a.W = g.W; a.H = g.H; a.T = g.T; a.FS = g.FS; a.centred = centred;
     a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
@@ -269,7 +273,7 @@ int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_
     IstftOlaArgs a{};
     a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
     a.twiddle = tb->twiddle.as<float2>(); a.trim = trim; a.out = c->out.as<float>(); a.n_out = n_out;
-    a.out_offset = out_offset; a.scale = (float)(1.0 / tb->cola);
+    a.out_offset = c->clip_base + out_offset; a.scale = (float)(1.0 / tb->cola);
     a.accumulate_weighted = weighted ? 1 : 0; a.fade_in = fade_in; a.fade_out = fade_out;
     hipError_t e = launch_istft_ola(a, c->stream);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
@@ -319,11 +323,11 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
             IstftOlaArgs a{};
             a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
             a.twiddle = tb->twiddle.as<float2>(); a.trim = g.W - g.H; a.out = c->out.as<float>(); a.n_out = n;
-            a.out_offset = 0; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 1;
+            a.out_offset = c->clip_base; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 1;
             a.n_batch = (B - k + classes - 1) / classes; a.batch_first = seg_first + k; a.batch_step = classes;
             a.batch_total = seg_total; a.batch_local0 = k; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
             a.batch_out_stride = hop > 0 ? hop : 0; a.overlap = overlap;
-            if (hop == 0) a.out_offset = offset;          // single (last) segment: explicit offset, j = seg_first
+            if (hop == 0) a.out_offset = c->clip_base + offset;   // single (last) segment: explicit offset, j = seg_first
             hipError_t e = launch_istft_ola(a, c->stream);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
             HIP_TRY(e);
@@ -361,12 +365,12 @@ int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_
     if (first < 0 || n_seg < 0 || first + n_seg > count) return fail(REPET_ERR_BAD_ARG, "extended: segment range outside the plan");
     if (count == 1) {                                               // repet.py:271
         if (n_seg == 1) return exec_original(c, p);
-        HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
         return REPET_OK;
     }
     const int64_t O = L - Hs;
     HIP_TRY(c->periods.ensure((size_t)std::max<int64_t>(n_seg, 1) * sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
     const int64_t last = count - 1;
     const int64_t uniform = std::min(first + n_seg, last) - first;  // equal-length segments in the range
     if (uniform > 0)
@@ -535,28 +539,56 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int64_t T = repet_frame_count(N, W, H, 0);
     const Geo g = make_geo(W, H, T, c->n_channels);
     if (p->sim_number < 1) return fail(REPET_ERR_BAD_ARG, "similarity_number must be >= 1");
-    RP_TRY(ensure_spectra(c, g, true, false));
-    RP_TRY(run_stft(c, g, tb, 0, N, 0, true, false));
+    // nb equal-shape clips (repet_ctx_upload_batch) go through every stage together: one launch per stage
+    const int nb = c->clip_base == 0 ? c->n_clips : 1;
+    RP_TRY(ensure_spectra(c, g, true, false, nb));
+    RP_TRY(run_stft(c, g, tb, 0, N, 0, true, false, nb, N));
     const int LP = (int)round_up(B, 64);
-    HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
-    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP));
-    mark(c, "similarity_band", 4.0 * g.F * T + 4.0 * T * B, 2.0 * g.F * (double)T * B);
+    const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP, spec_stride = (int64_t)g.C * g.chan_stride;
+    HIP_TRY(c->band.ensure((size_t)nb * band_stride * sizeof(float)));
+    if (nb == 1) {
+        RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP));
+    } else {
+        const int2* tiles; int n_tiles;
+        RP_TRY(get_tiles(c, T, gram_band_diagonals(B), &tiles, &n_tiles));
+        HIP_TRY(launch_gram_band(c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, tiles, n_tiles, nb, mean_stride,
+                                 band_stride, c->stream));
+    }
+    mark(c, "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;
-    HIP_TRY(c->idx.ensure((size_t)std::max<int64_t>(rows, 1) * KP * sizeof(int32_t)));
-    HIP_TRY(c->cnt.ensure((size_t)std::max<int64_t>(rows, 1) * sizeof(int32_t)));
+    const int64_t rows_alloc = std::max<int64_t>(rows, 1);
+    HIP_TRY(c->idx.ensure((size_t)nb * rows_alloc * KP * sizeof(int32_t)));
+    HIP_TRY(c->cnt.ensure((size_t)nb * rows_alloc * sizeof(int32_t)));
     PeakRefine rf{};
     RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_distance_frames, p->sim_threshold, &rf));
+    const PeakBatch pb{nb, band_stride, rows_alloc * KP, rows_alloc, mean_stride};
     hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
-                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf);
+                                       p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf,
+                                       nb > 1 ? &pb : nullptr);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
     HIP_TRY(e);
-    mark(c, "local_maxima", 4.0 * rows * B + 4.0 * K * rows, 0);
+    mark(c, "local_maxima", nb * (4.0 * rows * B + 4.0 * K * rows), 0);
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
-    HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream, c->side_stream,
+    MaskArgs m = mask_args(c, g, p->cutoff_bins);
+    m.n_batch = nb; m.batch_stride = spec_stride; m.idx_batch_stride = rows_alloc * KP; m.cnt_batch_stride = rows_alloc;
+    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream, c->side_stream,
                             c->fork_event, c->join_event));
-    mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
-    RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
+    mark(c, "mask_sim", nb * (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
+    if (nb == 1) {
+        RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
+    } else {
+        IstftOlaArgs a{};
+        a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+        a.twiddle = tb->twiddle.as<float2>(); a.trim = 0; a.out = c->out.as<float>(); a.n_out = N;
+        a.out_offset = 0; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 0;
+        a.n_batch = nb; a.batch_first = 0; a.batch_step = 1; a.batch_total = nb; a.batch_local0 = 0;
+        a.batch_spec_stride = spec_stride; a.batch_out_stride = N; a.overlap = 0;
+        hipError_t e2 = launch_istft_ola(a, c->stream);
+        if (e2 == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
+        HIP_TRY(e2);
+        mark(c, "istft_ola", nb * (8.0 * g.F * g.T * g.C + 4.0 * N * g.C), 0);
+    }
     c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = KP; c->last_idx_number = K;
     return REPET_OK;
 }
@@ -650,13 +682,14 @@ int repet_ctx_destroy(repet_ctx* c) {
     return REPET_OK;
 }
 
-int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int32_t ch) {
+int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n, int32_t ch, int32_t n_clips) {
     if (!c || !audio) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (n < 0 || ch < 1) return fail(REPET_ERR_BAD_ARG, "audio_signal must be (number_samples, number_channels)");
+    if (n_clips < 1) return fail(REPET_ERR_BAD_ARG, "n_clips must be >= 1");
     if (dtype < REPET_F32 || dtype > REPET_I16) return fail(REPET_ERR_BAD_ARG, "unsupported dtype");
     DeviceGuard guard(c->device);
     const size_t esz = dtype == REPET_F64 ? 8 : (dtype == REPET_F32 ? 4 : 2);
-    const int64_t count = n * ch;
+    const int64_t count = n * ch * n_clips;
     HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
     HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
     if (dtype == REPET_F32) {
@@ -669,8 +702,45 @@ int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int3
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_samples = n;
     c->n_channels = ch;
+    c->n_clips = n_clips;
+    c->clip_base = 0;
     return REPET_OK;
 }
+
+int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int32_t ch) {
+    return repet_ctx_upload_batch(c, audio, dtype, n, ch, 1);
+}
+
+namespace {
+int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
+    switch (algo) {
+        case REPET_ORIGINAL: return exec_original(c, p);
+        case REPET_EXTENDED: return exec_extended(c, p);
+        case REPET_ADAPTIVE: return exec_adaptive(c, p);
+        case REPET_SIM: return exec_sim(c, p);
+        case REPET_SIMONLINE: return exec_simonline(c, p);
+        default: return fail(REPET_ERR_BAD_ARG, "unknown algorithm");
+    }
+}
+
+// A batch context (n_clips > 1): simonline runs every stage once over all clips; the other variants work through
+// the resident clips one after the other (their intermediates -- periods, index lists -- are those of the last).
+int run_algo(repet_ctx* c, int algo, const repet_params* p) {
+    c->clip_base = 0;
+    if (c->n_clips <= 1 || algo == REPET_SIMONLINE) return run_algo_one(c, algo, p);
+    repet_timing* timing = c->timing;
+    c->timing = nullptr;                       // per-stage marks would repeat per clip: only the total is reported
+    int rc = REPET_OK;
+    for (int b = 0; b < c->n_clips && rc == REPET_OK; ++b) {
+        c->clip_base = (int64_t)b * c->n_samples;
+        rc = run_algo_one(c, algo, p);
+    }
+    c->clip_base = 0;
+    c->timing = timing;
+    if (rc == REPET_OK) mark(c, "clips", 0, 0);
+    return rc;
+}
+}  // namespace
 
 int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timing* timing) {
     if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
@@ -681,15 +751,7 @@ int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timin
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
-    int rc;
-    switch (algo) {
-        case REPET_ORIGINAL: rc = exec_original(c, p); break;
-        case REPET_EXTENDED: rc = exec_extended(c, p); break;
-        case REPET_ADAPTIVE: rc = exec_adaptive(c, p); break;
-        case REPET_SIM: rc = exec_sim(c, p); break;
-        case REPET_SIMONLINE: rc = exec_simonline(c, p); break;
-        default: rc = fail(REPET_ERR_BAD_ARG, "unknown algorithm");
-    }
+    int rc = run_algo(c, algo, p);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
     if (rc == REPET_OK) end_timing(c);
@@ -706,14 +768,7 @@ int repet_ctx_execute_async(repet_ctx* c, int algo, const repet_params* p) {
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
-    switch (algo) {
-        case REPET_ORIGINAL: return exec_original(c, p);
-        case REPET_EXTENDED: return exec_extended(c, p);
-        case REPET_ADAPTIVE: return exec_adaptive(c, p);
-        case REPET_SIM: return exec_sim(c, p);
-        case REPET_SIMONLINE: return exec_simonline(c, p);
-        default: return fail(REPET_ERR_BAD_ARG, "unknown algorithm");
-    }
+    return run_algo(c, algo, p);
 }
 
 int repet_ctx_synchronize(repet_ctx* c) {
@@ -749,7 +804,7 @@ int repet_ctx_execute_extended_range(repet_ctx* c, const repet_params* p, int64_
 int repet_ctx_download(repet_ctx* c, double* out) {
     if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
     DeviceGuard guard(c->device);
-    const int64_t count = c->n_samples * c->n_channels;
+    const int64_t count = c->n_samples * c->n_channels * c->n_clips;
     if (count == 0) return REPET_OK;
     HIP_TRY(c->out64.ensure((size_t)count * sizeof(double)));
     HIP_TRY(launch_convert_out(c->out.as<float>(), c->out64.as<double>(), count, c->stream));
@@ -762,7 +817,7 @@ int repet_ctx_download_foreground(repet_ctx* c, double* out) {
     if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (c->last_algo < 0) return fail(REPET_ERR_BAD_ARG, "no separation has been run on this context");
     DeviceGuard guard(c->device);
-    const int64_t count = c->n_samples * c->n_channels;
+    const int64_t count = c->n_samples * c->n_channels * c->n_clips;
     if (count == 0) return REPET_OK;
     HIP_TRY(c->out64.ensure((size_t)count * sizeof(double)));
     HIP_TRY(launch_foreground(c->audio.as<float>(), c->out.as<float>(), c->out64.as<double>(), count, c->stream));

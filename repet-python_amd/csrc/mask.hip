@@ -136,6 +136,11 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
                                                        const int* __restrict__ count, int64_t first_frame) {
     const int64_t t = a.frame0 + blockIdx.x;
     const int c = blockIdx.y;
+    a.V += blockIdx.z * a.batch_stride;              // clip of a batch (n_batch == 1: blockIdx.z == 0)
+    if (a.X) a.X += blockIdx.z * a.batch_stride;
+    if (a.mask) a.mask += blockIdx.z * a.batch_stride;
+    idx += blockIdx.z * a.idx_batch_stride;
+    count += blockIdx.z * a.cnt_batch_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nbins = SPLIT ? a.F - 1 : a.F;
     const int nfb = (nbins + 63) >> 6;
@@ -169,6 +174,11 @@ template <int NET>
 __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                               const int* __restrict__ count, int64_t first_frame) {
     const int c = blockIdx.y;
+    a.V += blockIdx.z * a.batch_stride;
+    if (a.X) a.X += blockIdx.z * a.batch_stride;
+    if (a.mask) a.mask += blockIdx.z * a.batch_stride;
+    idx += blockIdx.z * a.idx_batch_stride;
+    count += blockIdx.z * a.cnt_batch_stride;
     const int64_t r0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t n_rows = a.T - first_frame;       // first_frame >= frame0: rows before it are warm-up frames
     const bool active = r0 < n_rows;
@@ -196,21 +206,22 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
     const bool split = m.F > 64 && ((m.F - 1) & 63) == 0;
     const int64_t rows = m.T - first_frame;
     const unsigned n_launch = (unsigned)(t_end - m.frame0);   // frames [frame0, t_end) are processed
+    const unsigned nb = (unsigned)(m.n_batch > 1 ? m.n_batch : 1);
     dispatch_net(max_count, [&](auto net) {
         constexpr int NET = decltype(net)::value;
         if (split) {
             if (rows > 0 && (parts & 2)) {
                 if (forked) { (void)hipEventRecord(fork, s); (void)hipStreamWaitEvent(side, fork, 0); }
-                hipLaunchKernelGGL(mask_sim_nyquist_kernel<NET>, dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels),
+                hipLaunchKernelGGL(mask_sim_nyquist_kernel<NET>, dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels, nb),
                                    dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
                 if (forked) (void)hipEventRecord(join, side);
             }
             if (parts & 1)
-                hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
+                hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
                                    m, idx, idx_pitch, count, first_frame);
             if (forked && rows > 0) (void)hipStreamWaitEvent(s, join, 0);
         } else if (parts & 1) {
-            hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3(n_launch, (unsigned)m.n_channels), dim3(256), 0, s,
+            hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
                                m, idx, idx_pitch, count, first_frame);
         }
     });

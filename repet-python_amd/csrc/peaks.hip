@@ -43,6 +43,7 @@ struct PeakArgs {
     int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap; int64_t shift;
     // near-tie refinement (see below): unit rows the similarities were computed from, or null
     const float* unit; int unit_pitch; float delta; double min_value64; unsigned int* stats;
+    int64_t m_stride, idx_stride, cnt_stride, unit_stride;      // batch: blockIdx.y = clip
 };
 
 constexpr int kAmbCap = 96;    // near-tied elements refined per row; a row with more keeps its fp32 decisions
@@ -115,6 +116,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = a.n, d = a.d, dl = a.dl, groups = a.groups;
+    a.M += blockIdx.y * a.m_stride;
+    a.idx += blockIdx.y * a.idx_stride;
+    a.count += blockIdx.y * a.cnt_stride;
+    if (a.unit) a.unit += blockIdx.y * a.unit_stride;
     const int64_t r = blockIdx.x;           // row within this launch
     const int64_t j = a.row0 + r;           // absolute row (mode 1: current frame)
     if (tid == 0) { n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0; }
@@ -469,17 +474,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
 }
 
 template <int QMAX>
-static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, size_t bytes, hipStream_t s) {
+static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, int n_batch, size_t bytes, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&local_maxima_kernel<QMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((local_maxima_kernel<QMAX>), dim3((unsigned)n_rows), dim3(256), bytes, s, a);
+    hipLaunchKernelGGL((local_maxima_kernel<QMAX>), dim3((unsigned)n_rows, (unsigned)n_batch), dim3(256), bytes, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
-                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift, const PeakRefine* refine) {
+                               int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift, const PeakRefine* refine,
+                               const PeakBatch* batch) {
     if (n_rows <= 0) return hipSuccess;
     if (d > n_cols) d = n_cols;                                       // a wider window changes nothing
     PeakArgs a{};
@@ -490,18 +496,24 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
         a.unit = refine->unit_rows; a.unit_pitch = refine->pitch; a.delta = refine->delta;
         a.min_value64 = refine->min_value; a.stats = refine->stats;
     }
+    int n_batch = 1;
+    if (batch && batch->n_batch > 0) {
+        n_batch = batch->n_batch;
+        a.m_stride = batch->m_stride; a.idx_stride = batch->idx_stride; a.cnt_stride = batch->cnt_stride;
+        a.unit_stride = batch->unit_stride;
+    }
     a.dl = (int)round_up(d, 4);
     a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 3);      // slack for the aligned window reads past the end
     a.peak_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart
     const size_t bytes = (size_t)(4 * a.groups + 2 * a.peak_cap) * 4;
     const int per_thread = (int)ceil_div(a.groups, 256);
     if (bytes > 160 * 1024 - 64 || per_thread > 32) return hipErrorInvalidValue;
-    if (per_thread <= 1) return launch_one<1>(a, n_rows, bytes, s);
-    if (per_thread <= 2) return launch_one<2>(a, n_rows, bytes, s);
-    if (per_thread <= 4) return launch_one<4>(a, n_rows, bytes, s);
-    if (per_thread <= 8) return launch_one<8>(a, n_rows, bytes, s);
-    if (per_thread <= 16) return launch_one<16>(a, n_rows, bytes, s);
-    return launch_one<32>(a, n_rows, bytes, s);
+    if (per_thread <= 1) return launch_one<1>(a, n_rows, n_batch, bytes, s);
+    if (per_thread <= 2) return launch_one<2>(a, n_rows, n_batch, bytes, s);
+    if (per_thread <= 4) return launch_one<4>(a, n_rows, n_batch, bytes, s);
+    if (per_thread <= 8) return launch_one<8>(a, n_rows, n_batch, bytes, s);
+    if (per_thread <= 16) return launch_one<16>(a, n_rows, n_batch, bytes, s);
+    return launch_one<32>(a, n_rows, n_batch, bytes, s);
 }
 
 #ifdef REPET_PEAK_STAMPS

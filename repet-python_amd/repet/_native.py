@@ -47,6 +47,7 @@ _SIGNATURES = {
     "repet_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "repet_ctx_destroy": (C.c_int, [_P]),
     "repet_ctx_upload": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int32]),
+    "repet_ctx_upload_batch": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int32, C.c_int32]),
     "repet_ctx_execute": (C.c_int, [_P, C.c_int, C.POINTER(Params), C.POINTER(Timing)]),
     "repet_ctx_download": (C.c_int, [_P, _P]),
     "repet_ctx_execute_async": (C.c_int, [_P, C.c_int, C.POINTER(Params)]),
@@ -165,6 +166,18 @@ class Context:
         a, code = as_input(audio_signal)
         check(lib().repet_ctx_upload(self._h, ptr(a), code, n, c))
         self.shape = (n, c)
+
+    def upload_batch(self, audio_signals):
+        """Equal-shape clips ``(number_clips, number_samples, number_channels)`` (or a list of such clips) made
+        resident together; ``download`` then returns the same shape. ``simonline`` runs every stage once over
+        all of them."""
+        clips = np.stack([np.asarray(a) for a in audio_signals]) if not isinstance(audio_signals, np.ndarray) else audio_signals
+        if clips.ndim != 3:
+            raise ValueError("audio_signals must be (number_clips, number_samples, number_channels)")
+        b, n, c = clips.shape
+        a, code = as_input(clips.reshape(b * n, c))
+        check(lib().repet_ctx_upload_batch(self._h, ptr(a), code, n, c, b))
+        self.shape = (b, n, c)
 
     def execute(self, algo, params, timing=False):
         t = Timing() if timing else None

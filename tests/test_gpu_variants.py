@@ -194,6 +194,34 @@ def test_extended_with_other_overlaps(seg_len, seg_step, fs, channels, seconds, 
     assert rms_err(total, want) <= 2e-5
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+def test_resident_batch_of_clips(algo):
+    """repet_ctx_upload_batch: equal-shape clips resident together. simonline runs every stage once over all of
+    them (BASELINE.json configs[4] is 64 such clips); the other variants loop over the resident clips. Either way
+    clip k of the result is bit-identical to a single-clip run."""
+    fs, channels = 16000, 2
+    clips = np.stack([synth(13.0, fs, channels, 300 + k) for k in range(5)])
+    p = repet.derive_params(fs)
+    single = []
+    ctx = repet.Context(0)
+    for clip in clips:
+        ctx.upload(clip)
+        ctx.execute(algo, p)
+        single.append(ctx.download())
+    ctx.upload_batch(clips)
+    ctx.execute(algo, p)
+    got = ctx.download()
+    assert got.shape == clips.shape
+    for k in range(len(clips)):
+        assert np.array_equal(got[k], single[k]), k
+    fg = ctx.foreground()
+    assert np.allclose(fg, clips - got, atol=1e-6)
+    ctx.upload(clips[0])                       # back to a single clip on the same context
+    ctx.execute(algo, p)
+    assert np.array_equal(ctx.download(), single[0])
+    ctx.close()
+
+
 def test_batch_api_matches_single_calls():
     fs = 8000
     clips = [synth(d, fs, 2, s) for d, s in [(4, 1), (7, 2), (5, 3)]]
