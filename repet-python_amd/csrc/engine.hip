@@ -76,6 +76,7 @@ struct repet_ctx {
     int64_t n_samples = 0;        // per clip
     int32_t n_clips = 1;          // equal-shape clips back to back in `audio` / `out` (repet_ctx_upload_batch)
     int64_t clip_base = 0;        // first sample of the clip the single-clip pipelines currently work on
+    bool clip_loop = false;       // true while run_algo works through the clips one by one
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
@@ -313,8 +314,20 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     m.n_batch = B;
     HIP_TRY(launch_mask_period(m, period_slots, 0, p->period_lo + 1, c->stream));
     mark(c, "mask_period", B * (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
-    if (!weighted) {
+    if (!weighted && B == 1) {
         RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, false, 0, 0));
+    } else if (!weighted) {
+        // independent clips of a batch context: clip b is written at offset + b*hop, no cross-fade
+        IstftOlaArgs a{};
+        a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+        a.twiddle = tb->twiddle.as<float2>(); a.trim = g.W - g.H; a.out = c->out.as<float>(); a.n_out = n;
+        a.out_offset = c->clip_base + offset; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 0;
+        a.n_batch = B; a.batch_first = 0; a.batch_step = 1; a.batch_total = B; a.batch_local0 = 0;
+        a.batch_spec_stride = (int64_t)g.C * g.chan_stride; a.batch_out_stride = hop; a.overlap = 0;
+        hipError_t e = launch_istft_ola(a, c->stream);
+        if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
+        HIP_TRY(e);
+        mark(c, "istft_ola", B * (8.0 * g.F * g.T * g.C + 4.0 * n * g.C), 0);
     } else {
         // segments that overlap in the output must not be accumulated concurrently: one launch per residue
         // class modulo ceil(n / hop) (2 for the default 10 s / 5 s), each class writes disjoint samples
@@ -339,9 +352,11 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
 }
 
 int exec_original(repet_ctx* c, const repet_params* p) {
-    HIP_TRY(c->periods.ensure(sizeof(int32_t)));
-    RP_TRY(run_original(c, p, 0, c->n_samples, 1, 0, c->periods.as<int32_t>(), false, 0, 1, 0));
-    c->last_n_periods = 1;
+    // a batch context at its base runs all clips together (one launch per stage); otherwise the current clip
+    const int nb = c->clip_loop ? 1 : c->n_clips;
+    HIP_TRY(c->periods.ensure((size_t)nb * sizeof(int32_t)));
+    RP_TRY(run_original(c, p, 0, c->n_samples, nb, nb > 1 ? c->n_samples : 0, c->periods.as<int32_t>(), false, 0, 1, 0));
+    c->last_n_periods = nb;
     return REPET_OK;
 }
 
@@ -540,7 +555,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const Geo g = make_geo(W, H, T, c->n_channels);
     if (p->sim_number < 1) return fail(REPET_ERR_BAD_ARG, "similarity_number must be >= 1");
     // nb equal-shape clips (repet_ctx_upload_batch) go through every stage together: one launch per stage
-    const int nb = c->clip_base == 0 ? c->n_clips : 1;
+    const int nb = c->clip_loop ? 1 : c->n_clips;
     RP_TRY(ensure_spectra(c, g, true, false, nb));
     RP_TRY(run_stft(c, g, tb, 0, N, 0, true, false, nb, N));
     const int LP = (int)round_up(B, 64);
@@ -723,18 +738,20 @@ int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
     }
 }
 
-// A batch context (n_clips > 1): simonline runs every stage once over all clips; the other variants work through
+// A batch context (n_clips > 1): simonline and original run every stage once over all clips; the others work through
 // the resident clips one after the other (their intermediates -- periods, index lists -- are those of the last).
 int run_algo(repet_ctx* c, int algo, const repet_params* p) {
     c->clip_base = 0;
-    if (c->n_clips <= 1 || algo == REPET_SIMONLINE) return run_algo_one(c, algo, p);
+    if (c->n_clips <= 1 || algo == REPET_SIMONLINE || algo == REPET_ORIGINAL) return run_algo_one(c, algo, p);
     repet_timing* timing = c->timing;
     c->timing = nullptr;                       // per-stage marks would repeat per clip: only the total is reported
     int rc = REPET_OK;
+    c->clip_loop = true;
     for (int b = 0; b < c->n_clips && rc == REPET_OK; ++b) {
         c->clip_base = (int64_t)b * c->n_samples;
         rc = run_algo_one(c, algo, p);
     }
+    c->clip_loop = false;
     c->clip_base = 0;
     c->timing = timing;
     if (rc == REPET_OK) mark(c, "clips", 0, 0);
@@ -789,6 +806,7 @@ int repet_ctx_execute_extended_range(repet_ctx* c, const repet_params* p, int64_
     RP_TRY(check_params(p));
     if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
     if (n_seg < 0) return fail(REPET_ERR_BAD_ARG, "negative segment count");
+    if (c->n_clips > 1) return fail(REPET_ERR_BAD_ARG, "segment ranges apply to a single resident clip, not to a batch context");
     DeviceGuard guard(c->device);
     begin_timing(c, timing);
     c->last_algo = REPET_EXTENDED;

@@ -216,6 +216,10 @@ def test_resident_batch_of_clips(algo):
         assert np.array_equal(got[k], single[k]), k
     fg = ctx.foreground()
     assert np.allclose(fg, clips - got, atol=1e-6)
+    if algo == "original":
+        assert len(ctx.last_periods(16)) == len(clips)          # one period per clip, all stages batched
+    with pytest.raises(ValueError):
+        ctx.execute_extended_range(p, 0, 1)                     # segment ranges are a single-clip notion
     ctx.upload(clips[0])                       # back to a single clip on the same context
     ctx.execute(algo, p)
     assert np.array_equal(ctx.download(), single[0])
