@@ -66,6 +66,24 @@ typedef struct repet_params {
     double sim_threshold;        /* similarity_threshold                            repet.py:58  */
 } repet_params;
 
+/* The nine module-level parameters of the reference (repet.py:42-63), for hosts that do not keep them as Python
+ * globals, and the derivation of repet_params from them exactly as the reference's public functions do it
+ * (Python round / np.round are half-to-even; so is this). repet_default_settings writes the reference's defaults:
+ * 100 Hz, [1, 10] s, 10 s / 5 s segments, order 5, threshold 0, distance 1 s, 100 frames, 10-s buffer. */
+typedef struct repet_settings {
+    double cutoff_frequency;      /* Hz  */
+    double period_range[2];       /* s   */
+    double segment_length;        /* s   */
+    double segment_step;          /* s   */
+    double similarity_threshold;  /* [0, 1] */
+    double similarity_distance;   /* s   */
+    double buffer_length;         /* s   */
+    int32_t filter_order;
+    int32_t similarity_number;
+} repet_settings;
+void repet_default_settings(repet_settings* s);
+int repet_derive_params(const repet_settings* s /* NULL: the defaults */, double sampling_frequency, repet_params* out);
+
 /* Per-stage device time of the last repet_ctx_execute, from HIP events on the context's stream. */
 #define REPET_MAX_STAGES 16
 typedef struct repet_timing {

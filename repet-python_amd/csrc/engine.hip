@@ -697,6 +697,42 @@ int repet_ctx_destroy(repet_ctx* c) {
     return REPET_OK;
 }
 
+void repet_default_settings(repet_settings* s) {
+    if (!s) return;
+    s->cutoff_frequency = 100.0; s->period_range[0] = 1.0; s->period_range[1] = 10.0;       // repet.py:42-46
+    s->segment_length = 10.0; s->segment_step = 5.0; s->filter_order = 5;                   // repet.py:50-54
+    s->similarity_threshold = 0.0; s->similarity_distance = 1.0; s->similarity_number = 100; // repet.py:57-60
+    s->buffer_length = 10.0;                                                                // repet.py:63
+}
+
+int repet_derive_params(const repet_settings* settings, double fs, repet_params* out) {
+    if (!out) return fail(REPET_ERR_BAD_ARG, "params is null");
+    if (!(fs > 0.0)) return fail(REPET_ERR_BAD_ARG, "sampling frequency must be positive");
+    repet_settings d;
+    repet_default_settings(&d);
+    const repet_settings& s = settings ? *settings : d;
+    // nearbyint under the default rounding mode is round-half-to-even, like Python's round() and np.round()
+    auto rnd = [](double x) { return (int64_t)std::nearbyint(x); };
+    std::memset(out, 0, sizeof(*out));
+    const int w = (int)std::ldexp(1.0, (int)std::ceil(std::log2(0.04 * fs)));               // repet.py:130
+    const int h = w / 2;                                                                     // repet.py:132
+    out->window_length = w;
+    out->step_length = h;
+    out->period_lo = (int32_t)rnd(s.period_range[0] * fs / h);                               // repet.py:165
+    out->period_hi = (int32_t)rnd(s.period_range[1] * fs / h);
+    out->cutoff_bins = (int32_t)rnd(s.cutoff_frequency * w / fs);                            // repet.py:173
+    out->filter_order = s.filter_order;
+    out->seg_len_frames = (int32_t)rnd(s.segment_length * fs / h);                           // repet.py:519
+    out->seg_step_frames = (int32_t)rnd(s.segment_step * fs / h);                            // repet.py:520
+    out->sim_distance_frames = (int32_t)rnd(s.similarity_distance * fs / h);                 // repet.py:670
+    out->sim_number = s.similarity_number;
+    out->buffer_frames = (int32_t)rnd((s.buffer_length * fs) / h);                           // repet.py:787
+    out->seg_len_samples = rnd(s.segment_length * fs);                                       // repet.py:266
+    out->seg_step_samples = rnd(s.segment_step * fs);                                        // repet.py:267
+    out->sim_threshold = s.similarity_threshold;
+    return REPET_OK;
+}
+
 int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n, int32_t ch, int32_t n_clips) {
     if (!c || !audio) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (n < 0 || ch < 1) return fail(REPET_ERR_BAD_ARG, "audio_signal must be (number_samples, number_channels)");

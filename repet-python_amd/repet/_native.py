@@ -26,6 +26,13 @@ class Params(C.Structure):
                 ("sim_threshold", C.c_double)]
 
 
+class Settings(C.Structure):
+    """repet_settings of include/repet_hip.h: the nine module-level parameters of the reference."""
+    _fields_ = [("cutoff_frequency", C.c_double), ("period_range", C.c_double * 2), ("segment_length", C.c_double),
+                ("segment_step", C.c_double), ("similarity_threshold", C.c_double), ("similarity_distance", C.c_double),
+                ("buffer_length", C.c_double), ("filter_order", C.c_int32), ("similarity_number", C.c_int32)]
+
+
 class Timing(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("reserved0", C.c_int32), ("total_ms", C.c_float),
                 ("stage_ms", C.c_float * MAX_STAGES), ("stage_name", (C.c_char * 24) * MAX_STAGES),
@@ -44,6 +51,8 @@ _SIGNATURES = {
     "repet_abi_version": (C.c_int, []),
     "repet_device_count": (C.c_int, []),
     "repet_last_error": (C.c_char_p, []),
+    "repet_default_settings": (None, [C.POINTER(Settings)]),
+    "repet_derive_params": (C.c_int, [C.POINTER(Settings), C.c_double, C.POINTER(Params)]),
     "repet_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "repet_ctx_destroy": (C.c_int, [_P]),
     "repet_ctx_upload": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int32]),

@@ -37,15 +37,16 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "repet_hip.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(repet_params), sizeof(repet_timing),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(repet_params), sizeof(repet_timing),'
                    'offsetof(repet_params, seg_len_samples), offsetof(repet_params, sim_threshold),'
-                   'offsetof(repet_timing, stage_bytes));return 0;}\n')
+                   'offsetof(repet_timing, stage_bytes), sizeof(repet_settings), offsetof(repet_settings, filter_order));return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [ctypes.sizeof(_native.Params), ctypes.sizeof(_native.Timing),
                      _native.Params.seg_len_samples.offset, _native.Params.sim_threshold.offset,
-                     _native.Timing.stage_bytes.offset]
+                     _native.Timing.stage_bytes.offset, ctypes.sizeof(_native.Settings),
+                     _native.Settings.filter_order.offset]
 
 
 @pytest.mark.parametrize("fs,expect", [
@@ -67,6 +68,48 @@ def test_derived_sizes(fs, expect):
     assert (p.window_length, p.step_length) == (w, h)
     assert [p.period_lo, p.period_hi] == list(orc.period_range_frames(op, fs, h))
     assert p.cutoff_bins == orc.cutoff_bins(op, fs, w)
+
+
+def test_c_side_derivation_matches_python(monkeypatch):
+    """repet_derive_params (for hosts without Python globals) against derive_params, half-to-even cases included."""
+    lib = _native.lib()
+    d = _native.Settings()
+    lib.repet_default_settings(ctypes.byref(d))
+    assert (d.cutoff_frequency, list(d.period_range), d.segment_length, d.segment_step) == (100, [1, 10], 10, 5)
+    assert (d.filter_order, d.similarity_threshold, d.similarity_distance, d.similarity_number, d.buffer_length) == (5, 0, 1, 100, 10)
+    rs = np.random.RandomState(5)
+    rates = [4000, 8000, 11025, 16000, 22050, 32000, 44100, 48000, 51200, 88200, 96000, 12345, 6400.5]
+    for trial in range(60):
+        fs = rates[trial % len(rates)]
+        s = _native.Settings()
+        lib.repet_default_settings(ctypes.byref(s))
+        if trial >= len(rates):                     # random settings; x.5 products exercise the rounding rule
+            s.cutoff_frequency = float(rs.choice([0, 62.5, 100, 250.5, 1000]))
+            s.period_range[0], s.period_range[1] = float(rs.choice([0.5, 1, 1.5])), float(rs.choice([3, 7.25, 10]))
+            s.segment_length, s.segment_step = float(rs.choice([5, 8, 10, 12.5])), float(rs.choice([1.25, 2.5, 5]))
+            s.filter_order, s.similarity_number = int(rs.randint(1, 12)), int(rs.randint(1, 300))
+            s.similarity_threshold, s.similarity_distance = float(rs.rand()), float(rs.choice([0, 0.5, 1, 2.5]))
+            s.buffer_length = float(rs.choice([2, 5, 10, 12.5]))
+        for name in ("cutoff_frequency", "segment_length", "segment_step", "filter_order", "similarity_threshold",
+                     "similarity_distance", "similarity_number", "buffer_length"):
+            monkeypatch.setattr(repet, name, getattr(s, name))
+        monkeypatch.setattr(repet, "period_range", list(s.period_range))
+        want = repet.derive_params(fs)
+        got = _native.Params()
+        assert lib.repet_derive_params(ctypes.byref(s), fs, ctypes.byref(got)) == 0
+        for field, _ in _native.Params._fields_:
+            assert getattr(got, field) == getattr(want, field), (fs, field)
+    got = _native.Params()
+    assert lib.repet_derive_params(None, 8000.0, ctypes.byref(got)) == 0 and got.buffer_frames == 312   # round(312.5)
+    assert lib.repet_derive_params(None, 0.0, ctypes.byref(got)) == -1
+
+
+def test_c_client_example_compiles_against_the_header(tmp_path):
+    exe = tmp_path / "c_client"
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    subprocess.check_call(["gcc", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_client.c"),
+                           "-o", str(exe), "-L", lib_dir, "-lrepet_hip", f"-Wl,-rpath,{lib_dir}"])
+    assert exe.exists()
 
 
 def test_parameters_are_read_at_call_time():

@@ -226,6 +226,25 @@ def test_resident_batch_of_clips(algo):
     ctx.close()
 
 
+@pytest.mark.parametrize("algo", ["original", "sim"])
+def test_c_client_matches_the_python_drop_in(algo, tmp_path):
+    """examples/c_client.c -- a host with no Python in it -- through the same C ABI gives the same samples."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    exe = tmp_path / "c_client"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_client.c"), "-o", str(exe),
+                           "-L", lib_dir, "-lrepet_hip", f"-Wl,-rpath,{lib_dir}"])
+    fs = 22050
+    x = synth(12.0, fs, 2, 91)
+    (tmp_path / "in.f64").write_bytes(np.ascontiguousarray(x).tobytes())
+    out = subprocess.check_output([str(exe), str(_native.ALGO_IDS[algo]), str(fs), "2", str(tmp_path / "in.f64"), str(tmp_path / "out.f64")])
+    assert b"separated 264600 samples x 2 channels" in out
+    got = np.frombuffer((tmp_path / "out.f64").read_bytes(), dtype=np.float64).reshape(x.shape)
+    assert np.array_equal(got, getattr(repet, algo)(x, fs))
+
+
 def test_batch_api_matches_single_calls():
     fs = 8000
     clips = [synth(d, fs, 2, s) for d, s in [(4, 1), (7, 2), (5, 3)]]
