@@ -16,6 +16,12 @@
 // 4 LDS reads per element and there is no data-dependent loop.
 // Survivors are compacted with one LDS atomic per wave and ranked by counting (value descending,
 // higher index first on exact ties) so the top `number` land in idx[row][0..count) already sorted.
+//
+// Near-tie refinement (PeakRefine): the rows are fp32 similarities whose rounding error (~1e-6) is larger than
+// the margins repeating music produces, so a decision within `delta` of a tie -- against the window maximum,
+// the threshold or the top-`number` cut -- is not taken from the fp32 value. The few elements involved are
+// recomputed as float64 dot products of the fp32 unit rows (one wavefront per pair of elements) and decided
+// from those; the index lists then equal the float64 reference's (tools/refine_probe.py).
 #include "common.h"
 
 #include <type_traits>
