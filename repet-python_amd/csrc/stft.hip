@@ -163,7 +163,294 @@ __device__ __forceinline__ float2* fft_lds_regs(float2* a, float2* b, const FftT
     return a;
 }
 
+// Same Stockham FFT with the stage twiddles read from an LDS copy of the root table tw[m] = exp(-2 pi i m / TW),
+// m <= 3 TW / 4 (TW a multiple of 4N): no twiddle registers, no per-workgroup gather of 15 scattered loads. A
+// stage reads 3 more float2 per butterfly from LDS; early stages hit a handful of addresses (broadcast).
+template <int N, bool INVERSE>
+__device__ __forceinline__ float2* fft_lds_tab(float2* a, float2* b, const float2* tw, int TW) {
+    using P = FftPlan<N>;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < P::kRadix4Stages; ++s) {
+        const int p = 1 << (2 * s);
+        const int tstep = TW / (p * 4);
+#pragma unroll
+        for (int q = 0; q < P::kBpt4; ++q) {
+            const int i = tid + kFftThreads * q;
+            if (i < N / 4) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 2) + k;
+                float2 u0 = a[i], u1 = a[i + N / 4], u2 = a[i + N / 2], u3 = a[i + 3 * N / 4];
+                if (s > 0) {
+                    float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                    if (INVERSE) { w1 = cconj(w1); w2 = cconj(w2); w3 = cconj(w3); }
+                    u1 = cmul(u1, w1); u2 = cmul(u2, w2); u3 = cmul(u3, w3);
+                }
+                const float2 t0 = cadd(u0, u2), t1 = csub(u0, u2), t2 = cadd(u1, u3);
+                const float2 d = csub(u1, u3);
+                const float2 t3 = INVERSE ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                b[j] = cadd(t0, t2);
+                b[j + p] = cadd(t1, t3);
+                b[j + 2 * p] = csub(t0, t2);
+                b[j + 3 * p] = csub(t1, t3);
+            }
+        }
+        __syncthreads();
+        float2* tmp = a; a = b; b = tmp;
+    }
+    if (P::kFinalRadix2) {
+        const int p = N / 2;
+        const int tstep = TW / (p * 2);
+#pragma unroll
+        for (int q = 0; q < P::kBpt2; ++q) {
+            const int i = tid + kFftThreads * q;
+            if (i < N / 2) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 1) + k;
+                float2 w1 = tw[k * tstep];
+                if (INVERSE) w1 = cconj(w1);
+                const float2 u0 = a[i];
+                const float2 u1 = cmul(a[i + N / 2], w1);
+                b[j] = cadd(u0, u1);
+                b[j + p] = csub(u0, u1);
+            }
+        }
+        __syncthreads();
+        float2* tmp = a; a = b; b = tmp;
+    }
+    return a;
+}
+
 constexpr int kStftFrameRun = 4;     // frames per workgroup: the register tables are loaded once per run
+
+// Two transforms at once by the same 256 threads (the two channels of a stereo frame): every stage does the
+// butterflies of both before the ONE barrier they share and reads its twiddles once, so each thread has two
+// independent LDS -> math -> LDS chains in flight. a0/b0 and a1/b1 are the ping-pong pairs; tw as in fft_lds_tab.
+template <int N, bool INVERSE>
+__device__ __forceinline__ void fft_lds_tab2(float2*& a0, float2*& b0, float2*& a1, float2*& b1, const float2* tw, int TW) {
+    using P = FftPlan<N>;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < P::kRadix4Stages; ++s) {
+        const int p = 1 << (2 * s);
+        const int tstep = TW / (p * 4);
+#pragma unroll
+        for (int q = 0; q < P::kBpt4; ++q) {
+            const int i = tid + kFftThreads * q;
+            if (i < N / 4) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 2) + k;
+                float2 u0 = a0[i], u1 = a0[i + N / 4], u2 = a0[i + N / 2], u3 = a0[i + 3 * N / 4];
+                float2 v0 = a1[i], v1 = a1[i + N / 4], v2 = a1[i + N / 2], v3 = a1[i + 3 * N / 4];
+                if (s > 0) {
+                    float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                    if (INVERSE) { w1 = cconj(w1); w2 = cconj(w2); w3 = cconj(w3); }
+                    u1 = cmul(u1, w1); u2 = cmul(u2, w2); u3 = cmul(u3, w3);
+                    v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+                }
+                {
+                    const float2 t0 = cadd(u0, u2), t1 = csub(u0, u2), t2 = cadd(u1, u3), d = csub(u1, u3);
+                    const float2 t3 = INVERSE ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                    b0[j] = cadd(t0, t2); b0[j + p] = cadd(t1, t3); b0[j + 2 * p] = csub(t0, t2); b0[j + 3 * p] = csub(t1, t3);
+                }
+                {
+                    const float2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), d = csub(v1, v3);
+                    const float2 t3 = INVERSE ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                    b1[j] = cadd(t0, t2); b1[j + p] = cadd(t1, t3); b1[j + 2 * p] = csub(t0, t2); b1[j + 3 * p] = csub(t1, t3);
+                }
+            }
+        }
+        __syncthreads();
+        float2* tmp = a0; a0 = b0; b0 = tmp;
+        tmp = a1; a1 = b1; b1 = tmp;
+    }
+    if (P::kFinalRadix2) {
+        const int p = N / 2;
+        const int tstep = TW / (p * 2);
+#pragma unroll
+        for (int q = 0; q < P::kBpt2; ++q) {
+            const int i = tid + kFftThreads * q;
+            if (i < N / 2) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 1) + k;
+                float2 w1 = tw[k * tstep];
+                if (INVERSE) w1 = cconj(w1);
+                const float2 u0 = a0[i], u1 = cmul(a0[i + N / 2], w1);
+                const float2 v0 = a1[i], v1 = cmul(a1[i + N / 2], w1);
+                b0[j] = cadd(u0, u1); b0[j + p] = csub(u0, u1);
+                b1[j] = cadd(v0, v1); b1[j + p] = csub(v0, v1);
+            }
+        }
+        __syncthreads();
+        float2* tmp = a0; a0 = b0; b0 = tmp;
+        tmp = a1; a1 = b1; b1 = tmp;
+    }
+}
+
+// STFT of channel PAIRS (n_channels even, W <= 2048): same outputs as stft_kernel. The two channels of a frame are
+// transformed together (fft_lds_tab2), their interleaved samples arrive as one float2 per sample and are fetched
+// one frame ahead; window and twiddles live in LDS (see stft_kernel for why).
+template <int W>
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void stft_pair_kernel(StftArgs a) {
+    constexpr int N = W / 2;
+    constexpr int SLOTS = N / kFftThreads + 1;
+    constexpr int LOADS = (N + kFftThreads - 1) / kFftThreads;
+    constexpr int kTwLoads = (3 * W / 4 + 1 + kFftThreads - 1) / kFftThreads;
+    __shared__ float2 bufs[4][N];
+    __shared__ float2 win_lds[N];
+    __shared__ float2 tw_lds[3 * W / 4 + 1];
+    __shared__ float red[kFftThreads / kWave];
+
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int C = a.n_channels;
+    a.sample_offset += b * a.batch_sample_stride;
+    a.X += b * a.batch_spec_stride;
+    a.V += b * a.batch_spec_stride;
+    if (a.Vm) a.Vm += b * a.batch_mean_stride;
+    if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.P) a.P += b * a.batch_mean_stride;
+    {
+        float2 wreg[LOADS], treg[kTwLoads];
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int n = tid + kFftThreads * i;
+            wreg[i] = *reinterpret_cast<const float2*>(a.window + 2 * (n < N ? n : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < kTwLoads; ++i) {
+            const int m = tid + kFftThreads * i;
+            treg[i] = a.twiddle[m <= 3 * W / 4 ? m : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int n = tid + kFftThreads * i;
+            if (n < N) win_lds[n] = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kTwLoads; ++i) {
+            const int m = tid + kFftThreads * i;
+            if (m <= 3 * W / 4) tw_lds[m] = treg[i];
+        }
+    }
+    const int64_t t_begin = (int64_t)blockIdx.x * kStftFrameRun;
+    const int64_t t_end = (t_begin + kStftFrameRun < a.T) ? t_begin + kStftFrameRun : a.T;
+
+    float2 raw0[LOADS], raw1[LOADS];               // (channel c, channel c+1) of samples 2n and 2n+1
+    auto fetch = [&](int64_t t, int c) {
+        const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
+        const float* base = a.audio + ((a.sample_offset + start) * C + c);
+        if (start >= 0 && start + W <= a.n_samples) {
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int n = tid + kFftThreads * i;
+                const int m = n < N ? n : 0;
+                raw0[i] = *reinterpret_cast<const float2*>(base + (2 * m) * C);
+                raw1[i] = *reinterpret_cast<const float2*>(base + (2 * m + 1) * C);
+            }
+        } else {
+            const float2 zero = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int n = tid + kFftThreads * i;
+                const int64_t s0 = start + 2 * n, s1 = s0 + 1;
+                raw0[i] = (n < N && s0 >= 0 && s0 < a.n_samples) ? *reinterpret_cast<const float2*>(base + (2 * n) * C) : zero;
+                raw1[i] = (n < N && s1 >= 0 && s1 < a.n_samples) ? *reinterpret_cast<const float2*>(base + (2 * n + 1) * C) : zero;
+            }
+        }
+    };
+    if (t_begin < t_end) fetch(t_begin, 0);
+    __syncthreads();
+
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t row = t * a.FS;
+        float acc[SLOTS];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) acc[i] = 0.f;
+
+        for (int c = 0; c < C; c += 2) {
+            float2 *a0 = bufs[0], *b0 = bufs[1], *a1 = bufs[2], *b1 = bufs[3];
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int n = tid + kFftThreads * i;
+                if (n < N) {
+                    const float2 w = win_lds[n];
+                    a0[n] = make_float2(raw0[i].x * w.x, raw1[i].x * w.y);
+                    a1[n] = make_float2(raw0[i].y * w.x, raw1[i].y * w.y);
+                }
+            }
+            {
+                const bool same_frame = c + 2 < C;
+                const int64_t tn = same_frame ? t : t + 1;
+                if (tn < t_end) fetch(tn, same_frame ? c + 2 : 0);
+            }
+            __syncthreads();
+            fft_lds_tab2<N, false>(a0, b0, a1, b1, tw_lds, W);
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const int k = tid + kFftThreads * i;
+                if (k <= N) {
+                    const float2 tw = tw_lds[k];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const float2* Z = half == 0 ? a0 : a1;
+                        const float2 zk = Z[k & (N - 1)];
+                        const float2 zc = cconj(Z[(N - k) & (N - 1)]);
+                        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+                        const float2 d = csub(zk, zc);
+                        const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
+                        const float2 x = cadd(e, cmul(tw, o));
+                        const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                        a.X[(c + half) * a.chan_stride + row + k] = x;
+                        a.V[(c + half) * a.chan_stride + row + k] = mag;
+                        acc[i] += mag;
+                    }
+                }
+            }
+            if (tid < a.FS - (N + 1)) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    a.X[(c + half) * a.chan_stride + row + N + 1 + tid] = make_float2(0.f, 0.f);
+                    a.V[(c + half) * a.chan_stride + row + N + 1 + tid] = 0.f;
+                }
+            }
+            __syncthreads();
+        }
+
+        if (a.Vm == nullptr && a.Vn == nullptr && a.P == nullptr) continue;
+        const float inv_c = 1.0f / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int k = tid + kFftThreads * i;
+            acc[i] = acc[i] * inv_c;
+            if (k <= N) ss += acc[i] * acc[i];
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) ss += __shfl_down(ss, off);
+        if ((tid & (kWave - 1)) == 0) red[tid / kWave] = ss;
+        __syncthreads();
+        float total = 0.f;
+#pragma unroll
+        for (int w = 0; w < kFftThreads / kWave; ++w) total += red[w];
+        const float norm = sqrtf(total);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int k = tid + kFftThreads * i;
+            if (k <= N) {
+                if (a.Vm) a.Vm[row + k] = acc[i];
+                if (a.Vn) a.Vn[row + k] = acc[i] / norm;
+                if (a.P) a.P[row + k] = acc[i] * acc[i];
+            }
+        }
+        if (tid < a.FS - (N + 1)) {
+            if (a.Vm) a.Vm[row + N + 1 + tid] = 0.f;
+            if (a.Vn) a.Vn[row + N + 1 + tid] = 0.f;
+            if (a.P) a.P[row + N + 1 + tid] = 0.f;
+        }
+        __syncthreads();
+    }
+}
 
 #ifndef REPET_STFT_MIN_WAVES
 #define REPET_STFT_MIN_WAVES 4
@@ -176,8 +463,15 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     constexpr int N = W / 2;                       // complex FFT length; also the Nyquist bin index
     constexpr int SLOTS = N / kFftThreads + 1;     // bins k = tid + 256*i, k <= N
     constexpr int LOADS = (N + kFftThreads - 1) / kFftThreads;
+    // The kernel is bound by global-memory LATENCY, not by the FFT (removing all five stages saves 10 %): a
+    // workgroup used to wait for its samples, then for the split twiddles, once per transform. Now the window and
+    // the split twiddles sit in LDS for the whole run and the samples of the NEXT transform are fetched into
+    // registers before the current one is transformed.
+    constexpr bool kTables = W <= 2048;            // 2 x W/2 float2 of LDS beside the two FFT buffers (64 KB static limit)
     __shared__ float2 buf0[N];
     __shared__ float2 buf1[N];
+    __shared__ float2 win_lds[kTables ? N : 1];
+    __shared__ float2 tw_lds[kTables ? 3 * W / 4 + 1 : 1];      // exp(-2 pi i m / W): stage and split twiddles
     __shared__ float red[kFftThreads / kWave];
 
     const int tid = threadIdx.x;
@@ -190,33 +484,89 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     if (a.Vn) a.Vn += b * a.batch_mean_stride;
     if (a.P) a.P += b * a.batch_mean_stride;
 
-    // per-thread stage twiddles, loaded once (window and split twiddles stay in L1/L2: registers buy occupancy)
-    FftTwiddles<N> ft;
-    fft_twiddles<N, false>(ft, a.twiddle, W);
+    FftTwiddles<kTables ? 4 : N> ft;                // register twiddles only where the tables do not fit in LDS
+    if (kTables) {
+        // unrolled so that the loads of a thread are all in flight together (a runtime loop waits for each)
+        constexpr int kTwLoads = (3 * W / 4 + 1 + kFftThreads - 1) / kFftThreads;
+        float2 wreg[LOADS], treg[kTwLoads];
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int n = tid + kFftThreads * i;
+            wreg[i] = *reinterpret_cast<const float2*>(a.window + 2 * (n < N ? n : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < kTwLoads; ++i) {
+            const int m = tid + kFftThreads * i;
+            treg[i] = a.twiddle[m <= 3 * W / 4 ? m : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int n = tid + kFftThreads * i;
+            if (n < N) win_lds[n] = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kTwLoads; ++i) {
+            const int m = tid + kFftThreads * i;
+            if (m <= 3 * W / 4) tw_lds[m] = treg[i];
+        }
+    } else {
+        fft_twiddles<kTables ? 4 : N, false>(ft, a.twiddle, W);
+    }
     const int64_t t_begin = (int64_t)blockIdx.x * kStftFrameRun;
     const int64_t t_end = (t_begin + kStftFrameRun < a.T) ? t_begin + kStftFrameRun : a.T;
-    for (int64_t t = t_begin; t < t_end; ++t) {
+
+    float2 raw[LOADS];                             // samples (2n, 2n+1) of the transform about to be windowed
+    auto fetch = [&](int64_t t, int c) {
         const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
+        const float* base = a.audio + ((a.sample_offset + start) * C + c);   // only dereferenced inside the clip
+        if (start >= 0 && start + W <= a.n_samples) {          // block-uniform: the frame lies inside the clip
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int n = tid + kFftThreads * i;
+                const int m = n < N ? n : 0;
+                raw[i] = make_float2(base[(2 * m) * C], base[(2 * m + 1) * C]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int n = tid + kFftThreads * i;
+                const int64_t s0 = start + 2 * n, s1 = s0 + 1;
+                const float x0 = (n < N && s0 >= 0 && s0 < a.n_samples) ? base[(2 * n) * C] : 0.f;
+                const float x1 = (n < N && s1 >= 0 && s1 < a.n_samples) ? base[(2 * n + 1) * C] : 0.f;
+                raw[i] = make_float2(x0, x1);
+            }
+        }
+    };
+    constexpr bool kPrefetch = W <= 2048;          // larger windows keep 16+ samples per thread: no room to hold two sets
+    if (kPrefetch && t_begin < t_end) fetch(t_begin, 0);
+    __syncthreads();                               // tables visible
+
+    for (int64_t t = t_begin; t < t_end; ++t) {
         const int64_t row = t * a.FS;
         float acc[SLOTS];
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) acc[i] = 0.f;
 
         for (int c = 0; c < C; ++c) {
+            if (!kPrefetch) fetch(t, c);
 #pragma unroll
             for (int i = 0; i < LOADS; ++i) {
                 const int n = tid + kFftThreads * i;
                 if (n < N) {
-                    const int64_t s0 = start + 2 * n, s1 = s0 + 1;
-                    float x0 = 0.f, x1 = 0.f;
-                    if (s0 >= 0 && s0 < a.n_samples) x0 = a.audio[(a.sample_offset + s0) * C + c];
-                    if (s1 >= 0 && s1 < a.n_samples) x1 = a.audio[(a.sample_offset + s1) * C + c];
-                    const float2 w = *reinterpret_cast<const float2*>(a.window + 2 * n);
-                    buf0[n] = make_float2(x0 * w.x, x1 * w.y);
+                    const float2 w = kTables ? win_lds[n] : *reinterpret_cast<const float2*>(a.window + 2 * n);
+                    buf0[n] = make_float2(raw[i].x * w.x, raw[i].y * w.y);
                 }
             }
+            // next transform of this workgroup: same frame, next channel, or the next frame's first channel
+            if (kPrefetch) {                 // one call site: a second one costs a vmcnt(0) at the join
+                const bool same_frame = c + 1 < C;
+                const int64_t tn = same_frame ? t : t + 1;
+                if (tn < t_end) fetch(tn, same_frame ? c + 1 : 0);
+            }
             __syncthreads();
-            const float2* Z = fft_lds_regs<N, false>(buf0, buf1, ft);
+            const float2* Z;
+            if constexpr (kTables) Z = fft_lds_tab<N, false>(buf0, buf1, tw_lds, W);
+            else Z = fft_lds_regs<N, false>(buf0, buf1, ft);
             float2* Xrow = a.X + c * a.chan_stride + row;
             float* Vrow = a.V + c * a.chan_stride + row;
 #pragma unroll
@@ -228,7 +578,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
                     const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
                     const float2 d = csub(zk, zc);
                     const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);   // (zk - zc) / (2i)
-                    const float2 x = cadd(e, cmul(a.twiddle[k], o));
+                    const float2 x = cadd(e, cmul(kTables ? tw_lds[k] : a.twiddle[k], o));
                     const float mag = sqrtf(x.x * x.x + x.y * x.y);
                     Xrow[k] = x;
                     Vrow[k] = mag;
@@ -759,6 +1109,16 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
                 hipLaunchKernelGGL(stft_wave_kernel<Wc>, dim3((unsigned)ceil_div(a.T, fpw), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
                                    dim3(256), dyn, s, a, fpw);
             }
+        });
+    }
+    static const bool pair = [] { const char* e = getenv("REPET_FFT_PAIR"); return e ? atoi(e) != 0 : true; }();   // REPET_FFT_PAIR=0: one transform per pass
+    if (pair && (a.n_channels % 2) == 0 && a.W <= 2048) {
+        return dispatch_window(a.W, [&](auto w) {
+            constexpr int Wc = decltype(w)::value;
+            if constexpr (Wc <= 2048)
+                hipLaunchKernelGGL(stft_pair_kernel<Wc>,
+                                   dim3((unsigned)ceil_div(a.T, kStftFrameRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
+                                   dim3(kFftThreads), 0, s, a);
         });
     }
     return dispatch_window(a.W, [&](auto w) {
