@@ -80,6 +80,7 @@ struct repet_ctx {
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
+    DevBuf Vh, Vl;                // f16 hi / lo planes of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
     std::map<int, std::unique_ptr<Tables>> tables;
     DevBuf tiles;                 // Gram tile list of the last (nb, ndiag)
@@ -158,9 +159,23 @@ int get_tiles(repet_ctx* c, int64_t T, int ndiag, const int2** tiles, int* count
     return REPET_OK;
 }
 
-int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS) {
+// REPET_GRAM=f32 selects the exact-fp32 MFMA kernel for the similarity matrix of `sim` (default: the f16-split one)
+bool gram_f16_enabled() {
+    static const bool on = [] { const char* e = getenv("REPET_GRAM"); return !(e && e[0] == 'f' && e[1] == '3'); }();
+    return on;
+}
+
+int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS, bool unit_rows = false) {
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, 1 << 30, &tiles, &n));
+    if (unit_rows && gram_f16_enabled()) {      // rows are unit vectors (components in [0, 1]): safe for the f16 split
+        const int64_t count = round_up(T, kTile) * FS;
+        HIP_TRY(c->Vh.ensure((size_t)count * 2));
+        HIP_TRY(c->Vl.ensure((size_t)count * 2));
+        HIP_TRY(launch_split_f16(A, c->Vh.p, c->Vl.p, count, c->stream));
+        HIP_TRY(launch_gram_full_f16(c->Vh.p, c->Vl.p, T, FS, S, TS, tiles, n, c->stream));
+        return REPET_OK;
+    }
     HIP_TRY(launch_gram_full(A, T, FS, S, TS, tiles, n, c->stream));
     return REPET_OK;
 }
@@ -487,7 +502,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS));
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true));
     mark(c, "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T, 2.0 * g.F * (double)T * T);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
@@ -683,7 +698,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->Vl, &c->P, &c->S, &c->band, &c->beat,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }

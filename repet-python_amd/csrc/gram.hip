@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
                     if (gi < T && gj < TJ) out[gi * pitch + gj] = acc[m][n][r];
                 }
         if (MODE == GRAM_FULL && bi != bj) {
-            // mirror: transpose this wave's 64x64 block through a private LDS patch (pitch 65)
+            // mirror: transpose this wave's 64x64 block through a private LDS patch (pitch 65). The patches alias the
+            // tile buffers, which a slower wave may still be reading in its last K-tile: wait for the whole block.
+            __syncthreads();
             float* patch = lds + wave * (64 * 65);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
