@@ -95,10 +95,11 @@ inline int gram_band_diagonals(int n_lags) { return (n_lags + 126) / kTile + 1; 
 // K3: S[T][TS] = A A^T for A[Tpad][FS] fp32 (rows >= T are zero), MFMA fp32, upper tiles mirrored.
 hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int64_t TS, const int2* tiles,
                             int32_t n_tiles, hipStream_t s);
-// K3h (gram_f16.hip): the same S from the f16 matrix cores: the fp32 rows are split once into two f16 planes (hi, lo;
-// Tpad x FS halves each) and S = hi hi' + hi lo' + lo hi', fp32-class accuracy at 3/16 of the fp32 MFMA time.
-hipError_t launch_split_f16(const float* src, void* hi, void* lo, int64_t count, hipStream_t s);
-hipError_t launch_gram_full_f16(const void* hi, const void* lo, int64_t T, int32_t FS, float* S, int64_t TS,
+// K3h (gram_f16.hip): the same S from the f16 matrix cores: the fp32 rows are split once into f16 halves hi, lo
+// (`planes`: 2 * count halves, interleaved per 32 components) and S = hi hi' + hi lo' + lo hi': fp32-class accuracy
+// at 3/16 of the fp32 MFMA time.
+hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s);
+hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s);
 // K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,

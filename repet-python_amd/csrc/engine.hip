@@ -80,7 +80,7 @@ struct repet_ctx {
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
-    DevBuf Vh, Vl;                // f16 hi / lo planes of Vn for the split-precision Gram (gram_f16.hip)
+    DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
     std::map<int, std::unique_ptr<Tables>> tables;
     DevBuf tiles;                 // Gram tile list of the last (nb, ndiag)
@@ -170,10 +170,9 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
     RP_TRY(get_tiles(c, T, 1 << 30, &tiles, &n));
     if (unit_rows && gram_f16_enabled()) {      // rows are unit vectors (components in [0, 1]): safe for the f16 split
         const int64_t count = round_up(T, kTile) * FS;
-        HIP_TRY(c->Vh.ensure((size_t)count * 2));
-        HIP_TRY(c->Vl.ensure((size_t)count * 2));
-        HIP_TRY(launch_split_f16(A, c->Vh.p, c->Vl.p, count, c->stream));
-        HIP_TRY(launch_gram_full_f16(c->Vh.p, c->Vl.p, T, FS, S, TS, tiles, n, c->stream));
+        HIP_TRY(c->Vh.ensure((size_t)count * 4));
+        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        HIP_TRY(launch_gram_full_f16(c->Vh.p, T, FS, S, TS, tiles, n, c->stream));
         return REPET_OK;
     }
     HIP_TRY(launch_gram_full(A, T, FS, S, TS, tiles, n, c->stream));
@@ -698,7 +697,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->Vl, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->P, &c->S, &c->band, &c->beat,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }

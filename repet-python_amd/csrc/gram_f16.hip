@@ -11,11 +11,16 @@
 // f16 range (lo of a typical component is ~1e-3); it is removed exactly (2^-14) in the epilogue. NaN rows (silent
 // frames) stay NaN. Decisions that hinge on the last bits are re-taken in float64 anyway (peaks.hip).
 //
-// Same tiling as gram.hip: 128x128 tile per 256-thread workgroup (2x2 waves of 2x2 MFMA blocks), BK = 32, register
-// prefetch two K-tiles ahead, double-buffered LDS, XCD-ordered upper-triangle tile list, mirror through LDS. The
-// LDS image of a plane is [128 rows][4 chunks of 8 halves] with chunk c of row r stored at c ^ ((r >> 2) & 3): the
-// 16-lane groups of ds_read_b128 (rows {0-3,12-15,20-27}, ...) and the 8-lane groups of ds_write_b128 then touch
-// every bank once.
+// Same tiling as gram.hip: 128x128 tile per 256-thread workgroup (2x2 waves of 2x2 MFMA blocks), BK = 32, double-
+// buffered LDS, XCD-ordered upper-triangle tile list, mirror through LDS. With the MFMA share down to a fifth the
+// kernel lives on its staging path, so: (1) the global image interleaves hi and lo per 32 components -- one 128-byte
+// line per (row, K-tile) instead of two half-used ones; (2) three register sets carry K-tiles kt+1 .. kt+3 and a
+// pipeline step has no branch in it, so hipcc's vmcnt accounting stays exact (waits for the oldest set only);
+// (3) the LDS image of a plane is [128 rows][4 chunks of 8 halves] with chunk c of row r stored at
+// c ^ ((r >> 2) & 3) and the lo plane 64 bytes off a bank-row boundary: the 16-lane groups of ds_read_b128 (rows
+// {0-3,12-15,20-27}, ...) and the 8-lane groups of ds_write_b128 (one row's 4 hi + 4 lo chunks) touch every bank once.
+// Measured at cfg 2 (T = 7753, FS = 1056): 0.227 ms against 0.61 ms for the fp32 kernel; without the K loop 0.06 ms
+// (split + epilogue), without the MFMAs 0.20 ms -- the staging path, not the matrix cores, is what remains.
 #include "common.h"
 
 #include <hip/hip_fp16.h>
@@ -29,13 +34,18 @@ namespace {
 
 constexpr int HBK = 32;                        // K elements per K-tile
 constexpr int kPlaneHalves = kTile * HBK;      // one plane tile in LDS: 128 rows x 32 halves = 8 KB
-constexpr int kGramF16Lds = 2 /*buffers*/ * 4 /*A hi, A lo, B hi, B lo*/ * kPlaneHalves * 2;   // 65,536 bytes
+constexpr int kPlanePitch = kPlaneHalves + 32; // + 64 bytes: the hi and lo chunks one 8-lane ds_write group stores land on different banks
+constexpr int kOperandHalves = 2 * kPlanePitch;
+constexpr int kGramF16Lds = 2 /*buffers*/ * 2 /*A, B*/ * kOperandHalves * 2;   // 66,048 bytes
 constexpr float kSplitScale = 128.0f;          // 2^7
 constexpr float kUnscale = 1.0f / (kSplitScale * kSplitScale);
 
-__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                                        _Float16* __restrict__ lo, int64_t count) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+// planes[row][kb][hi | lo][32]: the hi and the lo halves of the 32 components kb*32 .. kb*32+31 of a row sit side by
+// side, 64 + 64 bytes = one 128-byte cache line per (row, K-tile). With two separate planes a K-tile touched only
+// half of every line it pulled into L1 and the other half was gone again by the next K-tile.
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ planes,
+                                                        int64_t count) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;     // FS is a multiple of 32: never straddles
     if (i >= count) return;
     const float4 x = *reinterpret_cast<const float4*>(src + i);
     const float v[4] = {x.x * kSplitScale, x.y * kSplitScale, x.z * kSplitScale, x.w * kSplitScale};
@@ -45,12 +55,14 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
         h[k] = (_Float16)v[k];
         l[k] = (_Float16)(v[k] - (float)h[k]);
     }
-    *reinterpret_cast<uint2*>(hi + i) = *reinterpret_cast<const uint2*>(h);
-    *reinterpret_cast<uint2*>(lo + i) = *reinterpret_cast<const uint2*>(l);
+    const int64_t blk = i >> 5, kk = i & 31;                                    // 32-component block, offset inside it
+    _Float16* dst = planes + blk * 64 + kk;
+    *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(h);
+    *reinterpret_cast<uint2*>(dst + 32) = *reinterpret_cast<const uint2*>(l);
 }
 
-__global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
-                                                       int64_t T, int FS, float* __restrict__ out, int64_t pitch,
+__global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
+                                                       float* __restrict__ out, int64_t pitch,
                                                        const int2* __restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const int2 tile = tiles[blockIdx.x];
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
 
-    const int64_t a_row0 = (int64_t)bi * kTile, b_row0 = (int64_t)bj * kTile;
+    const int64_t a_row0 = (int64_t)bi * kTile, b_row0 = (int64_t)bj * kTile;      // first row of the A / B panel
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -73,40 +85,45 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // staging: a plane tile is 128 rows x 4 chunks of 16 bytes = 512 chunks, two per thread (rows r and r + 64)
-    const int srow = tid >> 2, schunk = tid & 3;
-    const unsigned g0 = (unsigned)(srow * FS + schunk * 8);               // halves, relative to the tile's first row
-    const unsigned g1 = g0 + (unsigned)(64 * FS);
-    const int l0 = srow * HBK + ((schunk ^ ((srow >> 2) & 3)) << 3);      // halves inside a plane tile
-    const int l1 = l0 + 64 * HBK;                                          // (row + 64) has the same swizzle key
-    float4 pah0, pah1, pal0, pal1, pbh0, pbh1, pbl0, pbl1;                // register set P
-    float4 qah0, qah1, qal0, qal1, qbh0, qbh1, qbl0, qbl1;                // register set Q
+    // staging: per operand and K-tile 128 rows x (4 hi + 4 lo chunks of 16 bytes) = one cache line per row; a thread
+    // takes chunk (tid & 7) of rows (tid >> 3) + 32 j, j < 4: a wave-load covers 8 whole lines
+    const int srow = tid >> 3, sch = tid & 7;
+    const int splane = sch >> 2, schunk = sch & 3;                       // hi / lo, 16-byte chunk inside the plane row
+    const unsigned grow = (unsigned)(2 * FS);                            // halves per row of the interleaved image
+    const unsigned g0 = (unsigned)(srow * grow + sch * 8);               // halves, relative to (tile row 0, K-tile 0)
+    // LDS: plane p of an operand at p * kPlanePitch; chunk c of row r at c ^ ((r >> 2) & 3)
+    const int l0 = splane * kPlanePitch + srow * HBK + ((schunk ^ ((srow >> 2) & 3)) << 3);
+    // three staging register sets: tile t travels in set t % 3, so a K-tile has TWO iterations (~2 x 800 cycles of
+    // MFMA) to arrive before it is written to LDS -- with the 768-cycle f16 iterations one iteration of slack (two
+    // sets) left the loop waiting on L2 / Infinity-Cache latency; a fourth set does not fit beside the accumulators
+    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define F16_LOAD_TILE(S, kt)                                                          \
     {                                                                                 \
-        const _Float16* ah = Ah + a_row0 * FS + (kt) * HBK;                           \
-        const _Float16* al = Al + a_row0 * FS + (kt) * HBK;                           \
-        const _Float16* bh = Ah + b_row0 * FS + (kt) * HBK;                           \
-        const _Float16* bl = Al + b_row0 * FS + (kt) * HBK;                           \
-        S##ah0 = *reinterpret_cast<const float4*>(ah + g0);                           \
-        S##bh0 = *reinterpret_cast<const float4*>(bh + g0);                           \
-        S##al0 = *reinterpret_cast<const float4*>(al + g0);                           \
-        S##bl0 = *reinterpret_cast<const float4*>(bl + g0);                           \
-        S##ah1 = *reinterpret_cast<const float4*>(ah + g1);                           \
-        S##bh1 = *reinterpret_cast<const float4*>(bh + g1);                           \
-        S##al1 = *reinterpret_cast<const float4*>(al + g1);                           \
-        S##bl1 = *reinterpret_cast<const float4*>(bl + g1);                           \
+        const _Float16* ap = planes + a_row0 * grow + (kt) * 64 + g0;                 \
+        const _Float16* bp = planes + b_row0 * grow + (kt) * 64 + g0;                 \
+        S##a0 = *reinterpret_cast<const float4*>(ap);                                 \
+        S##b0 = *reinterpret_cast<const float4*>(bp);                                 \
+        S##a1 = *reinterpret_cast<const float4*>(ap + 32 * grow);                     \
+        S##b1 = *reinterpret_cast<const float4*>(bp + 32 * grow);                     \
+        S##a2 = *reinterpret_cast<const float4*>(ap + 64 * grow);                     \
+        S##b2 = *reinterpret_cast<const float4*>(bp + 64 * grow);                     \
+        S##a3 = *reinterpret_cast<const float4*>(ap + 96 * grow);                     \
+        S##b3 = *reinterpret_cast<const float4*>(bp + 96 * grow);                     \
     }
 #define F16_STORE_TILE(S, buf)                                                        \
     {                                                                                 \
-        _Float16* base = ldsh + (buf) * 4 * kPlaneHalves;                             \
-        *reinterpret_cast<float4*>(base + 0 * kPlaneHalves + l0) = S##ah0;            \
-        *reinterpret_cast<float4*>(base + 1 * kPlaneHalves + l0) = S##al0;            \
-        *reinterpret_cast<float4*>(base + 2 * kPlaneHalves + l0) = S##bh0;            \
-        *reinterpret_cast<float4*>(base + 3 * kPlaneHalves + l0) = S##bl0;            \
-        *reinterpret_cast<float4*>(base + 0 * kPlaneHalves + l1) = S##ah1;            \
-        *reinterpret_cast<float4*>(base + 1 * kPlaneHalves + l1) = S##al1;            \
-        *reinterpret_cast<float4*>(base + 2 * kPlaneHalves + l1) = S##bh1;            \
-        *reinterpret_cast<float4*>(base + 3 * kPlaneHalves + l1) = S##bl1;            \
+        _Float16* abase = ldsh + (buf) * 2 * kOperandHalves + l0;                     \
+        _Float16* bbase = abase + kOperandHalves;                                     \
+        *reinterpret_cast<float4*>(abase) = S##a0;                                    \
+        *reinterpret_cast<float4*>(bbase) = S##b0;                                    \
+        *reinterpret_cast<float4*>(abase + 32 * HBK) = S##a1;                         \
+        *reinterpret_cast<float4*>(bbase + 32 * HBK) = S##b1;                         \
+        *reinterpret_cast<float4*>(abase + 64 * HBK) = S##a2;                         \
+        *reinterpret_cast<float4*>(bbase + 64 * HBK) = S##b2;                         \
+        *reinterpret_cast<float4*>(abase + 96 * HBK) = S##a3;                         \
+        *reinterpret_cast<float4*>(bbase + 96 * HBK) = S##b3;                         \
     }
     // fragment of lane (lr, lh) for MFMA block row/col `blk` (0/1) of this wave and K-step `ks` (0/1): 8 halves
     // k = 16 ks + 8 lh .. +7 of tile row  w*64 + blk*32 + lr  -> chunk 2 ks + lh, swizzled by the row
@@ -115,12 +132,12 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
                                       (((2 * (ks) + lh) ^ (((lr) >> 2) & 3)) << 3)))
 #define F16_COMPUTE(buf)                                                                                        \
     {                                                                                                           \
-        const _Float16* base = ldsh + (buf) * 4 * kPlaneHalves;                                                 \
+        const _Float16* base = ldsh + (buf) * 2 * kOperandHalves;                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                      \
             const halfx8 ah0 = F16_FRAG(base, wr, 0, ks), ah1 = F16_FRAG(base, wr, 1, ks);                      \
-            const halfx8 al0 = F16_FRAG(base + kPlaneHalves, wr, 0, ks), al1 = F16_FRAG(base + kPlaneHalves, wr, 1, ks); \
-            const halfx8 bh0 = F16_FRAG(base + 2 * kPlaneHalves, wc, 0, ks), bh1 = F16_FRAG(base + 2 * kPlaneHalves, wc, 1, ks); \
-            const halfx8 bl0 = F16_FRAG(base + 3 * kPlaneHalves, wc, 0, ks), bl1 = F16_FRAG(base + 3 * kPlaneHalves, wc, 1, ks); \
+            const halfx8 al0 = F16_FRAG(base + kPlanePitch, wr, 0, ks), al1 = F16_FRAG(base + kPlanePitch, wr, 1, ks); \
+            const halfx8 bh0 = F16_FRAG(base + kOperandHalves, wc, 0, ks), bh1 = F16_FRAG(base + kOperandHalves, wc, 1, ks); \
+            const halfx8 bl0 = F16_FRAG(base + kOperandHalves + kPlanePitch, wc, 0, ks), bl1 = F16_FRAG(base + kOperandHalves + kPlanePitch, wc, 1, ks); \
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);                    \
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);                    \
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);                    \
@@ -137,22 +154,32 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
     }
 
     const int nk = FS / HBK;                // FS is a multiple of 32; nk >= 2 for every supported window
+    const int klast = nk - 1;
     F16_LOAD_TILE(p, 0)
+    F16_LOAD_TILE(q, min(1, klast))
+    F16_LOAD_TILE(r, min(2, klast))
     F16_STORE_TILE(p, 0)
-    if (nk > 1) F16_LOAD_TILE(q, 1)
     __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        if (kt + 2 < nk) F16_LOAD_TILE(p, kt + 2)
-        F16_COMPUTE(0)
-        F16_STORE_TILE(q, 1)
-        __syncthreads();
-        if (kt + 3 < nk) F16_LOAD_TILE(q, kt + 3)
-        F16_COMPUTE(1)
-        if (kt + 2 < nk) F16_STORE_TILE(p, 0)
-        __syncthreads();
+    // iteration kt: LDS[kt & 1] holds tile kt, the sets hold kt+1 and kt+2, the set of tile kt is free for kt+3.
+    // No branch inside a step: past the end the loads re-read the last tile and the LDS store goes to the buffer
+    // nobody reads any more. With conditional loads hipcc's waitcnt pass gave up at the joins and waited vmcnt(0)
+    // -- for the prefetches just issued -- before every barrier.
+#define F16_STEP(FREE, NEXT, kt)                                    \
+    {                                                               \
+        F16_LOAD_TILE(FREE, min((kt) + 3, klast))                   \
+        F16_COMPUTE((kt) & 1)                                       \
+        F16_STORE_TILE(NEXT, ((kt) + 1) & 1)                        \
+        __syncthreads();                                            \
     }
-    if (kt < nk) F16_COMPUTE(0)
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 3) {
+        F16_STEP(p, q, kt)
+        F16_STEP(q, r, kt + 1)
+        F16_STEP(r, p, kt + 2)
+    }
+    if (kt < nk) { F16_STEP(p, q, kt) ++kt; }
+    if (kt < nk) { F16_STEP(q, r, kt) ++kt; }
+#undef F16_STEP
 #undef F16_LOAD_TILE
 #undef F16_STORE_TILE
 #undef F16_FRAG
@@ -200,21 +227,21 @@ constexpr int kGramF16LdsAsk = 4 * 64 * 65 * 4 > kGramF16Lds ? 4 * 64 * 65 * 4 :
 
 }  // namespace
 
-hipError_t launch_split_f16(const float* src, void* hi, void* lo, int64_t count, hipStream_t s) {
+hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s) {
     if (count <= 0) return hipSuccess;
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, s, src,
-                       reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), count);
+                       reinterpret_cast<_Float16*>(planes), count);
     return hipGetLastError();
 }
 
-hipError_t launch_gram_full_f16(const void* hi, const void* lo, int64_t T, int32_t FS, float* S, int64_t TS,
+hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
     hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_f16_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_f16_kernel, dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
-                       reinterpret_cast<const _Float16*>(hi), reinterpret_cast<const _Float16*>(lo), T, FS, S, TS, tiles);
+                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles);
     return hipGetLastError();
 }
 
