@@ -321,6 +321,30 @@ def test_fft_paths_agree():
     assert rms_err(outs[0], outs[2]) < 2e-6
 
 
+def test_gram_paths_agree():
+    """sim's similarity matrix: the f16-split matrix-core kernel (default) against the exact-fp32 one (REPET_GRAM=f32).
+    Same similar-frame lists (the float64 refinement settles every near-tie either way), outputs equal to fp32 noise."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "x = synth(30, 44100, 2, 21); p = repet.derive_params(44100); c = repet.Context(0); c.upload(x); c.execute('sim', p); "
+            "y = c.download(); idx, cnt = c.last_sim_indices(c.last_frame_count(), p.sim_number); "
+            "np.savez(sys.argv[1], y=y, idx=np.sort(idx, axis=1), cnt=cnt)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for path in ("f16", "f32"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_gram_{path}_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_GRAM=path))
+        with np.load(out) as z:
+            outs.append({k: z[k] for k in z.files})
+        os.remove(out)
+    assert np.array_equal(outs[0]["cnt"], outs[1]["cnt"])
+    assert np.mean(np.any(outs[0]["idx"] != outs[1]["idx"], axis=1)) <= 0.002
+    assert rms_err(outs[0]["y"], outs[1]["y"]) < 5e-6
+
+
 def test_long_similarity_number_uses_bisection_path():
     """similarity_number > 128 takes the bisection median (no sorting network of that size)."""
     x, fs = golden_input("small_stereo")
