@@ -101,6 +101,10 @@ hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int
 hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s);
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s);
+// banded form (simonline: unit rows): band[t][l] = row t . row t+l; plane_batch_stride in halves (2 * Tpad * FS)
+hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
+                                const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
+                                int64_t band_batch_stride, hipStream_t s);
 // K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                             const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t a_batch_stride,

@@ -14,6 +14,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -178,10 +179,22 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
     HIP_TRY(launch_gram_full(A, T, FS, S, TS, tiles, n, c->stream));
     return REPET_OK;
 }
-int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP) {
+// unit_rows: A holds unit vectors (the similarity band of simonline), safe for the f16-split kernel; the beat-spectrum
+// bands (power spectra, wide dynamic range) stay on the exact-fp32 one. B clips: a_stride / band_stride in elements.
+int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP, bool unit_rows = false,
+                  int B = 1, int64_t a_stride = 0, int64_t band_stride = 0) {
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
-    HIP_TRY(launch_gram_band(A, T, FS, band, n_lags, LP, tiles, n, 1, 0, 0, c->stream));
+    if (unit_rows && gram_f16_enabled()) {
+        const int64_t per_clip = round_up(T, kTile) * FS;
+        if (B > 1 && a_stride != per_clip) return fail(REPET_ERR_BAD_ARG, "internal: batch stride of the unit rows");
+        const int64_t count = per_clip * B;
+        HIP_TRY(c->Vh.ensure((size_t)count * 4));
+        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream));
+        return REPET_OK;
+    }
+    HIP_TRY(launch_gram_band(A, T, FS, band, n_lags, LP, tiles, n, B, a_stride, band_stride, c->stream));
     return REPET_OK;
 }
 
@@ -575,14 +588,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int LP = (int)round_up(B, 64);
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP, spec_stride = (int64_t)g.C * g.chan_stride;
     HIP_TRY(c->band.ensure((size_t)nb * band_stride * sizeof(float)));
-    if (nb == 1) {
-        RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP));
-    } else {
-        const int2* tiles; int n_tiles;
-        RP_TRY(get_tiles(c, T, gram_band_diagonals(B), &tiles, &n_tiles));
-        HIP_TRY(launch_gram_band(c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, tiles, n_tiles, nb, mean_stride,
-                                 band_stride, c->stream));
-    }
+    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride));
     mark(c, "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;
@@ -777,6 +783,47 @@ int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int3
 }
 
 namespace {
+// Pipelines of different contexts on one device run back to back on the GPU, never interleaved. Why: with two host
+// threads hammering repet.sim on their own contexts (tools/thread_stress.py) about one run in 2 000 came back with a
+// few dozen damaged samples in one hop whenever the f16-split Gram kernel of one context overlapped the other
+// context's kernels (0 of 100 000 runs with one thread, with the fp32 Gram, or with this chain); the kernel itself
+// stays inside its LDS and global allocations (guard bands change nothing). Until that interaction is understood,
+// every pipeline waits for the device's previous one: a mutex covers the ENQUEUE of a pipeline (microseconds to a
+// millisecond), the ordering itself is a stream-wait on an event, so nobody blocks on the host for GPU work.
+struct DeviceChain {
+    std::mutex m;
+    hipEvent_t ring[8] = {};
+    int next = 0;
+    bool have_tail = false;
+    hipEvent_t tail = nullptr;
+};
+DeviceChain g_chains[16];
+
+struct ChainScope {
+    DeviceChain* d;
+    repet_ctx* c;
+    bool published = false;
+    explicit ChainScope(repet_ctx* ctx) : d(&g_chains[ctx->device & 15]), c(ctx) {
+        d->m.lock();
+        if (d->have_tail) (void)hipStreamWaitEvent(c->stream, d->tail, 0);
+    }
+    void publish() {                       // everything enqueued on c->stream so far precedes the next pipeline
+        if (published) return;
+        published = true;
+        hipEvent_t& e = d->ring[d->next];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        if (e && hipEventRecord(e, c->stream) == hipSuccess) {
+            d->tail = e;
+            d->have_tail = true;
+            d->next = (d->next + 1) & 7;
+        }
+        d->m.unlock();
+    }
+    ~ChainScope() { publish(); }
+};
+}  // namespace
+
+namespace {
 int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
     switch (algo) {
         case REPET_ORIGINAL: return exec_original(c, p);
@@ -814,11 +861,13 @@ int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timin
     RP_TRY(check_params(p));
     if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
     DeviceGuard guard(c->device);
+    ChainScope chain(c);
     begin_timing(c, timing);
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
     int rc = run_algo(c, algo, p);
+    chain.publish();
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
     if (rc == REPET_OK) end_timing(c);
@@ -831,6 +880,7 @@ int repet_ctx_execute_async(repet_ctx* c, int algo, const repet_params* p) {
     RP_TRY(check_params(p));
     if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
     DeviceGuard guard(c->device);
+    ChainScope chain(c);
     c->timing = nullptr;
     c->last_algo = algo;
     c->last_n_periods = 0;
@@ -858,10 +908,12 @@ int repet_ctx_execute_extended_range(repet_ctx* c, const repet_params* p, int64_
     if (n_seg < 0) return fail(REPET_ERR_BAD_ARG, "negative segment count");
     if (c->n_clips > 1) return fail(REPET_ERR_BAD_ARG, "segment ranges apply to a single resident clip, not to a batch context");
     DeviceGuard guard(c->device);
+    ChainScope chain(c);
     begin_timing(c, timing);
     c->last_algo = REPET_EXTENDED;
     c->last_n_periods = 0;
     int rc = exec_extended(c, p, first, n_seg);
+    chain.publish();
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
     if (rc == REPET_OK) end_timing(c);
@@ -1338,6 +1390,7 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, o->W, &tb));
     RP_TRY(online_ensure_windows(o, n_new));
+    ChainScope chain(c);                                         // after the (synchronising) window growth
     const int64_t plane = (o->rows_cap + kPadRows) * o->FS;      // chan_stride of X and V
     const int64_t r0 = o->Hh - o->hist_valid;                    // first valid window row
     const int64_t Tw = o->hist_valid + n_new;                    // valid rows (history + new), relative to r0
@@ -1363,7 +1416,7 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
         const int K = o->p.sim_number, KP = std::max(K, kMinIdxPitch);
         if (n_active > 0) {
             HIP_TRY(o->band.ensure((size_t)Tpad * o->LP * sizeof(float)));
-            RP_TRY(run_gram_band(c, Vnb, Tw, o->FS, o->band.as<float>(), o->B, o->LP));
+            RP_TRY(run_gram_band(c, Vnb, Tw, o->FS, o->band.as<float>(), o->B, o->LP, true));
             HIP_TRY(c->idx.ensure((size_t)n_active * KP * sizeof(int32_t)));
             HIP_TRY(c->cnt.ensure((size_t)n_active * sizeof(int32_t)));
             PeakRefine rf{};
@@ -1421,6 +1474,7 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
         o->pend_count = left;
         o->frames_done += n_new;
     }
+    chain.publish();
     HIP_TRY(hipStreamSynchronize(c->stream));
     o->emitted += n_emit;
     return REPET_OK;

@@ -61,10 +61,16 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     *reinterpret_cast<uint2*>(dst + 32) = *reinterpret_cast<const uint2*>(l);
 }
 
+// BAND: out[t][l] = row t . row t+l for 0 <= l < n_lags (pitch = band pitch), only the tiles that touch those lags;
+// blockIdx.y = clip of a batch (strides in halves / floats).
+template <bool BAND>
 __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
                                                        float* __restrict__ out, int64_t pitch,
-                                                       const int2* __restrict__ tiles) {
+                                                       const int2* __restrict__ tiles, int n_lags,
+                                                       int64_t plane_batch_stride, int64_t out_batch_stride) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    planes += blockIdx.y * plane_batch_stride;
+    out += blockIdx.y * out_batch_stride;
     const int2 tile = tiles[blockIdx.x];
     const int bi = tile.x, bj = tile.y;
     if (bi < 0) return;
@@ -197,8 +203,14 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
                 acc[m][n][r] *= kUnscale;
                 const int64_t gi = gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int64_t gj = gj0 + n * 32 + lr;
-                if (gi < T && gj < T) out[gi * pitch + gj] = acc[m][n][r];
+                if (BAND) {
+                    const int64_t lag = gj - gi;
+                    if (gi < T && gj < T && lag >= 0 && lag < n_lags) out[gi * pitch + lag] = acc[m][n][r];
+                } else {
+                    if (gi < T && gj < T) out[gi * pitch + gj] = acc[m][n][r];
+                }
             }
+    if (BAND) return;
     if (bi != bj) {
         // mirror: transpose this wave's 64x64 block through a private LDS patch (pitch 65 floats = 16,640 B per
         // wave, 66,560 B in all: the launch asks for that much). Every wave must be done with the tile buffers.
@@ -237,11 +249,24 @@ hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipSt
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
-    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_f16_kernel),
+    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_f16_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gram_f16_kernel, dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
-                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles);
+    hipLaunchKernelGGL(gram_f16_kernel<false>, dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
+                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0);
+    return hipGetLastError();
+}
+
+hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
+                                const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
+                                int64_t band_batch_stride, hipStream_t s) {
+    if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
+    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_f16_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kGramF16LdsAsk);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(gram_f16_kernel<true>, dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
+                       kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
+                       plane_batch_stride, band_batch_stride);
     return hipGetLastError();
 }
 
