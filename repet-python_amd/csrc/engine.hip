@@ -1104,7 +1104,7 @@ int repet_selfsim(repet_ctx* c, const float* v, int64_t T, int32_t F, float* s_o
     HIP_TRY(hipMemsetAsync(c->Vn.p, 0, (size_t)Tpad * FS * sizeof(float), c->stream));
     HIP_TRY(launch_unit_rows(c->tmp_a.as<float>(), c->Vn.as<float>(), T, F, FS, c->stream));
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, FS, c->S.as<float>(), TS));
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, FS, c->S.as<float>(), TS, true));   // unit rows: same kernel as `sim`
     return d2h_pitched(c, s_out, c->S.as<float>(), TS, T, T);
 }
 

@@ -199,38 +199,58 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[m][n][r] *= kUnscale;
-                const int64_t gi = gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int64_t gj = gj0 + n * 32 + lr;
-                if (BAND) {
-                    const int64_t lag = gj - gi;
-                    if (gi < T && gj < T && lag >= 0 && lag < n_lags) out[gi * pitch + lag] = acc[m][n][r];
-                } else {
-                    if (gi < T && gj < T) out[gi * pitch + gj] = acc[m][n][r];
-                }
-            }
-    if (BAND) return;
-    if (bi != bj) {
-        // mirror: transpose this wave's 64x64 block through a private LDS patch (pitch 65 floats = 16,640 B per
-        // wave, 66,560 B in all: the launch asks for that much). Every wave must be done with the tile buffers.
-        __syncthreads();
-        float* patch = reinterpret_cast<float*>(ldsh) + wave * (64 * 65);
+            for (int r = 0; r < 16; ++r) acc[m][n][r] *= kUnscale;
+    if (BAND || bi != bj) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int j = n * 32 + lr;
-                    patch[j * 65 + i] = acc[m][n][r];
+                    const int64_t gi = gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int64_t gj = gj0 + n * 32 + lr;
+                    if (BAND) {
+                        const int64_t lag = gj - gi;
+                        if (gi < T && gj < T && lag >= 0 && lag < n_lags) out[gi * pitch + lag] = acc[m][n][r];
+                    } else {
+                        if (gi < T && gj < T) out[gi * pitch + gj] = acc[m][n][r];
+                    }
                 }
+    }
+    if (BAND) return;
+    // Every wave's 64x64 block goes through an LDS patch (pitch 65 floats = 16,640 B per wave, 66,560 B in all: the
+    // launch asks for that much). The patches alias the tile buffers: wait until every wave is done with them.
+    __syncthreads();
+    float* patches = reinterpret_cast<float*>(ldsh);
+    float* patch = patches + wave * (64 * 65);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int j = n * 32 + lr;
+                patch[j * 65 + i] = acc[m][n][r];
+            }
+    if (bi != bj) {
+        // mirror of an off-diagonal tile: the transposed block, straight from this wave's own patch
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the patch is wave-private
         __builtin_amdgcn_wave_barrier();
         for (int j = 0; j < 64; ++j) {
             const int64_t gj = gj0 + j, gi = gi0 + lane;
             if (gj < T && gi < T) out[gj * pitch + gi] = patch[j * 65 + lane];
+        }
+    } else {
+        // diagonal tile: hi hi' + hi lo' + lo hi' is accumulated in a different order for (i, j) and (j, i), so the
+        // two differ in the last bit. S is stored exactly symmetric: both take the value computed for i <= j.
+        __syncthreads();
+        const float* upper = patches + (wc * 2 + wr) * (64 * 65);     // block (wc, wr): holds T(J, I) for this block's (I, J)
+        for (int i = 0; i < 64; ++i) {
+            const int I = wr * 64 + i, J = wc * 64 + lane;
+            const float v = (I <= J) ? patch[lane * 65 + i] : upper[i * 65 + lane];
+            const int64_t gi = gi0 + i, gj = gj0 + lane;
+            if (gi < T && gj < T) out[gi * pitch + gj] = v;
         }
     }
 }
