@@ -473,24 +473,26 @@ int ensure_chunk_events(repet_ctx* c, int n) {
 }
 
 // Near-tie refinement of the peak picking (peaks.hip): the tolerance inside which an fp32 similarity is not
-// trusted. The fp32 MFMA Gram accumulates FS products of unit-vector components, an error random walk of about
-// sqrt(FS) * 2^-24 (measured on MI355X at FS = 1056: rms 3.8e-7, largest 5.9e-6 of 3e6 entries). delta is 4x that
-// estimate (7.7e-6 at FS = 1056): on the probe clips of tools/refine_probe.py 4x, 8x and 16x give identical index
-// lists (0, 0, 0 and 1 rows of 8062 differ from the float64 oracle; plain fp32: 71, 31, 35, 110) and 2x loses one
-// more row, while the cost grows with delta (cfg 2: +0.10 ms at 4x, +0.26 ms at 16x).
-// REPET_PEAK_REFINE=0 turns the refinement off (plain fp32 decisions); REPET_PEAK_DELTA_SCALE overrides the 4.
-float peak_refine_delta(int FS, int d) {
+// trusted, delta = scale * sqrt(FS) * 2^-24 (an error random walk over the FS products of unit-vector components).
+// Measured against float64 on MI355X at FS = 1056 (tools/refine_probe.py --ambiguity):
+//   exact-fp32 MFMA chain : rms 3.8e-7, max 5.9e-6  -> scale 4 (7.7e-6); 4x, 8x, 16x give identical index lists
+//                           (0, 0, 0, 1 of 8062 rows differ from the float64 oracle; plain fp32: 71, 31, 35, 110),
+//                           2x loses one more row
+//   f16-split Gram kernel : rms 1.3e-7, max 1.1e-6  -> scale 2 (3.9e-6); 1x, 2x and 4x give identical lists
+// The cost grows with delta (cfg 2, f16 Gram: peaks 0.28 / 0.30 / 0.34 ms at 1x / 2x / 4x).
+// REPET_PEAK_REFINE=0 turns the refinement off (plain fp32 decisions); REPET_PEAK_DELTA_SCALE overrides the scale.
+float peak_refine_delta(int FS, bool f16_gram) {
     static const int on = [] { const char* e = getenv("REPET_PEAK_REFINE"); return e ? atoi(e) : 1; }();
-    (void)d;
     if (!on) return 0.0f;
-    static const float scale = [] { const char* e = getenv("REPET_PEAK_DELTA_SCALE"); return e ? (float)atof(e) : 4.0f; }();
+    static const float forced = [] { const char* e = getenv("REPET_PEAK_DELTA_SCALE"); return e ? (float)atof(e) : 0.0f; }();
+    const float scale = forced > 0.0f ? forced : (f16_gram ? 2.0f : 4.0f);
     return scale * sqrtf((float)FS) * 5.9604645e-8f;
 }
 
-int make_refine(repet_ctx* c, const float* unit_rows, int FS, int d, double threshold, PeakRefine* rf) {
+int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, PeakRefine* rf) {
     HIP_TRY(c->refine_stats.ensure(4 * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, 4 * sizeof(unsigned int), c->stream));
-    rf->unit_rows = unit_rows; rf->pitch = FS; rf->delta = peak_refine_delta(FS, d); rf->min_value = threshold;
+    rf->unit_rows = unit_rows; rf->pitch = FS; rf->delta = peak_refine_delta(FS, gram_f16_enabled()); rf->min_value = threshold;
     rf->stats = c->refine_stats.as<unsigned int>();
     return REPET_OK;
 }
@@ -523,7 +525,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
     const int n_chunks = sim_chunks(T);
     PeakRefine rf{};
-    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_distance_frames, p->sim_threshold, &rf));
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf));
     if (n_chunks <= 1) {
         hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
                                            p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf);
@@ -596,7 +598,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->idx.ensure((size_t)nb * rows_alloc * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)nb * rows_alloc * sizeof(int32_t)));
     PeakRefine rf{};
-    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_distance_frames, p->sim_threshold, &rf));
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf));
     const PeakBatch pb{nb, band_stride, rows_alloc * KP, rows_alloc, mean_stride};
     hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
                                        p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf,
@@ -1420,7 +1422,7 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
             HIP_TRY(c->idx.ensure((size_t)n_active * KP * sizeof(int32_t)));
             HIP_TRY(c->cnt.ensure((size_t)n_active * sizeof(int32_t)));
             PeakRefine rf{};
-            RP_TRY(make_refine(c, Vnb, o->FS, o->p.sim_distance_frames, o->p.sim_threshold, &rf));
+            RP_TRY(make_refine(c, Vnb, o->FS, o->p.sim_threshold, &rf));
             hipError_t e = launch_local_maxima(o->band.as<float>(), n_active, first_active, o->B, o->LP, 1, (float)o->p.sim_threshold,
                                                o->p.sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream,
                                                first_global, &rf);
