@@ -14,6 +14,10 @@ constexpr float kMaskEps = 2.220446049250313e-16f;  // np.finfo(float).eps, repe
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for `kernel` on the current device, grow-only and under a lock: the
+// attribute is process state, and setting it per launch from several host threads races with their launches.
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
 // ---- kernel launchers (implemented in the .hip files; all asynchronous on `s`) -------------------
 
 // K1: frame + window + real FFT + magnitude (+ channel mean, unit-norm rows).

@@ -18,6 +18,21 @@
 #include <thread>
 #include <vector>
 
+namespace repet {
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex m;
+    static std::map<std::pair<int, const void*>, int> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(m);
+    int& cur = granted[std::make_pair(dev, kernel)];
+    if (bytes <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
+}  // namespace repet
+
 using namespace repet;
 
 namespace {
@@ -806,6 +821,8 @@ struct ChainScope {
     repet_ctx* c;
     bool published = false;
     explicit ChainScope(repet_ctx* ctx) : d(&g_chains[ctx->device & 15]), c(ctx) {
+        static const bool off = [] { const char* e = getenv("REPET_NO_CHAIN"); return e && atoi(e) != 0; }();   // experiments only
+        if (off) { published = true; return; }
         d->m.lock();
         if (d->have_tail) (void)hipStreamWaitEvent(c->stream, d->tail, 0);
     }

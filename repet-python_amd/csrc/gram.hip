@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ A, 
 }
 
 static hipError_t set_lds(const void* fn) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds);
+    return ensure_dynamic_lds(fn, kGramLds);
 }
 
 // Upper-triangle tile list (bj - bi < ndiag) in XCD-aware order, see gram_kernel.

@@ -269,8 +269,7 @@ hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipSt
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
-    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_f16_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kGramF16LdsAsk);
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_f16_kernel<false>, dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
                        reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0);
@@ -281,8 +280,7 @@ hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
                                 int64_t band_batch_stride, hipStream_t s) {
     if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
-    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_f16_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kGramF16LdsAsk);
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_f16_kernel<true>, dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
                        kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,

@@ -481,8 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
 
 template <int QMAX>
 static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, int n_batch, size_t bytes, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&local_maxima_kernel<QMAX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_kernel<QMAX>), (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((local_maxima_kernel<QMAX>), dim3((unsigned)n_rows, (unsigned)n_batch), dim3(256), bytes, s, a);
     return hipGetLastError();

@@ -1104,8 +1104,7 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
         return dispatch_window(a.W, [&](auto w) {
             constexpr int Wc = decltype(w)::value;
             if constexpr (Wc <= 4096) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_wave_kernel<Wc>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&stft_wave_kernel<Wc>), (int)dyn);
                 hipLaunchKernelGGL(stft_wave_kernel<Wc>, dim3((unsigned)ceil_div(a.T, fpw), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
                                    dim3(256), dyn, s, a, fpw);
             }
@@ -1155,8 +1154,7 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
         return dispatch_window(a.W, [&](auto w) {
             constexpr int Wc = decltype(w)::value;
             if constexpr (Wc <= 4096) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_wave_kernel<Wc>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw);
+                (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_wave_kernel<Wc>), (int)dynw);
                 hipLaunchKernelGGL(istft_ola_wave_kernel<Wc>, dim3((unsigned)ceil_div(hops, run), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
                                    dim3(256), dynw, s, a, run);
             }
@@ -1166,8 +1164,7 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     if (dyn > 96 * 1024) return hipErrorInvalidValue;
     return dispatch_window(a.W, [&](auto w) {
         constexpr int Wc = decltype(w)::value;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), (int)dyn);
         hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, kOlaRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
                            dim3(kFftThreads), dyn, s, a);
     });

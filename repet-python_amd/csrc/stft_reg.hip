@@ -376,8 +376,7 @@ hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t
     want = want < 7 ? 7 : (want > 31 ? 31 : want);
     const int run = (int)round_up(want + 1, FI) - 1;        // + the frame before = a whole number of rounds
     const size_t dyn = (size_t)(4 * kExPitch + kTwFloat2) * sizeof(float2) + (size_t)C * kRegN * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_reg_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_reg_kernel), (int)dyn);
     hipLaunchKernelGGL(istft_ola_reg_kernel, dim3((unsigned)ceil_div(hops, run), (unsigned)batches), dim3(256), dyn, s, a, run);
     return hipGetLastError();
 }
