@@ -11,6 +11,10 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name.startswith("_ZN5repet"):                      # not demangled (anonymous namespace): keep the readable part
+            for key in ("gram_f16_kernel", "split_f16_kernel", "stft_reg_kernel", "istft_ola_reg_kernel"):
+                if key in name:
+                    name = "repet::" + key
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name in sorted(acc):
     if not name.startswith("repet::"):
