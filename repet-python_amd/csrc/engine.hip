@@ -96,6 +96,7 @@ struct repet_ctx {
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
+    DevBuf amax;                  // largest magnitude of the matrix being split (device scalar)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
     std::map<int, std::unique_ptr<Tables>> tables;
@@ -200,6 +201,20 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
                   int B = 1, int64_t a_stride = 0, int64_t band_stride = 0) {
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
+    static const bool scaled = [] { const char* e = getenv("REPET_GRAM_BAND"); return !(e && e[0] == 'f' && e[1] == '3'); }();
+    // power spectra (beat spectrum): any range, so the split is scaled by the matrix's largest magnitude. Two extra
+    // passes over the matrix (max, split): worth it from about two rounds of tiles on (the batched segments of
+    // `extended`: 0.58 -> 0.43 ms at cfg 3), not for one clip's narrow band (0.16 -> 0.17 ms at cfg 2 / cfg 4 sizes)
+    if (!unit_rows && scaled && gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS)) {
+        const int64_t per_clip = round_up(T, kTile) * FS;
+        const int64_t count = per_clip * B;
+        HIP_TRY(c->Vh.ensure((size_t)count * 4));
+        HIP_TRY(c->amax.ensure(sizeof(float)));
+        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream, c->amax.as<float>()));
+        HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream,
+                                     c->amax.as<float>()));
+        return REPET_OK;
+    }
     if (unit_rows && gram_f16_enabled()) {
         const int64_t per_clip = round_up(T, kTile) * FS;
         if (B > 1 && a_stride != per_clip) return fail(REPET_ERR_BAD_ARG, "internal: batch stride of the unit rows");
@@ -342,12 +357,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP;
     HIP_TRY(c->band.ensure((size_t)B * band_stride * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)B * LP * sizeof(float)));
-    {
-        const int2* tiles; int n_tiles;
-        RP_TRY(get_tiles(c, T, gram_band_diagonals(hi), &tiles, &n_tiles));
-        HIP_TRY(launch_gram_band(c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, tiles, n_tiles, B, mean_stride,
-                                 band_stride, c->stream));
-    }
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, false, B, mean_stride, band_stride));
     mark(c, "gram_band", B * (4.0 * g.F * T + 4.0 * T * hi), B * 2.0 * g.F * T * hi);
     HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, B, band_stride, LP, c->stream));
     HIP_TRY(launch_periods(c->beat.as<float>(), B, LP, (int)T, p->period_lo, p->period_hi, period_slots, c->stream));
@@ -720,7 +730,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->P, &c->S, &c->band, &c->beat,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
