@@ -123,10 +123,12 @@ hipError_t launch_acorr(const float* x, int32_t R, int32_t n_cols, int32_t pitch
 
 // Windowed diagonal sums of the band: beat[w][l] = sum_{t=lo_w}^{hi_w - l} band[t][l] / ((len - l) * F)
 //   window w covers frames [start0 + w*step, start0 + w*step + len) clipped to [0,T).
+//   partial: scratch of n_batch * n_windows * band_window_chunks(T, len) * LP floats (chunk sums, fixed chunk size)
+int band_window_chunks(int64_t T, int64_t len);
 hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,
                                   int64_t start0, int64_t step, int64_t len, int32_t n_windows,
                                   float* beat, int32_t beat_pitch, int32_t n_batch, int64_t band_batch_stride,
-                                  int64_t beat_batch_stride, hipStream_t s);
+                                  int64_t beat_batch_stride, float* partial, hipStream_t s);
 
 // K7: period[c] = argmax(beat[c][lo:hi]) + 1 + lo (first max wins), hi = min(period_hi, n_lags/3).
 hipError_t launch_periods(const float* beat, int32_t n_cols, int32_t pitch, int32_t n_lags, int32_t lo,

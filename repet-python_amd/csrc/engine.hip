@@ -96,6 +96,7 @@ struct repet_ctx {
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
+    DevBuf beat_partial;          // chunk sums of the beat-spectrum windows (launch_band_window_sum)
     DevBuf amax;                  // largest magnitude of the matrix being split (device scalar)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
@@ -173,6 +174,17 @@ int get_tiles(repet_ctx* c, int64_t T, int ndiag, const int2** tiles, int* count
     }
     *tiles = c->tiles.as<int2>();
     *count = c->tiles_count;
+    return REPET_OK;
+}
+
+int run_band_window_sum(repet_ctx* c, const float* band, int64_t T, int LP, int n_lags, int n_freq, int64_t start0,
+                        int64_t step, int64_t len, int n_windows, float* beat, int beat_pitch, int n_batch,
+                        int64_t band_batch_stride, int64_t beat_batch_stride) {
+    const int nb = n_batch > 0 ? n_batch : 1;
+    const size_t need = (size_t)nb * std::max(n_windows, 1) * band_window_chunks(T, len) * LP * sizeof(float);
+    HIP_TRY(c->beat_partial.ensure(std::max<size_t>(need, 256)));
+    HIP_TRY(launch_band_window_sum(band, T, LP, n_lags, n_freq, start0, step, len, n_windows, beat, beat_pitch, n_batch,
+                                   band_batch_stride, beat_batch_stride, c->beat_partial.as<float>(), c->stream));
     return REPET_OK;
 }
 
@@ -359,7 +371,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     HIP_TRY(c->beat.ensure((size_t)B * LP * sizeof(float)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, false, B, mean_stride, band_stride));
     mark(c, "gram_band", B * (4.0 * g.F * T + 4.0 * T * hi), B * 2.0 * g.F * T * hi);
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, B, band_stride, LP, c->stream));
+    RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, B, band_stride, LP));
     HIP_TRY(launch_periods(c->beat.as<float>(), B, LP, (int)T, p->period_lo, p->period_hi, period_slots, c->stream));
     mark(c, "beat_period", B * 4.0 * T * hi, 0);
     MaskArgs m = mask_args(c, g, p->cutoff_bins);
@@ -476,7 +488,7 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
     mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
     const int64_t left = (Ls - 1 + 1) / 2;    // ceil((Ls-1)/2), repet.py:1182
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0, c->stream));
+    RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0));
     HIP_TRY(launch_periods(c->beat.as<float>(), n_win, LP, Ls, p->period_lo, p->period_hi, c->win_periods.as<int32_t>(), c->stream));
     HIP_TRY(launch_expand_periods(c->win_periods.as<int32_t>(), n_win, Hs, T, p->period_lo, c->periods.as<int32_t>(), c->stream));
     mark(c, "beat_periods", 4.0 * n_win * (double)Ls * hi, 0);
@@ -730,7 +742,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->P, &c->S, &c->band, &c->beat,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
@@ -1182,7 +1194,7 @@ int repet_beat_spectrum(repet_ctx* c, const float* p, int64_t T, int32_t F, floa
     HIP_TRY(c->band.ensure((size_t)Tpad * LP * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)LP * sizeof(float)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, FS, c->band.as<float>(), n_lags, LP));
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, n_lags, F, 0, 0, T, 1, c->beat.as<float>(), LP, 1, 0, 0, c->stream));
+    RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, n_lags, F, 0, 0, T, 1, c->beat.as<float>(), LP, 1, 0, 0));
     return d2h_pitched(c, beat_out, c->beat.as<float>(), LP, 1, n_lags);
 }
 
@@ -1200,7 +1212,7 @@ int repet_beat_spectrogram(repet_ctx* c, const float* p, int64_t T, int32_t F, i
     HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, FS, c->band.as<float>(), Ls, LP));
     const int64_t left = Ls / 2;                                     // ceil((Ls-1)/2)
-    HIP_TRY(launch_band_window_sum(c->band.as<float>(), T, LP, Ls, F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0, c->stream));
+    RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, Ls, F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0));
     std::vector<float> win((size_t)n_win * Ls);
     RP_TRY(d2h_pitched(c, win.data(), c->beat.as<float>(), LP, n_win, Ls));
     // replicate with the reference's hole (repet.py:1194-1204): frame i+Hs-1 of each step stays zero

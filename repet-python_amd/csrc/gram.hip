@@ -296,53 +296,70 @@ hipError_t launch_acorr(const float* x, int32_t R, int32_t n_cols, int32_t pitch
 }
 
 // ---- windowed diagonal sums of the band (beat spectrum / beat spectrogram) -------------------------
-// One workgroup per (window, 64-lag block); the window's rows are split over 4 waves and reduced in
-// a fixed order, so the result is bitwise reproducible.
-__global__ __launch_bounds__(256) void band_window_sum_kernel(const float* __restrict__ band, int64_t T, int LP,
-                                                              int n_lags, int n_freq, int64_t start0,
-                                                              int64_t step, int64_t len, float* beat,
-                                                              int beat_pitch, int64_t band_batch_stride,
-                                                              int64_t beat_batch_stride) {
+// beat[w][l] = sum over the window's rows of band[t][l], unbiased and averaged over F. The rows of a window are cut
+// into chunks of kBeatChunk (fixed, so the summation order -- and the result -- never depends on the launch shape):
+// pass 1 sums each chunk with one workgroup per (64-lag block, chunk, window x batch), four waves taking a quarter
+// of the chunk each; pass 2 adds the chunk sums in order. A 180-s clip's single window is 7 753 rows: one workgroup
+// per lag block took 0.7 ms for it, 31 chunks take a few tens of microseconds.
+constexpr int kBeatChunk = 256;
+
+__global__ __launch_bounds__(256) void band_chunk_sum_kernel(const float* __restrict__ band, int64_t T, int LP, int n_lags,
+                                                             int64_t start0, int64_t step, int64_t len, int n_windows,
+                                                             int n_chunks, float* __restrict__ partial,
+                                                             int64_t band_batch_stride) {
     __shared__ float part[4][64];
-    band += blockIdx.z * band_batch_stride;
-    beat += blockIdx.z * beat_batch_stride;
-    const int w = blockIdx.y;
+    const int w = blockIdx.z % n_windows, batch = blockIdx.z / n_windows;
+    const int chunk = blockIdx.y;
+    band += batch * band_batch_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = blockIdx.x * 64 + lane;
-    const int64_t a = start0 + w * step;             // first frame of the window (may be < 0)
-    int64_t lo = a < 0 ? 0 : a;
+    const int64_t a = start0 + (int64_t)w * step;    // first frame of the window (may be < 0)
+    const int64_t lo = a < 0 ? 0 : a;
     int64_t hi = a + len - 1 - l;                    // last t with t + l inside the window
     if (hi > T - 1 - l) hi = T - 1 - l;
     float sum = 0.f;
     if (l < n_lags && l < len) {
-        const int64_t rows = hi - lo + 1;
-        if (rows > 0) {
-            const int64_t chunk = ceil_div(rows, 4);
-            const int64_t t0 = lo + wave * chunk;
-            int64_t t1 = t0 + chunk;
-            if (t1 > hi + 1) t1 = hi + 1;
-            for (int64_t t = t0; t < t1; ++t) sum += band[t * LP + l];
-        }
+        const int64_t c0 = lo + (int64_t)chunk * kBeatChunk;          // this chunk: rows [c0, c0 + kBeatChunk) of the window
+        const int64_t t0 = c0 + wave * (kBeatChunk / 4);
+        int64_t t1 = t0 + kBeatChunk / 4;
+        if (t1 > hi + 1) t1 = hi + 1;
+        for (int64_t t = t0; t < t1; ++t) sum += band[t * LP + l];
     }
     part[wave][lane] = sum;
     __syncthreads();
-    if (wave == 0 && l < n_lags) {
-        const float total = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        // unbiased by the window length minus the lag (repet.py:1135-1137), mean over F (repet.py:1156)
-        beat[(int64_t)w * beat_pitch + l] = (l < len) ? total / ((float)(len - l) * (float)n_freq) : 0.f;
-    }
+    if (wave == 0 && l < n_lags)
+        partial[((int64_t)blockIdx.z * n_chunks + chunk) * LP + l] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
+__global__ __launch_bounds__(64) void band_chunk_reduce_kernel(const float* __restrict__ partial, int LP, int n_lags, int n_freq,
+                                                               int64_t len, int n_windows, int n_chunks, float* beat,
+                                                               int beat_pitch, int64_t beat_batch_stride) {
+    const int w = blockIdx.y % n_windows, batch = blockIdx.y / n_windows;
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= n_lags) return;
+    float total = 0.f;
+    for (int k = 0; k < n_chunks; ++k) total += partial[((int64_t)blockIdx.y * n_chunks + k) * LP + l];
+    // unbiased by the window length minus the lag (repet.py:1135-1137), mean over F (repet.py:1156)
+    beat[batch * beat_batch_stride + (int64_t)w * beat_pitch + l] = (l < len) ? total / ((float)(len - l) * (float)n_freq) : 0.f;
 }
 
 hipError_t launch_band_window_sum(const float* band, int64_t T, int32_t LP, int32_t n_lags, int32_t n_freq,
                                   int64_t start0, int64_t step, int64_t len, int32_t n_windows, float* beat,
                                   int32_t beat_pitch, int32_t n_batch, int64_t band_batch_stride,
-                                  int64_t beat_batch_stride, hipStream_t s) {
+                                  int64_t beat_batch_stride, float* partial, hipStream_t s) {
     if (n_windows <= 0 || n_lags <= 0) return hipSuccess;
-    hipLaunchKernelGGL(band_window_sum_kernel,
-                       dim3((unsigned)ceil_div(n_lags, 64), (unsigned)n_windows, (unsigned)(n_batch > 0 ? n_batch : 1)),
-                       dim3(256), 0, s, band, T, LP, n_lags, n_freq, start0, step, len, beat, beat_pitch,
-                       band_batch_stride, beat_batch_stride);
+    const int nb = n_batch > 0 ? n_batch : 1;
+    const int n_chunks = band_window_chunks(T, len);
+    hipLaunchKernelGGL(band_chunk_sum_kernel, dim3((unsigned)ceil_div(n_lags, 64), (unsigned)n_chunks, (unsigned)(n_windows * nb)),
+                       dim3(256), 0, s, band, T, LP, n_lags, start0, step, len, n_windows, n_chunks, partial, band_batch_stride);
+    hipLaunchKernelGGL(band_chunk_reduce_kernel, dim3((unsigned)ceil_div(n_lags, 64), (unsigned)(n_windows * nb)), dim3(64), 0, s,
+                       partial, LP, n_lags, n_freq, len, n_windows, n_chunks, beat, beat_pitch, beat_batch_stride);
     return hipGetLastError();
+}
+
+int band_window_chunks(int64_t T, int64_t len) {
+    const int64_t rows = len < T ? len : T;
+    return (int)ceil_div(rows > 0 ? rows : 1, kBeatChunk);
 }
 
 // ---- K7: period = argmax(beat[lo:hi]) + 1 + lo, first maximum wins (repet.py:1263-1289) ------------

@@ -11,6 +11,8 @@
 // mask[1..cutoff] = 1 (repet.py:185) and the multiplication into the STFT happen in the same pass.
 #include "common.h"
 
+#include <algorithm>
+
 #include <type_traits>
 
 namespace repet {
@@ -276,14 +278,30 @@ hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32
 // the segments that really contain frame s*p+q (all S for q < T-(S-1)p, else the first S-1); it is
 // computed once and applied to every segment. The period is read on the device, so the network size
 // is chosen for the smallest admissible period (most segments): max_segments = ceil(T / min_period).
+// The period is estimated on the device just before, so the number of segments n = ceil(T / p) is only known inside
+// the kernel: the network is picked THERE (one wave-uniform switch over the compiled sizes) instead of compiling the
+// launch for the shortest admissible period -- which for a 3-minute clip meant 177 > 128 "possible" segments and the
+// bisection fallback for a list that really has 107 entries (0.67 ms; 0.1 ms now).
+template <int NET>
+__device__ __forceinline__ float period_median(int n, const RowGather& g, int base_bytes, int step_bytes, int pad_bytes,
+                                               int row_bytes) {
+    // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the caller's loop
+    int n_it = n;
+    asm volatile("" : "+s"(n_it));
+    return median_of<NET>(n_it, [&](int k) {
+        return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
+}
+
+// NET > 0: the launch knows that no position has more than NET segments (short clips, the segments of `extended`) and
+// compiles that one network -- fewer registers, more waves; NET == -1: the switch described above.
 template <int NET>
 __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int* __restrict__ period_dev,
-                                                          int period_host) {
+                                                          int period_host, int parts) {
     const int bz = blockIdx.z;                  // clip of the batch (segments of `extended`)
     const int p = period_dev ? period_dev[bz] : period_host;
     const int q = blockIdx.x;
     if (q >= p) return;
-    const int c = blockIdx.y;
+    const int c = blockIdx.y % a.n_channels, part = blockIdx.y / a.n_channels;    // `parts` workgroups share the bins
     a.V += bz * a.batch_stride;
     if (a.X) a.X += bz * a.batch_stride;
     if (a.mask) a.mask += bz * a.batch_stride;
@@ -295,17 +313,20 @@ __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int*
     const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
     const int base_bytes = q * row_bytes, step_bytes = p * row_bytes;
     RowGather g{channel_rsrc(Vc, a.chan_stride), 0};
-    for (int fb = wave; fb < nfb; fb += 4) {
+    for (int fb = wave + 4 * part; fb < nfb; fb += 4 * parts) {
         const int f = fb * 64 + lane;
         const bool active = f < a.F;
         const int fc = active ? f : a.F - 1;
         g.bin_bytes = fc * 4;
-        // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the loop; hoisted, hipcc
-        // parks all NET offsets in VGPRs and halves the occupancy
-        int n_it = n;
-        asm volatile("" : "+s"(n_it));
-        const float med = median_of<NET>(n_it, [&](int k) {
-            return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
+        float med;
+        if constexpr (NET >= 0) med = period_median<NET>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else if (n <= 8) med = period_median<8>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else if (n <= 16) med = period_median<16>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else if (n <= 32) med = period_median<32>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else if (n <= 64) med = period_median<64>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else if (n <= 100) med = period_median<100>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else if (n <= 128) med = period_median<128>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        else med = period_median<0>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
         if (active)
             for (int s = 0; s < n; ++s) {
                 const int64_t t = (int64_t)s * p + q;
@@ -321,13 +342,22 @@ hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int3
     // admissible period (a third of the frames, repet.py:1266) and surplus workgroups exit
     unsigned gx = period_dev ? (unsigned)(m.T / 3 + 2) : (unsigned)period_host;
     if (gx < 1) gx = 1;
+    const int nb = m.n_batch > 0 ? m.n_batch : 1;
     const int pmin = period_dev ? (min_period > 0 ? min_period : 1) : period_host;
     const int max_segments = (int)((m.T + pmin - 1) / pmin);
-    dispatch_net(max_segments, [&](auto net) {
-        hipLaunchKernelGGL(mask_period_kernel<decltype(net)::value>,
-                           dim3(gx, (unsigned)m.n_channels, (unsigned)(m.n_batch > 0 ? m.n_batch : 1)), dim3(256), 0, s,
-                           m, period_dev, period_host);
-    });
+    // few positions x channels x clips (one long clip): let several workgroups share a position's frequency blocks
+    const int64_t useful = (int64_t)(period_dev ? std::max(min_period, 1) : period_host) * m.n_channels * nb;
+    const int nfb = (m.F + 63) >> 6;
+    int parts = 1;
+    while (parts < 4 && useful * parts < 2048 && 4 * parts < nfb) parts *= 2;
+    const dim3 grid(gx, (unsigned)(m.n_channels * parts), (unsigned)nb);
+    if (max_segments <= 32) {        // a tight bound and a small network: the single-network kernel
+        dispatch_net(max_segments, [&](auto net) {
+            hipLaunchKernelGGL(mask_period_kernel<decltype(net)::value>, grid, dim3(256), 0, s, m, period_dev, period_host, parts);
+        });
+    } else {
+        hipLaunchKernelGGL(mask_period_kernel<-1>, grid, dim3(256), 0, s, m, period_dev, period_host, parts);
+    }
     return hipGetLastError();
 }
 
