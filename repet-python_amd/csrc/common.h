@@ -154,7 +154,11 @@ struct PeakBatch { int32_t n_batch; int64_t m_stride, idx_stride, cnt_stride, un
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0,
-                               const PeakRefine* refine = nullptr, const PeakBatch* batch = nullptr);
+                               const PeakRefine* refine = nullptr, const PeakBatch* batch = nullptr,
+                               void* scratch = nullptr);
+//   scratch (nullable): local_maxima_scratch_bytes(n_rows, n_cols, d) bytes (0 for rows that fit one workgroup). With
+//           it, rows of any length are handled in segments; without it the limit is about 40 000 elements per row.
+size_t local_maxima_scratch_bytes(int64_t n_rows, int32_t n_cols, int32_t d);
 
 // K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
 // multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).

@@ -96,6 +96,7 @@ struct repet_ctx {
     int32_t n_channels = 0;
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
+    DevBuf peak_scratch;          // per-segment candidates of long similarity rows (launch_local_maxima)
     DevBuf beat_partial;          // chunk sums of the beat-spectrum windows (launch_band_window_sum)
     DevBuf amax;                  // largest magnitude of the matrix being split (device scalar)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
@@ -564,8 +565,11 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     PeakRefine rf{};
     RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf));
     if (n_chunks <= 1) {
+        const size_t scratch = local_maxima_scratch_bytes(T, (int)T, p->sim_distance_frames);
+        if (scratch > 0) HIP_TRY(c->peak_scratch.ensure(scratch));
         hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
-                                           p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf);
+                                           p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf,
+                                           nullptr, scratch > 0 ? c->peak_scratch.p : nullptr);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
         mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
@@ -742,7 +746,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }

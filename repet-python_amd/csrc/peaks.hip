@@ -50,6 +50,10 @@ struct PeakArgs {
     // near-tie refinement (see below): unit rows the similarities were computed from, or null
     const float* unit; int unit_pitch; float delta; double min_value64; unsigned int* stats;
     int64_t m_stride, idx_stride, cnt_stride, unit_stride;      // batch: blockIdx.y = clip
+    // long rows: STAGE 1 workgroups handle one segment [seg * seg_len, (seg+1) * seg_len) of the row each (blockIdx.z)
+    // and leave their candidates in cand_*[(row * n_seg + seg) * cand_cap ...]; STAGE 2 ranks a row's candidates
+    int seg_len, n_seg, cand_cap;
+    float* cand_val; int* cand_idx; int* cand_cnt;
 };
 
 constexpr int kAmbCap = 96;    // near-tied elements refined per row; a row with more keeps its fp32 decisions
@@ -106,7 +110,10 @@ __device__ __forceinline__ float nan_to_inf(float v) { return (v != v) ? INFINIT
 // The padded row lives in LDS as `groups` float4: dl = round_up(d,4) "-inf" pads, the n values, then
 // "-inf" up to the end (at least d + 4 of them). Thread `tid` owns groups tid + 256*q, q < QMAX, and
 // keeps their original values in registers.
-template <int QMAX>
+// STAGE 0: the whole row in one workgroup. STAGE 1 / 2: rows too long for that (one row of a 10-minute clip is 100 KB
+// of LDS, i.e. one workgroup per CU and 11 ms for the matrix) are cut into segments with a halo of d elements on both
+// sides: stage 1 finds (and refines) the strict maxima of one segment per workgroup, stage 2 ranks them per row.
+template <int QMAX, int STAGE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ? 4 : (QMAX <= 16 ? 2 : 1), QMAX <= 16 ? 8 : 1))) void local_maxima_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* M4 = reinterpret_cast<float4*>(smem);              // groups float4 (row, then window maxima)
@@ -121,7 +128,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     __shared__ unsigned char amb_ok[kAmbCap], amb_lose[kAmbCap];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int n = a.n, d = a.d, dl = a.dl, groups = a.groups;
+    const int n = a.n, d = a.d, dl = a.dl;
+    const int groups = (STAGE == 2) ? 0 : a.groups;      // stage 2 has no row: every row loop below is empty
     a.M += blockIdx.y * a.m_stride;
     a.idx += blockIdx.y * a.idx_stride;
     a.count += blockIdx.y * a.cnt_stride;
@@ -130,6 +138,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     const int64_t j = a.row0 + r;           // absolute row (mode 1: current frame)
     if (tid == 0) { n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0; }
     float dlt = a.delta;                    // 0: no refinement
+    const int seg = (STAGE == 1) ? (int)blockIdx.z : 0;
+    const int seg_lo = (STAGE == 1) ? seg * a.seg_len : 0;                                  // elements tested here:
+    const int seg_hi = (STAGE == 1) ? (seg_lo + a.seg_len < n ? seg_lo + a.seg_len : n) : n;   // [seg_lo, seg_hi)
     STAMP(0)
 
     auto fetch = [&](int i) -> float {      // element i of the row, -inf outside [0, n)
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     for (int q = 0; q < QMAX; ++q) {
         const int g = tid + 256 * q;
         if (g < groups) {
-            const int i0 = 4 * g - dl;
+            const int i0 = seg_lo + 4 * g - dl;       // LDS group g holds elements i0 .. i0+3 (the halo included)
             float4 v;
             if (vec_ok && i0 >= 0 && i0 + 3 < n) {
                 v = *reinterpret_cast<const float4*>(src + i0);
@@ -224,8 +235,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     for (int q = 0; q < QMAX; ++q) {
         const int g = tid + 256 * q;
         if (256 * q < groups) {             // wave-uniform guard
-            const int i0 = 4 * g - dl;      // dl is a multiple of 4: a group is all pad or starts on a real element
-            const bool real = (g < groups) && i0 >= 0 && i0 < n;
+            const int i0 = seg_lo + 4 * g - dl;   // dl, seg_lo are multiples of 4: a group is all halo/pad or starts on a tested element
+            const bool real = (g < groups) && i0 >= seg_lo && i0 < seg_hi;
             float4 left = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), right = left;
             if (real && d > 0) {
                 left = max4(read4(g, -d), read4(g, -w));
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = vals[e];
-                const bool valid = real && i0 + e < n && (v < INFINITY);
+                const bool valid = real && i0 + e < seg_hi && (v < INFINITY);
                 oks[e] = valid && (v >= a.min_value) && (v > lefts[e]) && (v > rights[e]);
                 nears[e] = false;
                 was_ok[e] = oks[e];
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
                 for (int s = 0; s < n_near; ++s) {
                     const int i = amb_idx[s];
                     // this thread's groups inside the window: one when the window spans fewer than 256 groups
-                    const int g_lo = (i - d + dl) >> 2, g_hi = (i + d + dl) >> 2;
+                    const int g_lo = (i - seg_lo - d + dl) >> 2, g_hi = (i - seg_lo + d + dl) >> 2;
                     const float lim = amb_val[s] - dlt;
                     for (int g = g_lo + ((tid - g_lo) & 255); g <= g_hi && g < groups; g += 256) {
                         const int qsel = g >> 8;
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
 #pragma unroll
                         for (int q = 1; q < QMAX; ++q) if (qsel == q) v = own[q];
                         const float vals[4] = {v.x, v.y, v.z, v.w};
-                        const int i0 = 4 * g - dl;
+                        const int i0 = seg_lo + 4 * g - dl;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int k = i0 + e;
@@ -390,6 +401,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     }
 
     STAMP(3)
+    if constexpr (STAGE == 1) {
+        // leave this segment's candidates (refined ones included) for the ranking kernel
+        const int cnt = n_peak < a.peak_cap ? n_peak : a.peak_cap;
+        const int64_t slot = r * a.n_seg + seg;
+        for (int k = tid; k < cnt; k += 256) {
+            a.cand_val[slot * a.cand_cap + k] = pval[k];
+            a.cand_idx[slot * a.cand_cap + k] = pidx[k];
+        }
+        if (tid == 0) a.cand_cnt[slot] = cnt;
+        return;
+    }
+    if constexpr (STAGE == 2) {
+        __shared__ int seg_base[65];
+        if (tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < a.n_seg; ++k) { seg_base[k] = acc; acc += a.cand_cnt[r * a.n_seg + k]; }
+            seg_base[a.n_seg] = acc;
+            n_peak = acc;
+        }
+        __syncthreads();
+        for (int k = 0; k < a.n_seg; ++k) {
+            const int cnt = seg_base[k + 1] - seg_base[k];
+            const int64_t slot = r * a.n_seg + k;
+            for (int e = tid; e < cnt; e += 256) {
+                const int to = seg_base[k] + e;
+                if (to < a.peak_cap) { pval[to] = a.cand_val[slot * a.cand_cap + e]; pidx[to] = a.cand_idx[slot * a.cand_cap + e]; }
+            }
+        }
+        __syncthreads();
+    }
     // rank by counting: value descending, higher index first on ties (np.argsort(...)[::-1])
     int np_ = n_peak;
     if (np_ > a.peak_cap) np_ = a.peak_cap;
@@ -479,18 +520,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     if (tid == 0) a.count[r] = kept;
 }
 
-template <int QMAX>
-static hipError_t launch_one(const PeakArgs& a, int64_t n_rows, int n_batch, size_t bytes, hipStream_t s) {
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_kernel<QMAX>), (int)bytes);
+template <int QMAX, int STAGE>
+static hipError_t launch_one(const PeakArgs& a, dim3 grid, size_t bytes, hipStream_t s) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_kernel<QMAX, STAGE>), (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((local_maxima_kernel<QMAX>), dim3((unsigned)n_rows, (unsigned)n_batch), dim3(256), bytes, s, a);
+    hipLaunchKernelGGL((local_maxima_kernel<QMAX, STAGE>), grid, dim3(256), bytes, s, a);
     return hipGetLastError();
+}
+
+template <int STAGE>
+static hipError_t launch_by_size(const PeakArgs& a, dim3 grid, size_t bytes, hipStream_t s) {
+    const int per_thread = (int)ceil_div(a.groups, 256);
+    if (bytes > 160 * 1024 - 4096 || per_thread > 32) return hipErrorInvalidValue;
+    if (per_thread <= 1) return launch_one<1, STAGE>(a, grid, bytes, s);
+    if (per_thread <= 2) return launch_one<2, STAGE>(a, grid, bytes, s);
+    if (per_thread <= 4) return launch_one<4, STAGE>(a, grid, bytes, s);
+    if (per_thread <= 8) return launch_one<8, STAGE>(a, grid, bytes, s);
+    if constexpr (STAGE == 0) {
+        if (per_thread <= 16) return launch_one<16, 0>(a, grid, bytes, s);
+        return launch_one<32, 0>(a, grid, bytes, s);
+    }
+    return hipErrorInvalidValue;      // segments are sized for at most 8 groups per thread
+}
+
+// Elements per segment of a long row: what 8 float4 groups per thread hold beside the two halos of d elements
+// (0: the window is too wide to segment, the whole-row kernel is used).
+static int peak_segment_length(int d) {
+    const int seg = ((8 * 256 - 3) * 4 - (int)round_up(d, 4) - d) & ~3;
+    return seg >= 2048 ? seg : 0;
+}
+
+size_t local_maxima_scratch_bytes(int64_t n_rows, int32_t n_cols, int32_t d) {
+    if (d > n_cols) d = n_cols;
+    const int seg = peak_segment_length(d);
+    if (seg == 0 || n_cols <= seg + 512) return 0;      // fits one workgroup at 8 groups per thread (or nearly)
+    const int64_t n_seg = ceil_div(n_cols, seg);
+    const int64_t cap = round_up(d > 0 ? seg / (d + 1) + 2 : seg + 1, 4);
+    return (size_t)(n_rows * n_seg * cap * 8 + n_rows * n_seg * 4 + 256);
 }
 
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift, const PeakRefine* refine,
-                               const PeakBatch* batch) {
+                               const PeakBatch* batch, void* scratch) {
     if (n_rows <= 0) return hipSuccess;
     if (d > n_cols) d = n_cols;                                       // a wider window changes nothing
     PeakArgs a{};
@@ -508,17 +580,34 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
         a.unit_stride = batch->unit_stride;
     }
     a.dl = (int)round_up(d, 4);
+    const int total_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart
+    const size_t scratch_bytes = local_maxima_scratch_bytes(n_rows, n_cols, d);
+    if (scratch && scratch_bytes > 0 && mode == 0 && n_batch == 1) {
+        // long rows: one workgroup per (row, segment) finds the maxima, a second kernel ranks them per row
+        const int seg_len = peak_segment_length(d);
+        const int n_seg = (int)ceil_div(n_cols, seg_len);
+        if (n_seg > 64) return hipErrorInvalidValue;
+        const int cap = (int)round_up(d > 0 ? seg_len / (d + 1) + 2 : seg_len + 1, 4);
+        a.seg_len = seg_len; a.n_seg = n_seg; a.cand_cap = cap;
+        a.cand_val = reinterpret_cast<float*>(scratch);
+        a.cand_idx = reinterpret_cast<int*>(a.cand_val + n_rows * n_seg * cap);
+        a.cand_cnt = a.cand_idx + n_rows * n_seg * cap;
+        PeakArgs a1 = a;
+        a1.groups = (int)(round_up(a.dl + seg_len + d, 4) / 4 + 3);
+        a1.peak_cap = cap;
+        const size_t bytes1 = (size_t)(4 * a1.groups + 2 * a1.peak_cap) * 4;
+        hipError_t e = launch_by_size<1>(a1, dim3((unsigned)n_rows, 1, (unsigned)n_seg), bytes1, s);
+        if (e != hipSuccess) return e;
+        PeakArgs a2 = a;
+        a2.peak_cap = (int)round_up(total_cap + n_seg, 4);
+        a2.groups = a2.peak_cap / 4 + 1;             // room for the ranks that reuse the row area
+        const size_t bytes2 = (size_t)(4 * a2.groups + 2 * a2.peak_cap) * 4;
+        return launch_one<1, 2>(a2, dim3((unsigned)n_rows), bytes2, s);
+    }
     a.groups = (int)(round_up(a.dl + n_cols + d, 4) / 4 + 3);      // slack for the aligned window reads past the end
-    a.peak_cap = (int)round_up(d > 0 ? n_cols / (d + 1) + 2 : n_cols + 1, 4);   // peaks are more than d apart
+    a.peak_cap = total_cap;
     const size_t bytes = (size_t)(4 * a.groups + 2 * a.peak_cap) * 4;
-    const int per_thread = (int)ceil_div(a.groups, 256);
-    if (bytes > 160 * 1024 - 64 || per_thread > 32) return hipErrorInvalidValue;
-    if (per_thread <= 1) return launch_one<1>(a, n_rows, n_batch, bytes, s);
-    if (per_thread <= 2) return launch_one<2>(a, n_rows, n_batch, bytes, s);
-    if (per_thread <= 4) return launch_one<4>(a, n_rows, n_batch, bytes, s);
-    if (per_thread <= 8) return launch_one<8>(a, n_rows, n_batch, bytes, s);
-    if (per_thread <= 16) return launch_one<16>(a, n_rows, n_batch, bytes, s);
-    return launch_one<32>(a, n_rows, n_batch, bytes, s);
+    return launch_by_size<0>(a, dim3((unsigned)n_rows, (unsigned)n_batch), bytes, s);
 }
 
 #ifdef REPET_PEAK_STAMPS

@@ -396,14 +396,31 @@ def test_two_host_threads_with_their_own_contexts():
         assert np.array_equal(a, b)
 
 
+def test_long_similarity_rows_are_picked_in_segments():
+    """Rows longer than one workgroup's LDS (about 8 600 frames) are cut into segments with a halo of the similarity
+    distance; a second kernel ranks the per-segment candidates. 310 s at 8 kHz = 9 687 frames = two segments."""
+    fs = 8000
+    x = synth(310.0, fs, 1, 17)
+    tr = orc.Trace()
+    want = orc.sim(x, fs, None, tr)
+    theirs = tr.items["similarity_indices"]
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute("sim", p)
+    got = ctx.download()
+    t = ctx.last_frame_count()
+    assert t == len(theirs) and t > 9000
+    idx, cnt = ctx.last_sim_indices(t, p.sim_number)
+    ctx.close()
+    differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(t))
+    assert differ <= max(1, 0.001 * t), differ
+    ok = ~np.isnan(want)
+    assert rms_err(got[ok], want[ok]) <= 2e-5
+
+
 def test_size_limits_and_bad_arguments_raise():
     fs = 44100
-    # peak-picking kernel keeps one similarity row in LDS: ~32.6 k frames is the documented limit for sim
-    too_long = np.zeros((34_000 * 1024, 1), dtype=np.float32)
-    too_long[::997] = 0.1
-    with pytest.raises(RuntimeError, match="too many frames"):
-        repet.sim(too_long, fs)
-    del too_long
     x = synth(4, fs, 2, 1)
     ctx = repet.Context(0)
     ctx.upload(x)
