@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(OlaArgs a) {
 // half of frame h, so it inverts frames h0-1 .. h0+RUN-1 and carries each channel's tail in LDS. The
 // time-domain frames never touch HBM and every output sample is written exactly once, coalesced over
 // the interleaved channels.
-constexpr int kOlaRun = 8;
+constexpr int kOlaRun = 8;          // hops per workgroup (16 for big batches: the frame before the run is redone per workgroup)
 template <int W>
 struct InverseTables {
     FftTwiddles<W / 2> ft;
@@ -737,7 +737,7 @@ __device__ __forceinline__ const float2* inverse_frame(const SpectrumRegs<W>& r,
 }
 
 template <int W>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_ISTFT_MIN_WAVES : 1, 8))) void istft_ola_kernel(IstftOlaArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_ISTFT_MIN_WAVES : 1, 8))) void istft_ola_kernel(IstftOlaArgs a, int run) {
     constexpr int N = W / 2;          // complex points per frame = samples per hop (H = W/2)
     constexpr int HP = N / 2;         // float2 per half frame
     __shared__ float2 buf0[N];
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     float2* tails = reinterpret_cast<float2*>(dyn);            // [C][HP] second half of the previous frame
     float* stage = dyn + (size_t)C * N;                        // [N samples][C] one hop, interleaved
     const int tid = threadIdx.x;
-    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * kOlaRun;
+    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * run;
     const float inv_n = 1.0f / (float)N;
     InverseTables<W> tables;
     inverse_tables<W>(tables, a.twiddle);
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
         }
         __syncthreads();
     }
-    for (int r = 0; r < kOlaRun; ++r) {
+    for (int r = 0; r < run; ++r) {
         const int64_t h = h0 + r;
         if (h > a.last_hop) break;
         for (int c = 0; c < C; ++c) {
@@ -1165,8 +1165,10 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     return dispatch_window(a.W, [&](auto w) {
         constexpr int Wc = decltype(w)::value;
         (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), (int)dyn);
-        hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, kOlaRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
-                           dim3(kFftThreads), dyn, s, a);
+        const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
+        const int run = hops * batches >= 8192 ? 2 * kOlaRun : kOlaRun;      // enough workgroups either way
+        hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, run), (unsigned)batches),
+                           dim3(kFftThreads), dyn, s, a, run);
     });
 }
 
