@@ -349,13 +349,18 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
                 raw1[i] = *reinterpret_cast<const float2*>(base + (2 * m + 1) * C);
             }
         } else {
-            const float2 zero = make_float2(0.f, 0.f);
+            // out-of-range samples read sample 0 of the clip and are zeroed by value: selecting between the global
+            // address and the address of a local zero would put that zero in scratch and turn the loads into flat ones
+            const float* clip = a.audio + (a.sample_offset * C + c);
 #pragma unroll
             for (int i = 0; i < LOADS; ++i) {
                 const int n = tid + kFftThreads * i;
                 const int64_t s0 = start + 2 * n, s1 = s0 + 1;
-                raw0[i] = (n < N && s0 >= 0 && s0 < a.n_samples) ? *reinterpret_cast<const float2*>(base + (2 * n) * C) : zero;
-                raw1[i] = (n < N && s1 >= 0 && s1 < a.n_samples) ? *reinterpret_cast<const float2*>(base + (2 * n + 1) * C) : zero;
+                const bool in0 = n < N && s0 >= 0 && s0 < a.n_samples, in1 = n < N && s1 >= 0 && s1 < a.n_samples;
+                const float2 v0 = *reinterpret_cast<const float2*>(clip + (in0 ? s0 : 0) * C);
+                const float2 v1 = *reinterpret_cast<const float2*>(clip + (in1 ? s1 : 0) * C);
+                raw0[i] = make_float2(in0 ? v0.x : 0.f, in0 ? v0.y : 0.f);
+                raw1[i] = make_float2(in1 ? v1.x : 0.f, in1 ? v1.y : 0.f);
             }
         }
     };

@@ -112,6 +112,34 @@ def test_c_client_example_compiles_against_the_header(tmp_path):
     assert exe.exists()
 
 
+def test_device_code_has_no_packed_fp32_or_scratch(tmp_path):
+    """The library is built without packed-fp32 VALU ops (csrc/Makefile NO_PK, DESIGN.md "Contexts and concurrency":
+    FFT kernels built with them were damaged by co-resident kernels of other contexts) and no kernel may touch scratch
+    memory (a spill in a hot loop costs a full memory wait; a select between a global address and the address of a local
+    turns the loads into flat ones)."""
+    import shutil
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    copy = tmp_path / "librepet_hip.so"
+    shutil.copy(_native.LIB_PATH, copy)
+    subprocess.check_call([objdump, "--offloading", str(copy)], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    bundles = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f)
+    assert bundles, "no device code objects found in librepet_hip.so"
+    spilling = set()
+    for b in bundles:
+        text = subprocess.check_output([objdump, "-d", str(tmp_path / b)], text=True)
+        assert not re.search(r"\bv_pk_(add|mul|fma)_f32\b|\bv_pk_mov_b32\b", text), f"packed fp32 op in {b}"
+        kernel = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel = m.group(1)
+            elif kernel and re.search(r"\bscratch_(load|store)|\bbuffer_(load|store)\S* .*s\[0:3\].*offen", line):
+                spilling.add(kernel)
+    assert not spilling, spilling
+
+
 def test_parameters_are_read_at_call_time():
     saved = repet.period_range, repet.similarity_number
     try:

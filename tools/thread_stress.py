@@ -47,15 +47,26 @@ def work(ids):
                     idx, cnt = ctx.last_sim_indices(ctx.last_frame_count(), p.sim_number)
                     rows = [int(k) for k in np.flatnonzero(np.any(idx != want_idx[i][0], axis=1) | (cnt != want_idx[i][1]))]
                     detail = [(k, idx[k, :cnt[k]].tolist(), want_idx[i][0][k, :want_idx[i][1][k]].tolist()) for k in rows[:2]]
+                if os.environ.get("REPET_STRESS_DETAIL") and len(bad) < 3:
+                    W = p.window_length
+                    rel = nz - (nz[0] // (W // 2)) * (W // 2)
+                    print("detail clip", i, "first", int(nz[0]), "W", W, "rel rows", rel[:40].tolist(), "...", rel[-8:].tolist(), flush=True)
+                    print("  residues mod 4:", np.bincount(rel % 4, minlength=4).tolist(), "diffs ch0", (y - want[i])[nz[:12], 0].tolist(),
+                          "ch1", (y - want[i])[nz[:12], 1].tolist(), flush=True)
+                    dd = (y - want[i])[nz]
+                    print("  |diff| min/median/max", float(np.abs(dd).max(axis=1).min()), float(np.median(np.abs(dd).max(axis=1))), float(np.abs(dd).max()), flush=True)
                 bad.append((r, i, float(d.max()), int(np.count_nonzero(d)), int(np.flatnonzero(d.max(axis=1))[0]), rows, detail, extra))
     ctx.close()
 
 
+import time  # noqa: E402
+_t0 = time.perf_counter()
 threads = [threading.Thread(target=work, args=(ids,)) for ids in ([[0, 2], [1, 3]] if n_threads == 2 else [[0, 1, 2, 3]])]
 for th in threads:
     th.start()
 for th in threads:
     th.join()
-print("mismatching runs:", len(bad), "of", rounds * 4, "threads", n_threads, algo)
+_dt = time.perf_counter() - _t0
+print("mismatching runs:", len(bad), "of", rounds * 4, "threads", n_threads, algo, f"-- {_dt:.1f} s, {rounds * 4 / _dt:.0f} clips/s")
 for b in bad[:10]:
     print(b)
