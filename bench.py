@@ -97,7 +97,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the REPET engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (os.environ.get("REPET_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ):   # the switch: 1-rank check of the RCCL path
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
