@@ -396,6 +396,20 @@ def test_two_host_threads_with_their_own_contexts():
         assert np.array_equal(a, b)
 
 
+def test_contexts_overlapping_on_the_device_do_not_disturb_each_other():
+    """Without the device chain (REPET_NO_CHAIN=1) the forward STFT of one context runs beside the f16-split similarity
+    kernels of another. Built with packed-fp32 VALU ops the FFT kernels lost about one result in five here (DESIGN.md
+    "Contexts and concurrency", tools/pk_pairs.py); the shipped build must lose none."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pk_pairs.py"), "600", "stft:selfsim"],
+                         env=dict(os.environ, REPET_NO_CHAIN="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "0 of 600 differ" in out.stdout, out.stdout
+
+
 def test_long_similarity_rows_are_picked_in_segments():
     """Rows longer than one workgroup's LDS (about 8 600 frames) are cut into segments with a halo of the similarity
     distance; a second kernel ranks the per-segment candidates. 310 s at 8 kHz = 9 687 frames = two segments."""
