@@ -1,15 +1,11 @@
 // Standalone reproducer (no Python, no engine) of the interaction in DESIGN.md "Contexts and concurrency": the forward
 // STFT kernel on one stream, the f16-split similarity kernels on another; every STFT result is compared with the first.
-// Link it against the library's own kernel objects, with the FFT kernels built WITH and WITHOUT packed-fp32 VALU ops:
-//   cd repet-python_amd/csrc && F="-O3 -std=c++17 -fPIC --offload-arch=gfx950"
-//   NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
-//   hipcc $F       -c stft.hip -o /tmp/stft_pk.o ; hipcc $F $NOPK -c stft.hip -o /tmp/stft_nopk.o
-//   for f in stft_reg gram gram_f16; do hipcc $F $NOPK -c $f.hip -o /tmp/$f.o; done
-//   hipcc $F -I. -c ../../tools/microbench/pk_overlap.hip -o /tmp/main.o
-//   hipcc --offload-arch=gfx950 /tmp/main.o /tmp/stft_pk.o   /tmp/stft_reg.o /tmp/gram.o /tmp/gram_f16.o -o pk_overlap_pk
-//   hipcc --offload-arch=gfx950 /tmp/main.o /tmp/stft_nopk.o /tmp/stft_reg.o /tmp/gram.o /tmp/gram_f16.o -o pk_overlap_nopk
+// `make -C repet-python_amd/csrc repro` links it against the library's own kernel objects twice: build/pk_overlap_pk has
+// the FFT kernels built WITH packed-fp32 VALU ops, build/pk_overlap_nopk the shipped ones (without).
 // usage: ./pk_overlap_pk [iterations] [aggressor: 1 = split + f16 Gram (default), 2 = split only, 3 = f16 Gram only, 4 = fp32 Gram,
-//        5..8 = nothing but v_mfma_f32_32x32x16_f16 / 32x32x8_f16 / 16x16x32_f16 / 32x32x16_bf16 on registers, 0 = none]
+//        5..8 = nothing but v_mfma_f32_32x32x16_f16 / 32x32x8_f16 / 16x16x32_f16 / 32x32x16_bf16 on registers (132 registers per wave),
+//        9 / 10 / 14 = 32x32x16_f16 with AGPR accumulators and 132 / 200 / 164 registers per wave, 11 = 200 registers rewritten by
+//        v_mov only, 12 = 32x32x16_f16 with VGPR accumulators, 13 = 32x32x8_f16 with AGPR accumulators and 200 registers, 0 = none]
 #include "common.h"
 
 #include <cmath>
