@@ -2,7 +2,10 @@
 // STFT kernel on one stream, the f16-split similarity kernels on another; every STFT result is compared with the first.
 // `make -C repet-python_amd/csrc repro` links it against the library's own kernel objects twice: build/pk_overlap_pk has
 // the FFT kernels built WITH packed-fp32 VALU ops, build/pk_overlap_nopk the shipped ones (without).
-// usage: ./pk_overlap_pk [iterations] [aggressor: 1 = split + f16 Gram (default), 2 = split only, 3 = f16 Gram only, 4 = fp32 Gram,
+// usage: ./pk_overlap_pk [iterations] [aggressor] [victim: 0 = the library's STFT kernel (default), 1 = a loop of inline-asm
+//        v_pk_fma/mul/add_f32 on registers, 2 = the same arithmetic in scalar fp32,
+//        3 = inline-asm packed butterflies exchanging through LDS]      aggressor:
+//        [ 1 = split + f16 Gram (default), 2 = split only, 3 = f16 Gram only, 4 = fp32 Gram,
 //        5..8 = nothing but v_mfma_f32_32x32x16_f16 / 32x32x8_f16 / 16x16x32_f16 / 32x32x16_bf16 on registers (132 registers per wave),
 //        9 / 10 / 14 = 32x32x16_f16 with AGPR accumulators and 132 / 200 / 164 registers per wave, 11 = 200 registers rewritten by
 //        v_mov only, 12 = 32x32x16_f16 with VGPR accumulators, 13 = 32x32x8_f16 with AGPR accumulators and 200 registers, 0 = none]
@@ -81,11 +84,61 @@ __global__ __launch_bounds__(256) void mfma_only(float* sink, int iters) {
     if (t == 12345.678f) sink[threadIdx.x] = t;
 }
 
+// Synthetic victim: nothing but packed-fp32 arithmetic on registers (KIND 0: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// written as inline asm so the build flags cannot change them; KIND 1: the same arithmetic as scalar v_fma_f32).
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(256) void pk_victim(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    floatx2 x = {in[2 * i], in[2 * i + 1]}, y = {0.25f, -0.5f}, z = {1.0f, 0.75f};
+    const floatx2 a = {0.999f, 1.001f}, b = {0.001f, -0.002f};
+    for (int k = 0; k < iters; ++k) {
+        if (KIND == 0) {
+            asm volatile("v_pk_fma_f32 %0, %0, %3, %4\n v_pk_mul_f32 %1, %1, %3\n v_pk_add_f32 %2, %2, %4\n"
+                         "v_pk_fma_f32 %1, %0, %4, %1\n v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n"
+                         : "+v"(x), "+v"(y), "+v"(z) : "v"(a), "v"(b));
+        } else {
+            x = x * a + b; y = y * a; z = z + b; y = x * b + y; x = x - z;
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+        }
+    }
+    out[2 * i] = x[0] + y[0] + z[0];
+    out[2 * i + 1] = x[1] + y[1] + z[1];
+}
+
+// Synthetic victim with LDS in the loop: radix-2-like exchanges through LDS, the arithmetic as inline-asm packed fp32.
+__global__ __launch_bounds__(256) void pk_lds_victim(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    __shared__ floatx2 buf[2][1024];
+    const int tid = threadIdx.x;
+    const float* src = in + (size_t)(blockIdx.x & 63) * 2048;
+    for (int q = 0; q < 4; ++q) buf[0][tid + 256 * q] = floatx2{src[2 * (tid + 256 * q)], src[2 * (tid + 256 * q) + 1]};
+    __syncthreads();
+    const floatx2 w = {0.70710678f, 0.70710678f}, h = {0.5f, 0.5f};
+    int cur = 0;
+    for (int k = 0; k < iters; ++k) {
+        const int p = 1 << (k % 9);
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + 256 * q, lo = i & (p - 1), j = ((i - lo) << 1) + lo;
+            floatx2 u0 = buf[cur][i], u1 = buf[cur][i + 512], s, d;
+            asm volatile("v_pk_mul_f32 %1, %1, %4\n v_pk_add_f32 %2, %0, %1\n v_pk_add_f32 %3, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n"
+                         "v_pk_mul_f32 %2, %2, %5\n v_pk_mul_f32 %3, %3, %5\n"
+                         : "+v"(u0), "+v"(u1), "=&v"(s), "=&v"(d) : "v"(w), "v"(h));
+            buf[cur ^ 1][j] = s;
+            buf[cur ^ 1][j + p] = d;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* dst = out + (size_t)blockIdx.x * 2048;
+    for (int q = 0; q < 4; ++q) { dst[2 * (tid + 256 * q)] = buf[cur][tid + 256 * q][0]; dst[2 * (tid + 256 * q) + 1] = buf[cur][tid + 256 * q][1]; }
+}
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 4000;
     const int aggressor = argc > 2 ? atoi(argv[2]) : 1;
+    const int victim = argc > 3 ? atoi(argv[3]) : 0;      // 0 = the library's STFT kernel, 1 = synthetic packed-fp32 loop, 2 = the same loop in scalar fp32
     // victim: STFT of a 9-s mono clip at 16 kHz, W = 1024, H = 512, centred
     const int W = 1024, H = 512, F = W / 2 + 1, FS = 544;
     const int64_t n = 9 * 16000;
@@ -139,8 +192,16 @@ int main(int argc, char** argv) {
     CHECK(launch_split_f16(d_rows, d_planes, (int64_t)rows.size(), sa, nullptr));
     CHECK(hipStreamSynchronize(sa));
 
+    auto launch_victim = [&]() -> hipError_t {
+        if (victim == 0) return launch_stft(a, sv);
+        // 2048 workgroups x 256 threads, one float2 each: reads d_x (n >= 2 * 2048 * 256 is not needed: indices wrap below)
+        if (victim == 1) hipLaunchKernelGGL(pk_victim<0>, dim3(256), dim3(256), 0, sv, d_x, reinterpret_cast<float*>(d_X), 3000);
+        else if (victim == 2) hipLaunchKernelGGL(pk_victim<1>, dim3(256), dim3(256), 0, sv, d_x, reinterpret_cast<float*>(d_X), 3000);
+        else hipLaunchKernelGGL(pk_lds_victim, dim3(128), dim3(256), 0, sv, d_x, reinterpret_cast<float*>(d_X), 200);
+        return hipGetLastError();
+    };
     std::vector<float2> want(chan_stride), got(chan_stride);
-    CHECK(launch_stft(a, sv));
+    CHECK(launch_victim());
     CHECK(hipStreamSynchronize(sv));
     CHECK(hipMemcpy(want.data(), d_X, chan_stride * sizeof(float2), hipMemcpyDeviceToHost));
     int bad = 0;
@@ -160,7 +221,7 @@ int main(int argc, char** argv) {
             if (aggressor == 12) hipLaunchKernelGGL(mfma_only<7>, dim3(1024), dim3(256), 0, sa, d_S, 400);
             if (aggressor == 13) hipLaunchKernelGGL(mfma_only<8>, dim3(1024), dim3(256), 0, sa, d_S, 800);
             if (aggressor == 14) hipLaunchKernelGGL(mfma_only<9>, dim3(1024), dim3(256), 0, sa, d_S, 400);
-            if (rep == 0) CHECK(launch_stft(a, sv));
+            if (rep == 0) CHECK(launch_victim());
         }
         CHECK(hipStreamSynchronize(sv));
         CHECK(hipMemcpy(got.data(), d_X, chan_stride * sizeof(float2), hipMemcpyDeviceToHost));
