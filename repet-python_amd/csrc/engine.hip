@@ -826,13 +826,12 @@ int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int3
 }
 
 namespace {
-// Pipelines of different contexts on one device run back to back on the GPU, never interleaved. Why: with two host
-// threads hammering repet.sim on their own contexts (tools/thread_stress.py) about one run in 2 000 came back with a
-// few dozen damaged samples in one hop whenever the f16-split Gram kernel of one context overlapped the other
-// context's kernels (0 of 100 000 runs with one thread, with the fp32 Gram, or with this chain); the kernel itself
-// stays inside its LDS and global allocations (guard bands change nothing). Until that interaction is understood,
-// every pipeline waits for the device's previous one: a mutex covers the ENQUEUE of a pipeline (microseconds to a
-// millisecond), the ordering itself is a stream-wait on an event, so nobody blocks on the host for GPU work.
+// REPET_CHAIN=1: pipelines of different contexts on one device run back to back on the GPU instead of interleaved. It
+// was the default while an interaction between contexts was unexplained (DESIGN.md "Contexts and concurrency": on
+// gfx950 packed-fp32 VALU results are corrupted beside another kernel's v_mfma_f32_32x32x16_f16; the library is now
+// built without packed-fp32 ops and 4 million overlapped pipelines came back clean). Interleaving is worth 14 % on
+// four 180-s clips and 1.8x on eight 30-s clips, so the chain is opt-in: a mutex covers the ENQUEUE of a pipeline,
+// the ordering itself is a stream-wait on an event, nobody blocks on the host for GPU work.
 struct DeviceChain {
     std::mutex m;
     hipEvent_t ring[8] = {};
@@ -847,8 +846,8 @@ struct ChainScope {
     repet_ctx* c;
     bool published = false;
     explicit ChainScope(repet_ctx* ctx) : d(&g_chains[ctx->device & 15]), c(ctx) {
-        static const bool off = [] { const char* e = getenv("REPET_NO_CHAIN"); return e && atoi(e) != 0; }();   // experiments only
-        if (off) { published = true; return; }
+        static const bool on = [] { const char* e = getenv("REPET_CHAIN"); return e && atoi(e) != 0; }();
+        if (!on) { published = true; return; }
         d->m.lock();
         if (d->have_tail) (void)hipStreamWaitEvent(c->stream, d->tail, 0);
     }

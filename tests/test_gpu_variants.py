@@ -397,7 +397,7 @@ def test_two_host_threads_with_their_own_contexts():
 
 
 def test_contexts_overlapping_on_the_device_do_not_disturb_each_other():
-    """Without the device chain (REPET_NO_CHAIN=1) the forward STFT of one context runs beside the f16-split similarity
+    """Pipelines of different contexts interleave on the device: the forward STFT of one context runs beside the f16-split similarity
     kernels of another. Built with packed-fp32 VALU ops the FFT kernels lost about one result in five here (DESIGN.md
     "Contexts and concurrency", tools/pk_pairs.py); the shipped build must lose none."""
     import os
@@ -405,7 +405,7 @@ def test_contexts_overlapping_on_the_device_do_not_disturb_each_other():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "pk_pairs.py"), "600", "stft:selfsim"],
-                         env=dict(os.environ, REPET_NO_CHAIN="1"), capture_output=True, text=True, timeout=300)
+                         env={k: v for k, v in os.environ.items() if k != "REPET_CHAIN"}, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "0 of 600 differ" in out.stdout, out.stdout
 
