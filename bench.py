@@ -64,6 +64,7 @@ def main():
                          "fixture under tests/golden), 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz "
                          "mono, 5 simonline 30-s clips (64 over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="config 5: one context and stream per clip instead of one batch context")
     ap.add_argument("--cpu-seconds", type=float, default=180.0,
                     help="length of the CPU-baseline clip (default: the whole config-2 clip, ~25 s of host time)")
     args = ap.parse_args()
@@ -104,7 +105,7 @@ def main():
     fs, channels = args.fs, args.channels
     params = repet.derive_params(fs)
     ctxs = []
-    batched = args.clips > 1 and args.algo == "simonline"       # equal-shape clips: every stage once over all of them
+    batched = args.clips > 1 and args.algo == "simonline" and not args.no_batch       # equal-shape clips: every stage once over all of them
     clips = []
     for k in range(args.clips):           # inputs resident in HBM (fp32, interleaved) before timing starts
         clip = example_clip if example_clip is not None else synth(args.duration, fs, channels, seed=rank * args.clips + k)
