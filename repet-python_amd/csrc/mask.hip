@@ -11,6 +11,8 @@
 // mask[1..cutoff] = 1 (repet.py:185) and the multiplication into the STFT happen in the same pass.
 #include "common.h"
 
+#include <utility>
+
 #include <algorithm>
 
 #include <type_traits>
@@ -24,11 +26,17 @@ namespace repet {
 // rest, which keeps the two middle order statistics of the n real values at wires N/2-1 and N/2.
 // (The kernels fetch the pads from two constant rows behind each channel's spectrogram, selected
 // with scalar arithmetic, so there is ONE branch-free gather whatever the list length.)
+// a[w] = load(w) for every wire, issued in the order the network first reads the wires (MedianNet<N>::kLoadOrder):
+// the first comparators start while the tail of the gather is still in flight. Indices are compile-time constants.
+template <int N, class Load, size_t... Q>
+__device__ __forceinline__ void gather_in_network_order(float (&a)[N], Load load, std::index_sequence<Q...>) {
+    ((a[MedianNet<N>::kLoadOrder[Q]] = load((int)MedianNet<N>::kLoadOrder[Q])), ...);
+}
+
 template <int N, class Load>
 __device__ __forceinline__ float median_network(int n, Load load) {
     float a[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) a[k] = load(k);
+    gather_in_network_order<N>(a, load, std::make_index_sequence<N>{});
     MedianNet<N>::run(a);
     return (n & 1) ? a[N / 2 - 1] : 0.5f * (a[N / 2 - 1] + a[N / 2]);
 }

@@ -148,6 +148,8 @@ def main():
                        "median_networks.inc")
     lines = ["// GENERATED by tools/gen_median_network.py -- do not edit.",
              "// MedianNet<N>::run(a): afterwards a[N/2-1] <= a[N/2] are the two middle order statistics.",
+             "// kLoadOrder lists the wires in the order the network first reads them: gathering in that order lets the",
+             "// first comparators start while the tail of the gather is still in flight.",
              "// A comparator is two integer min/max on the float bit patterns: every value is a non-negative float",
              "// (a magnitude), +inf or the -1.0f pad, for which signed-integer order equals float order. The asm is",
              "// volatile so the steps issue in network order: the live set stays at N values + 1 temporary (hipcc",
@@ -171,6 +173,13 @@ def main():
               f"({2 * len(ces)} before output-level pruning and min3/max3 fusion)", file=sys.stderr)
         lines.append(f"template <> struct MedianNet<{n}> {{")
         lines.append(f"    static constexpr int kInstructions = {n_instr};")
+        first = []
+        for kind, dst, srcs in ops:                 # wires in the order the network first reads them
+            for w in srcs:
+                if w not in first:
+                    first.append(w)
+        first += [w for w in range(n) if w not in first]
+        lines.append(f"    static constexpr unsigned char kLoadOrder[{n}] = {{{', '.join(str(w) for w in first)}}};")
         lines.append(f"    static __device__ __forceinline__ void run(float (&a)[{n}]) {{")
         row = []
         for kind, dst, srcs in ops:
