@@ -173,9 +173,19 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
         // parks all NET offsets in VGPRs and halves the occupancy
         int n_it = n;
         asm volatile("" : "+s"(n_it));
+        // the frame's own magnitude and spectrum bin do not depend on the median: fetch them before the network so
+        // they arrive while it runs (3 more live registers) instead of after it
+        const int64_t o = c * a.chan_stride + t * a.FS + fc;
+        const float v_own = Vc[t * a.FS + fc];
+        float2 x_own = make_float2(0.f, 0.f);
+        if (a.X) x_own = a.X[o];
         const float med = median_of<NET>(n_it, [&](int k) {
             return g(k < n_it ? list[k] * row_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
-        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
+        if (active) {
+            const float m = soft_mask(v_own, med, f, a.cutoff);
+            if (a.mask) a.mask[o] = m;
+            if (a.X) a.X[o] = make_float2(x_own.x * m, x_own.y * m);
+        }
     }
 }
 
@@ -266,9 +276,17 @@ __global__ __launch_bounds__(256) void mask_adaptive_kernel(MaskArgs a, const in
         // parks all NET offsets in VGPRs and halves the occupancy
         int n_it = n;
         asm volatile("" : "+s"(n_it));
+        const int64_t o = c * a.chan_stride + t * a.FS + fc;     // own magnitude / spectrum bin: in flight during the network
+        const float v_own = Vc[t * a.FS + fc];
+        float2 x_own = make_float2(0.f, 0.f);
+        if (a.X) x_own = a.X[o];
         const float med = median_of<NET>(n_it, [&](int k) {
             return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
-        if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
+        if (active) {
+            const float m = soft_mask(v_own, med, f, a.cutoff);
+            if (a.mask) a.mask[o] = m;
+            if (a.X) a.X[o] = make_float2(x_own.x * m, x_own.y * m);
+        }
     }
 }
 
