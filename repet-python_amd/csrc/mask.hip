@@ -353,10 +353,28 @@ __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int*
         else if (n <= 100) med = period_median<100>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
         else if (n <= 128) med = period_median<128>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
         else med = period_median<0>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        // every segment's frame at this position gets the mask of the shared model: four frames per round, all their
+        // loads first (a load -> multiply -> store chain per frame would pay the memory latency n times in a row)
         if (active)
-            for (int s = 0; s < n; ++s) {
-                const int64_t t = (int64_t)s * p + q;
-                emit(a, c, t, f, soft_mask(Vc[t * a.FS + fc], med, f, a.cutoff));
+            for (int s0 = 0; s0 < n; s0 += 4) {
+                float v[4];
+                float2 x[4];
+                int64_t o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + u < n ? s0 + u : n - 1;
+                    const int64_t t = (int64_t)s * p + q;
+                    o[u] = c * a.chan_stride + t * a.FS + f;
+                    v[u] = Vc[t * a.FS + f];
+                    x[u] = a.X ? a.X[o[u]] : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (s0 + u >= n) break;
+                    const float m = soft_mask(v[u], med, f, a.cutoff);
+                    if (a.mask) a.mask[o[u]] = m;
+                    if (a.X) a.X[o[u]] = make_float2(x[u].x * m, x[u].y * m);
+                }
             }
     }
 }
