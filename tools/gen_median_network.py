@@ -179,6 +179,7 @@ def main():
                 if w not in first:
                     first.append(w)
         first += [w for w in range(n) if w not in first]
+        assert sorted(first) == list(range(n)), n
         lines.append(f"    static constexpr unsigned char kLoadOrder[{n}] = {{{', '.join(str(w) for w in first)}}};")
         lines.append(f"    static __device__ __forceinline__ void run(float (&a)[{n}]) {{")
         row = []
