@@ -60,9 +60,10 @@ def main():
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--clips", type=int, default=1, help="independent clips per rank and step (config 5: 64 in total)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5],
-                    help="BASELINE.json configs[i-1]: 1 original on the reference's 23-s example clip (replayed from the PCM "
-                         "fixture under tests/golden), 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz "
+                    help="BASELINE.json configs[i-1]: 1 original on the reference's 23-s example clip (--wav, only where the "
+                         "reference tree is present), 2 sim 180 s (headline), 3 extended 600 s, 4 adaptive 300 s 48 kHz "
                          "mono, 5 simonline 30-s clips (64 over all ranks)")
+    ap.add_argument("--wav", default="/root/reference/audio_file.wav", help="config 1: the reference's example clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="config 5: one context and stream per clip instead of one batch context")
     ap.add_argument("--cpu-seconds", type=float, default=180.0,
@@ -71,9 +72,10 @@ def main():
 
     example_clip = None
     if args.config == 1:
-        import numpy
-        with numpy.load(os.path.join(ROOT, "tests", "golden", "cfg1_audio_pcm.npz")) as z:
-            pcm, args.fs = z["pcm"], int(z["fs"])
+        import scipy.io.wavfile            # the clip is not redistributed with this repository: build container only
+        if not os.path.exists(args.wav):
+            raise SystemExit(f"--config 1 needs the reference's example clip ({args.wav}); it is not part of this repository")
+        args.fs, pcm = scipy.io.wavfile.read(args.wav)
         example_clip = pcm / pow(2, pcm.itemsize * 8 - 1)
         args.algo, args.duration, args.channels = "original", len(pcm) / args.fs, pcm.shape[1]
     elif args.config == 3:
@@ -196,7 +198,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if example_clip is None else "the reference's example clip (tests/golden/cfg1_audio_pcm.npz)",
+            "dtype": "f32", "data": "synthetic" if example_clip is None else "the reference's example clip (audio_file.wav, read in place)",
             "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
                                    f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
                        "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,

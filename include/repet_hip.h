@@ -205,7 +205,8 @@ int repet_mask_sim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_f
 
 /* Integer intermediates of the last repet_ctx_execute (for index-set / period parity checks).
  * periods: original -> 1 value; extended -> one per segment; adaptive -> one per frame.
- * sim indices: idx[T][number] (-1 padded) + count[T]; simonline: rows for frames B-1..T-1, FRAME numbers. */
+ * sim indices: idx[T][number] (-1 padded) + count[T]; simonline: rows for frames B-1..T-1, FRAME numbers
+ * (of a batch context: n_rows = rows of one clip gives the first clip's, rows * n_clips all clips' back to back). */
 int repet_ctx_last_periods(repet_ctx* ctx, int32_t* out, int32_t capacity, int32_t* n_written);
 int repet_ctx_last_sim_indices(repet_ctx* ctx, int32_t* idx_out, int32_t* count_out, int32_t n_rows,
                                int32_t number);

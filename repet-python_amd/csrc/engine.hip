@@ -111,6 +111,7 @@ struct repet_ctx {
     int64_t last_idx_rows = 0;
     int32_t last_idx_pitch = 0;
     int32_t last_idx_number = 0;
+    int32_t last_idx_batch = 1;   // clips whose lists sit back to back in idx / cnt (batch contexts)
     // timing
     std::vector<hipEvent_t> events;
     repet_timing* timing = nullptr;
@@ -668,6 +669,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
         mark(c, "istft_ola", nb * (8.0 * g.F * g.T * g.C + 4.0 * N * g.C), 0);
     }
     c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = KP; c->last_idx_number = K;
+    c->last_idx_batch = rows >= 1 ? nb : 1;       // rows_alloc == rows then: the clips' lists are contiguous
     return REPET_OK;
 }
 
@@ -910,6 +912,7 @@ int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timin
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
+    c->last_idx_batch = 1;
     int rc = run_algo(c, algo, p);
     chain.publish();
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -929,6 +932,7 @@ int repet_ctx_execute_async(repet_ctx* c, int algo, const repet_params* p) {
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
+    c->last_idx_batch = 1;
     return run_algo(c, algo, p);
 }
 
@@ -1326,7 +1330,9 @@ int repet_ctx_last_periods(repet_ctx* c, int32_t* out, int32_t capacity, int32_t
 
 int repet_ctx_last_sim_indices(repet_ctx* c, int32_t* idx_out, int32_t* count_out, int32_t n_rows, int32_t number) {
     if (!c || !idx_out || !count_out) return fail(REPET_ERR_BAD_ARG, "null argument");
-    if (n_rows != c->last_idx_rows || number != c->last_idx_number) return fail(REPET_ERR_BAD_ARG, "shape does not match the last run");
+    // a batch context holds the lists of its clips back to back: n_rows may be rows-per-clip (first clip) or all of them
+    if ((n_rows != c->last_idx_rows && n_rows != c->last_idx_rows * c->last_idx_batch) || number != c->last_idx_number)
+        return fail(REPET_ERR_BAD_ARG, "shape does not match the last run");
     DeviceGuard guard(c->device);
     if (n_rows > 0) {
         HIP_TRY(hipMemcpy2D(idx_out, (size_t)number * sizeof(int32_t), c->idx.p, (size_t)c->last_idx_pitch * sizeof(int32_t),

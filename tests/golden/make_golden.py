@@ -225,10 +225,9 @@ def main():
             run_case(ref, name, spec, 16)
     if "cfg1" in want:
         # BASELINE.json configs[0]: the reference's own example clip (README.md:62-75), read the way its wavread
-        # does (repet.py:914-931). The int16 PCM goes into the fixture as data so the GPU box can replay it.
+        # does (repet.py:914-931). Only outputs/statistics are stored; the audio itself is not redistributed.
         import scipy.io.wavfile
         fs, pcm = scipy.io.wavfile.read("/root/reference/audio_file.wav")
-        np.savez_compressed(os.path.join(HERE, "cfg1_audio_pcm.npz"), fs=fs, pcm=pcm)
         clip = pcm / pow(2, pcm.itemsize * 8 - 1)
         run_case(ref, "cfg1_audio_file", (len(pcm) / fs, fs, pcm.shape[1], -1, 211, ALGOS), 4, clip=clip)
 

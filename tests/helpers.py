@@ -8,6 +8,7 @@ import numpy as np
 from repet_synth import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REFERENCE_WAV = "/root/reference/audio_file.wav"
 
 
 @functools.lru_cache(maxsize=8)
@@ -26,9 +27,15 @@ def golden_input(name):
     """Regenerate the clip of a fixture from the synth formula and check it against the stored
     strided samples (guards against libm differences between hosts)."""
     g = load_golden(name)
-    if name == "cfg1_audio_file":      # BASELINE.json configs[0]: the reference's example clip, stored as its int16 PCM
-        with np.load(os.path.join(GOLDEN, "cfg1_audio_pcm.npz")) as z:
-            pcm = z["pcm"]
+    if name == "cfg1_audio_file":
+        # BASELINE.json configs[0]: the reference's example clip. The audio itself is NOT in this repository (SURVEY 0:
+        # a commercial song excerpt without a licence); only statistics of the reference's outputs on it are. So this
+        # case runs where the reference tree is present (the build container) and is skipped elsewhere (the GPU box).
+        import pytest
+        if not os.path.exists(REFERENCE_WAV):
+            pytest.skip("needs %s (build container only; the clip is not redistributed)" % REFERENCE_WAV)
+        import scipy.io.wavfile
+        _, pcm = scipy.io.wavfile.read(REFERENCE_WAV)
         x = pcm / pow(2, pcm.itemsize * 8 - 1)             # what the reference's wavread returns (repet.py:929)
     else:
         x = synth(float(g["duration"]), int(g["fs"]), int(g["channels"]), int(g["seed"]))
@@ -46,45 +53,17 @@ def rms_err(a, b):
     return rms(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
 
 
-def assert_parity_modulo_near_ties(algo, x, fs, params_kwargs=None, rms_tol=1e-4, tie_tol=5e-6, strict_tol=2e-5):
-    """Parity check for the similarity variants (sim / simonline) that is honest about fp32.
-
-    The engine computes the cosine similarity in fp32 (exact-fp32 MFMA); the reference in float64. Where two
-    candidate frames are tied to ~1e-7 the peak picker may legitimately choose the other one (SURVEY 7,
-    hard part 1), and on short clips with few similar frames one such flip moves a median visibly. So:
-      1. if the plain RMS error is within `rms_tol`, done;
-      2. otherwise every frame that is in one list but not the other must be a near-tie in the ORACLE's
-         float64 similarity: within `tie_tol` of the maximum of its +-d window (the strict local-maximum
-         test flips, or an exact fp32 tie drops both candidates), of the top-K cut, or of the threshold; and
-         with the oracle forced to use the engine's index lists the outputs must agree to `strict_tol` --
-         i.e. nothing but the discrete tie decisions differs.
-    Returns the number of frames whose lists differed."""
-    import repet
-    from oracle import repet_oracle as orc
-    p = orc.Params(**(params_kwargs or {}))
-    tr = orc.Trace()
-    want = orc.ALGORITHMS[algo](np.array(x), fs, p, tr)
-    got = getattr(repet, algo)(x, fs)
-    assert got.shape == want.shape
-    assert np.array_equal(np.isnan(got), np.isnan(want))
-    ok = ~np.isnan(want)
-    err = rms_err(got[ok], want[ok])
-    if err <= rms_tol:
-        return 0
-    prm = repet.derive_params(fs)
-    ctx = repet.Context(0)
-    ctx.upload(x)
-    ctx.execute(algo, prm)
-    t = ctx.last_frame_count()
-    rows = t if algo == "sim" else max(t - prm.buffer_frames + 1, 0)
-    idx, cnt = ctx.last_sim_indices(rows, prm.sim_number)
-    ctx.close()
-    ours = [idx[r, :cnt[r]].astype(int) for r in range(rows)]
+def list_difference_gaps(algo, tr, ours, prm):
+    """Rows whose similar-frame list differs from the oracle's (trace `tr` of the oracle run), and for every frame that
+    is in one list but not the other the distance, in the ORACLE's float64 similarity, to the decision it sat on:
+    the largest other value of its +-d window (strict local-maximum test, repet.py:1318-1326), the smallest kept
+    value when the top-K cut is active (repet.py:1335-1340), or the threshold. A small gap NAMES the tie.
+    Returns (number of differing rows, [(row, frame, gap), ...])."""
     theirs = tr.items["similarity_indices"]
     dist = prm.sim_distance_frames
-    differ = 0
-    for r in range(rows):
-        a, b = set(ours[r].tolist()), set(np.asarray(theirs[r]).tolist())
+    differ, named = 0, []
+    for r in range(len(theirs)):
+        a, b = set(np.asarray(ours[r]).tolist()), set(np.asarray(theirs[r]).tolist())
         if a == b:
             continue
         differ += 1
@@ -101,11 +80,87 @@ def assert_parity_modulo_near_ties(algo, x, fs, params_kwargs=None, rms_tol=1e-4
             i = pos[f]
             lo, hi = max(i - dist, 0), min(i + dist + 1, len(vec))
             window = np.concatenate((vec[lo:i], vec[i + 1:hi]))
-            near_window_tie = len(window) > 0 and abs(np.nanmax(window) - vec[i]) <= tie_tol
-            near_cut_tie = cut is not None and abs(vec[i] - cut) <= tie_tol
-            near_threshold = abs(vec[i] - prm.sim_threshold) <= tie_tol
-            assert near_window_tie or near_cut_tie or near_threshold, (r, f, vec[i], sorted(a ^ b))
+            gap_window = abs(np.nanmax(window) - vec[i]) if len(window) > 0 else np.inf
+            gap_cut = abs(vec[i] - cut) if cut is not None else np.inf
+            gap_thr = abs(vec[i] - prm.sim_threshold)
+            named.append((r, int(f), float(min(gap_window, gap_cut, gap_thr))))
+    return differ, named
+
+
+class ParityOutcome(int):
+    """What assert_parity_modulo_near_ties found: the int value is the number of frames whose lists differed;
+    `.branch` says which bar was met -- "strict" (plain RMS <= rms_tol, the north-star bar) or "ties" (the
+    diagnostic fallback) -- and `.rms` is the plain RMS error either way."""
+    def __new__(cls, differ, branch, rms):
+        o = super().__new__(cls, differ)
+        o.branch, o.rms = branch, rms
+        return o
+
+
+def assert_parity_modulo_near_ties(algo, x, fs, params_kwargs=None, rms_tol=1e-4, tie_tol=5e-6, strict_tol=2e-5,
+                                   require_strict=True):
+    """Parity check for the similarity variants (sim / simonline).
+
+    The bar is the north star's: plain RMS error of background_signal <= `rms_tol` (1e-4). With the float64
+    near-tie refinement in the peak kernel (peaks.hip) the engine's similar-frame lists are the reference's, so
+    that bar is REQUIRED by default (`require_strict=True`): when it is missed the test fails, and the tie
+    analysis below only runs to say why (which frames differ, and whether each is a float64 near-tie).
+
+    `require_strict=False` keeps the old two-way policy for inputs where a tie can be NAMED (a similarity
+    threshold that sits exactly on float64 rounding, similarity_distance = 0 with 300 candidates):
+      1. plain RMS within `rms_tol` -> branch "strict";
+      2. otherwise every frame that is in one list but not the other must be a near-tie in the ORACLE's
+         float64 similarity (within `tie_tol` of the maximum of its +-d window, of the top-K cut, or of the
+         threshold), and with the oracle forced to use the engine's lists the outputs must agree to
+         `strict_tol` -> branch "ties".
+    Returns a ParityOutcome (int = number of frames whose lists differed, .branch, .rms)."""
+    import repet
+    from oracle import repet_oracle as orc
+    p = orc.Params(**(params_kwargs or {}))
+    tr = orc.Trace()
+    want = orc.ALGORITHMS[algo](np.array(x), fs, p, tr)
+    got = getattr(repet, algo)(x, fs)
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    err = rms_err(got[ok], want[ok])
+    if err <= rms_tol:
+        return ParityOutcome(0, "strict", err)
+    prm = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute(algo, prm)
+    t = ctx.last_frame_count()
+    rows = t if algo == "sim" else max(t - prm.buffer_frames + 1, 0)
+    idx, cnt = ctx.last_sim_indices(rows, prm.sim_number)
+    stats = ctx.last_refine_stats()
+    ctx.close()
+    ours = [idx[r, :cnt[r]].astype(int) for r in range(rows)]
+    differ, named = list_difference_gaps(algo, tr, ours, prm)
+    if not require_strict:
+        for r, f, gap in named:
+            assert gap <= tie_tol, (r, f, gap)
+    if require_strict:
+        raise AssertionError(f"{algo}: rms {err:.3e} > {rms_tol:g}; {differ} of {rows} similar-frame lists differ from the "
+                             f"float64 oracle's; (row, frame, gap to the nearest tie) of the first: {named[:8]}; refine stats {stats}")
     assert differ > 0, f"rms {err:.3e} above tolerance although every index list matches"
     forced = orc.ALGORITHMS[algo](np.array(x), fs, p, None, override_indices=ours)
     assert rms_err(got[ok], forced[ok]) <= strict_tol
-    return differ
+    return ParityOutcome(differ, "ties", err)
+
+
+def periodic_clip(fs, period_hops, seconds, channels, seed=3, jitter=0.0):
+    """An EXACTLY periodic clip: one period of `period_hops` STFT hops of the synth() mixture, tiled bit for bit
+    (SURVEY 7 hard part 1: the period is a multiple of the hop, there is no noise floor between periods, so frames
+    one period apart have identical spectra and the similarity matrix holds exact ties). `jitter` > 0 adds white
+    noise of that amplitude over the whole clip: the ties become differences far below fp32 resolution."""
+    from oracle import repet_oracle as orc
+    hop = orc.window_length_for(fs) // 2
+    period = period_hops * hop
+    base = synth(period / fs, fs, channels, seed)
+    assert len(base) == period
+    n = int(round(seconds * fs))
+    x = np.tile(base, (-(-n // period), 1))[:n].copy()
+    if jitter > 0:
+        x += jitter * np.random.RandomState(seed + 1).standard_normal(x.shape)
+    return x

@@ -6,7 +6,8 @@ import pytest
 
 import repet
 from repet import _native, parallel
-from helpers import assert_parity_modulo_near_ties, golden_input, load_edge_cases, load_golden, rms_err
+from helpers import (assert_parity_modulo_near_ties, golden_input, list_difference_gaps, load_edge_cases, load_golden,
+                     rms_err)
 from oracle import repet_oracle as orc
 from repet_synth import synth
 
@@ -128,17 +129,17 @@ def test_integer_intermediates_through_the_context():
     ctx.execute("adaptive", p)
     t = ctx.last_frame_count()
     got = ctx.last_periods(t)
-    assert np.sum(got != g["adaptive.periods"]) <= 2             # measured: 0 of 626
+    assert np.array_equal(got, g["adaptive.periods"])
 
     ctx.execute("sim", p)
     t = ctx.last_frame_count()
     idx, cnt = ctx.last_sim_indices(t, p.sim_number)
-    assert np.mean(cnt != g["sim.counts"]) <= 0.002
+    assert np.array_equal(cnt, g["sim.counts"])
     differ = 0
     for row, frame in zip(g["sim.indices"], g["sim.index_frames"]):
         differ += set(idx[frame, :cnt[frame]]) != set(row[row >= 0])
     # near-ties of the fp32 similarity are re-decided in float64 (peaks.hip), so the lists are the reference's
-    assert differ <= max(1, 0.005 * len(g["sim.index_frames"]))
+    assert differ == 0
 
     timing = ctx.execute("sim", p, timing=True)
     names = [s["name"] for s in timing["stages"]]
@@ -274,7 +275,7 @@ def test_sim_headline_config_properties():
     assert np.array_equal(cnt, g["sim.counts"])
     differ = sum(set(idx[f, :cnt[f]].tolist()) != set(row[row >= 0].tolist())
                  for row, f in zip(g["sim.indices"], g["sim.index_frames"]))
-    assert differ <= 1, (differ, stats)
+    assert differ == 0, (differ, stats)
     assert stats["flat_rows"] == 0 and stats["decisions_changed"] > 0
     n = (len(y) // fs) * fs
     per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, 2) ** 2, axis=1))
@@ -291,7 +292,7 @@ def test_other_rates_and_channel_counts(algo, fs, channels, seconds):
     """Window lengths 256..4096, 1-5 channels (block and per-channel kernel paths), every variant."""
     x = synth(seconds, fs, channels, 40 + channels)
     if algo in ("sim", "simonline"):
-        assert_parity_modulo_near_ties(algo, x, fs)
+        assert assert_parity_modulo_near_ties(algo, x, fs).branch == "strict"       # plain RMS <= 1e-4, no tie allowance
         return
     got = getattr(repet, algo)(x, fs)
     want = orc.ALGORITHMS[algo](x, fs)
@@ -341,7 +342,7 @@ def test_gram_paths_agree():
             outs.append({k: z[k] for k in z.files})
         os.remove(out)
     assert np.array_equal(outs[0]["cnt"], outs[1]["cnt"])
-    assert np.mean(np.any(outs[0]["idx"] != outs[1]["idx"], axis=1)) <= 0.002
+    assert np.array_equal(outs[0]["idx"], outs[1]["idx"])
     assert rms_err(outs[0]["y"], outs[1]["y"]) < 5e-6
 
 
@@ -352,7 +353,7 @@ def test_long_similarity_number_uses_bisection_path():
     try:
         repet.similarity_number = 300
         repet.similarity_distance = 0.005         # 0 frames: every frame is a candidate, the 300 most similar are kept
-        assert_parity_modulo_near_ties("sim", x, fs, dict(similarity_number=300, similarity_distance=0.005))
+        assert assert_parity_modulo_near_ties("sim", x, fs, dict(similarity_number=300, similarity_distance=0.005)).branch == "strict"
         ctx = repet.Context(0)
         ctx.upload(x)
         ctx.execute("sim", repet.derive_params(fs))
@@ -428,7 +429,7 @@ def test_long_similarity_rows_are_picked_in_segments():
     idx, cnt = ctx.last_sim_indices(t, p.sim_number)
     ctx.close()
     differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(t))
-    assert differ <= max(1, 0.001 * t), differ
+    assert differ == 0, differ
     ok = ~np.isnan(want)
     assert rms_err(got[ok], want[ok]) <= 2e-5
 
@@ -503,8 +504,8 @@ def test_streaming_online_equals_offline_simonline(fs, channels, seconds, seed):
     got = np.concatenate(pieces, axis=0)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
-    # and against the oracle, like every other variant
-    assert_parity_modulo_near_ties("simonline", x, fs)
+    # and against the oracle, like every other variant: the plain 1e-4 bar
+    assert assert_parity_modulo_near_ties("simonline", x, fs).branch == "strict"
 
 
 def test_streaming_online_errors():
@@ -545,19 +546,27 @@ def test_reference_example_clip(algo):
     if algo == "extended":
         assert np.array_equal(ctx.last_periods(16), g["extended.periods"])
     if algo == "adaptive":
-        assert np.sum(ctx.last_periods(ctx.last_frame_count()) != g["adaptive.periods"]) <= 2      # measured: 0 of 992
+        assert np.array_equal(ctx.last_periods(ctx.last_frame_count()), g["adaptive.periods"])
     if algo == "sim":
         t = ctx.last_frame_count()
         idx, cnt = ctx.last_sim_indices(t, p.sim_number)
         assert t == 992 and np.array_equal(cnt, g["sim.counts"])
         differ = sum(set(idx[f, :cnt[f]].tolist()) != set(row[row >= 0].tolist())
                      for row, f in zip(g["sim.indices"], g["sim.index_frames"]))
-        assert differ <= 1
+        assert differ == 0
     if algo == "simonline":
         rows = ctx.last_frame_count() - p.buffer_frames + 1
         idx, cnt = ctx.last_sim_indices(rows, p.sim_number)
         assert np.array_equal(cnt, g["simonline.counts"])
     ctx.close()
+
+
+# Rows whose list may differ from the float64 oracle's, per case: the MEASURED count. Such a row must hold a tie that is
+# closer in the oracle's float64 similarity than the fp32 rounding of the SPECTRA the engine's float64 refinement starts
+# from (unit rows with 24-bit components: similarity error up to ~2e-7), which no refinement of the similarity can see;
+# the test names it (gap <= SPECTRA_TIE). Everything else: 0.
+LIST_DIFFER_BOUND = {("sim", 90, 16000, 4): 1}
+SPECTRA_TIE = 5e-7
 
 
 @pytest.mark.parametrize("algo,seconds,fs,channels,seed,number", [
@@ -581,12 +590,12 @@ def test_similar_frame_lists_are_the_float64_references(algo, seconds, fs, chann
     idx, cnt = ctx.last_sim_indices(len(theirs), p.sim_number)
     stats = ctx.last_refine_stats()
     ctx.close()
-    differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(len(theirs)))
-    assert differ <= max(1, 0.001 * len(theirs)), (differ, len(theirs), stats)
+    differ, named = list_difference_gaps(algo, tr, [idx[r, :cnt[r]] for r in range(len(theirs))], p)
+    assert differ <= LIST_DIFFER_BOUND.get((algo, seconds, fs, seed), 0), (differ, len(theirs), named, stats)
+    assert all(gap <= SPECTRA_TIE for _, _, gap in named), named
     assert stats["elements_refined"] > 0 and stats["flat_rows"] == 0
-    if differ == 0:
-        ok = ~np.isnan(want)
-        assert rms_err(got[ok], want[ok]) <= 2e-5          # what is left is fp32 arithmetic, not decisions
+    ok = ~np.isnan(want)
+    assert rms_err(got[ok], want[ok]) <= (2e-5 if differ == 0 else RMS_TOL)    # equal lists: fp32 arithmetic is all that is left
 
 
 def test_similar_frame_lists_with_a_wide_window(monkeypatch):
@@ -608,7 +617,7 @@ def test_similar_frame_lists_with_a_wide_window(monkeypatch):
     idx, cnt = ctx.last_sim_indices(len(theirs), p.sim_number)
     ctx.close()
     differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(len(theirs)))
-    assert differ <= 1, differ
+    assert differ == 0, differ
     assert rms_err(got, want) <= 1e-4
 
 
@@ -629,12 +638,16 @@ def test_full_size_configs_against_reference_goldens(case, algo):
     n = (len(y) // fs) * fs
     per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, y.shape[1]) ** 2, axis=1))
     if algo == "simonline":
-        # 30-s clips leave <= 10 similar frames per list, so ONE fp32 near-tie flip moves a frame's median visibly
-        # (measured: 4 of 861 frames flip, 5e-4 RMS, 0.04 peak). Require what can be required: every flip is a
-        # genuine tie in the oracle's float64 similarity and the outputs agree once the lists are the same.
-        differing = assert_parity_modulo_near_ties(algo, x, fs)
-        assert differing <= 0.02 * (ctx.last_frame_count() - p.buffer_frames + 1)
-        assert np.mean(np.abs(per_s - g[f"{algo}.rms_per_second"]) < 3e-4) >= 0.9
+        # 30-s clips leave <= 10 similar frames per list, so ONE near-tie flip would move a frame's median visibly
+        # (plain fp32 decisions: 4 of 861 frames, 5e-4 RMS). With the float64 near-tie refinement the lists are the
+        # reference's, so the plain bar holds: RMS <= 1e-4 against the oracle AND against the reference's samples.
+        outcome = assert_parity_modulo_near_ties(algo, x, fs)
+        assert outcome.branch == "strict" and outcome.rms <= RMS_TOL
+        assert rms_err(y[::stride], g[f"{algo}.samples"]) <= RMS_TOL
+        assert np.max(np.abs(per_s - g[f"{algo}.rms_per_second"])) < 3e-4
+        rows = ctx.last_frame_count() - p.buffer_frames + 1
+        _, cnt = ctx.last_sim_indices(rows, p.sim_number)
+        assert np.array_equal(cnt, g["simonline.counts"])
     else:
         assert rms_err(y[::stride], g[f"{algo}.samples"]) <= RMS_TOL
         assert np.max(np.abs(per_s - g[f"{algo}.rms_per_second"])) < 3e-4
@@ -645,7 +658,7 @@ def test_full_size_configs_against_reference_goldens(case, algo):
         assert len(periods) == 119 and np.array_equal(periods, g["extended.periods"])
     if algo == "adaptive":
         periods = ctx.last_periods(ctx.last_frame_count())
-        assert np.sum(periods != g["adaptive.periods"]) <= 4                    # measured: 0 of 14 064 frames
+        assert np.array_equal(periods, g["adaptive.periods"])                   # all 14 064 frames
     if algo == "original":
         assert ctx.last_periods(1)[0] == int(g["original.period"])
     if algo == "simonline":

@@ -116,7 +116,8 @@ def run_case(k, algo, fs, channels, seconds, params):
                 rec["ok"] = True
                 rec["ill_conditioned"] = "similarity_threshold >= 1"
             elif algo in ("sim", "simonline") and same_nan:
-                rec["near_tie_rows"] = int(assert_parity_modulo_near_ties(algo, x, fs, params))
+                outcome = assert_parity_modulo_near_ties(algo, x, fs, params, require_strict=False)
+                rec["near_tie_rows"], rec["branch"] = int(outcome), outcome.branch
                 rec["ok"] = True
             else:
                 rec["ok"] = False

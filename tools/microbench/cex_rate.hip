@@ -1,0 +1,107 @@
+// Compare-exchange building blocks on gfx950: cycles per wave64 instruction per SIMD (8 waves/SIMD, 8 independent
+// chains per lane). Complements valu_rate.hip with the candidates for a cheaper median comparator:
+//   * v_sub_co_u32 + 2 x v_cndmask_b32 (borrow-driven select) against v_min_i32 + v_max_i32;
+//   * packed 16-bit min/max (two rank-coded bins per lane), and gfx950's v_pk_minimum3_f16 / v_pk_maximum3_f16;
+//   * cross-lane moves for an in-register column sort (ds_swizzle, v_permlane32_swap, DPP row_shr).
+// Build: hipcc --offload-arch=gfx950 -O3 cex_rate.hip -o cex_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define REP8(X) X X X X X X X X
+#define KERNEL(NAME, BODY)                                                                          \
+__global__ __launch_bounds__(512) void k_##NAME(unsigned* out, int iters) {                         \
+    unsigned a0 = threadIdx.x * 2654435761u, a1 = a0 + 11, a2 = a0 * 3 + 2, a3 = a0 ^ 0x1234, a4 = a0 + 4, a5 = a0 * 7, a6 = a0 + 6, a7 = a0 ^ 77; \
+    unsigned b = out[threadIdx.x & 3], c = out[(threadIdx.x & 3) + 4];                              \
+    for (int i = 0; i < iters; ++i) { REP8(BODY) }                                                  \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b + c;    \
+}
+#define IO : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b), "+v"(c)
+// 4 comparators per asm block on the pairs (a0,a1) (a2,a3) (a4,a5) (a6,a7)
+KERNEL(cex_minmax, asm volatile(
+    "v_min_u32 %8, %0, %1\n v_max_u32 %1, %0, %1\n v_mov_b32 %0, %8\n"
+    "v_min_u32 %8, %2, %3\n v_max_u32 %3, %2, %3\n v_mov_b32 %2, %8\n"
+    "v_min_u32 %8, %4, %5\n v_max_u32 %5, %4, %5\n v_mov_b32 %4, %8\n"
+    "v_min_u32 %8, %6, %7\n v_max_u32 %7, %6, %7\n v_mov_b32 %6, %8\n" IO);)
+KERNEL(cex_minmax_nomov, asm volatile(
+    "v_min_u32 %8, %0, %1\n v_max_u32 %9, %0, %1\n"
+    "v_min_u32 %0, %2, %3\n v_max_u32 %1, %2, %3\n"
+    "v_min_u32 %2, %4, %5\n v_max_u32 %3, %4, %5\n"
+    "v_min_u32 %4, %6, %7\n v_max_u32 %5, %6, %7\n" IO);)
+KERNEL(cex_subco_cnd, asm volatile(
+    "v_sub_co_u32 %8, vcc, %0, %1\n v_cndmask_b32 %8, %1, %0, vcc\n v_cndmask_b32 %9, %0, %1, vcc\n"
+    "v_sub_co_u32 %0, vcc, %2, %3\n v_cndmask_b32 %0, %3, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n"
+    "v_sub_co_u32 %2, vcc, %4, %5\n v_cndmask_b32 %2, %5, %4, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n"
+    "v_sub_co_u32 %4, vcc, %6, %7\n v_cndmask_b32 %4, %7, %6, vcc\n v_cndmask_b32 %5, %6, %7, vcc\n" IO : : "vcc");)
+KERNEL(cex_cmp_cnd, asm volatile(
+    "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %8, %1, %0, vcc\n v_cndmask_b32 %9, %0, %1, vcc\n"
+    "v_cmp_lt_u32 vcc, %2, %3\n v_cndmask_b32 %0, %3, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n"
+    "v_cmp_lt_u32 vcc, %4, %5\n v_cndmask_b32 %2, %5, %4, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n"
+    "v_cmp_lt_u32 vcc, %6, %7\n v_cndmask_b32 %4, %7, %6, vcc\n v_cndmask_b32 %5, %6, %7, vcc\n" IO : : "vcc");)
+#define E8(OP) OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n"
+#define E8_3(OP) OP " %0, %0, %8, %9\n" OP " %1, %1, %8, %9\n" OP " %2, %2, %8, %9\n" OP " %3, %3, %8, %9\n" OP " %4, %4, %8, %9\n" OP " %5, %5, %8, %9\n" OP " %6, %6, %8, %9\n" OP " %7, %7, %8, %9\n"
+KERNEL(sub_co, asm volatile(
+    "v_sub_co_u32 %0, vcc, %0, %8\n v_sub_co_u32 %1, vcc, %1, %8\n v_sub_co_u32 %2, vcc, %2, %8\n v_sub_co_u32 %3, vcc, %3, %8\n"
+    "v_sub_co_u32 %4, vcc, %4, %8\n v_sub_co_u32 %5, vcc, %5, %8\n v_sub_co_u32 %6, vcc, %6, %8\n v_sub_co_u32 %7, vcc, %7, %8\n" IO : : "vcc");)
+KERNEL(pk_min_u16, asm volatile(E8("v_pk_min_u16") IO);)
+KERNEL(pk_max_u16, asm volatile(E8("v_pk_max_u16") IO);)
+KERNEL(pk_min_i16, asm volatile(E8("v_pk_min_i16") IO);)
+KERNEL(pk_max_f16, asm volatile(E8("v_pk_max_f16") IO);)
+KERNEL(pk_minimum3_f16, asm volatile(E8_3("v_pk_minimum3_f16") IO);)
+KERNEL(pk_maximum3_f16, asm volatile(E8_3("v_pk_maximum3_f16") IO);)
+KERNEL(minimum3_f32, asm volatile(E8_3("v_minimum3_f32") IO);)
+KERNEL(bfi_b32, asm volatile(E8_3("v_bfi_b32") IO);)
+KERNEL(perm_b32, asm volatile(E8_3("v_perm_b32") IO);)
+KERNEL(min_u32_dpp, asm volatile(
+    "v_min_u32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "v_min_u32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "v_min_u32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "v_min_u32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n" IO);)
+KERNEL(mov_dpp, asm volatile(
+    "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" IO);)
+KERNEL(permlane32_swap, asm volatile(
+    "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+    "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n" IO);)
+KERNEL(permlane16_swap, asm volatile(
+    "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+    "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n" IO);)
+KERNEL(ds_swizzle, asm volatile(
+    "ds_swizzle_b32 %0, %0 offset:swizzle(BITMASK_PERM, \"0000p\")\n ds_swizzle_b32 %1, %1 offset:swizzle(BITMASK_PERM, \"0000p\")\n"
+    "ds_swizzle_b32 %2, %2 offset:swizzle(BITMASK_PERM, \"0000p\")\n ds_swizzle_b32 %3, %3 offset:swizzle(BITMASK_PERM, \"0000p\")\n"
+    "ds_swizzle_b32 %4, %4 offset:swizzle(BITMASK_PERM, \"0000p\")\n ds_swizzle_b32 %5, %5 offset:swizzle(BITMASK_PERM, \"0000p\")\n"
+    "ds_swizzle_b32 %6, %6 offset:swizzle(BITMASK_PERM, \"0000p\")\n ds_swizzle_b32 %7, %7 offset:swizzle(BITMASK_PERM, \"0000p\")\n"
+    "s_waitcnt lgkmcnt(0)\n" IO);)
+
+template <class K> void run(const char* name, K kern, unsigned* d, int per_iter, int units, const char* unit_name) {
+    const int iters = 2000, blocks = 256 * 4;   // 512 threads = 8 waves; 4 blocks/CU -> 8 waves/SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double per_simd = (double)blocks * 8 * iters * per_iter / 1024.0;     // wave-instructions per SIMD
+    const double ns = ms * 1e6 / per_simd;
+    printf("%-20s %8.3f ms  %5.2f cycles per wave-instr per SIMD at 2.4 GHz", name, ms, ns * 2.4);
+    if (units > 0) printf("  -> %5.2f cycles per %s", ns * 2.4 * per_iter / units, unit_name);
+    printf("\n");
+}
+int main() {
+    unsigned* d; hipMalloc(&d, 1 << 22); hipMemset(d, 0, 1 << 22);
+    run("cex min/max (+mov)", k_cex_minmax, d, 8 * 12, 8 * 4, "comparator");
+    run("cex min/max", k_cex_minmax_nomov, d, 8 * 8, 8 * 4, "comparator");
+    run("cex sub_co+2cndmask", k_cex_subco_cnd, d, 8 * 12, 8 * 4, "comparator");
+    run("cex cmp+2cndmask", k_cex_cmp_cnd, d, 8 * 12, 8 * 4, "comparator");
+    run("v_sub_co_u32", k_sub_co, d, 64, 0, "");
+    run("v_pk_min_u16", k_pk_min_u16, d, 64, 0, ""); run("v_pk_max_u16", k_pk_max_u16, d, 64, 0, "");
+    run("v_pk_min_i16", k_pk_min_i16, d, 64, 0, ""); run("v_pk_max_f16", k_pk_max_f16, d, 64, 0, "");
+    run("v_pk_minimum3_f16", k_pk_minimum3_f16, d, 64, 0, ""); run("v_pk_maximum3_f16", k_pk_maximum3_f16, d, 64, 0, "");
+    run("v_minimum3_f32", k_minimum3_f32, d, 64, 0, "");
+    run("v_bfi_b32", k_bfi_b32, d, 64, 0, ""); run("v_perm_b32", k_perm_b32, d, 64, 0, "");
+    run("v_min_u32 dpp", k_min_u32_dpp, d, 64, 0, ""); run("v_mov_b32 dpp", k_mov_dpp, d, 64, 0, "");
+    run("v_permlane32_swap", k_permlane32_swap, d, 64, 0, ""); run("v_permlane16_swap", k_permlane16_swap, d, 64, 0, "");
+    run("ds_swizzle_b32", k_ds_swizzle, d, 64 + 8, 0, "");
+    return 0;
+}
