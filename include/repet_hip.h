@@ -203,6 +203,13 @@ int repet_mask_adaptive(repet_ctx* ctx, const float* v, int64_t n_frames, int32_
 int repet_mask_sim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, const int32_t* idx,
                    const int32_t* count, int32_t number, float* mask_out);
 
+/* Rank transform behind the median of `sim` (np.median over the similar frames is a selection, repet.py:1535: it only
+ * needs the ORDER of a bin's magnitudes over the clip). v[T][F] -> codes_out[T][n] (0x0400 + number of frames whose
+ * magnitude in that bin is strictly smaller) and sorted_out[n][T] (every bin's magnitudes in ascending order), for the
+ * first n = F rounded down to a multiple of 128 bins; 1024 < n_frames <= 30720. */
+int repet_rank_columns(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, uint16_t* codes_out,
+                       float* sorted_out);
+
 /* Integer intermediates of the last repet_ctx_execute (for index-set / period parity checks).
  * periods: original -> 1 value; extended -> one per segment; adaptive -> one per frame.
  * sim indices: idx[T][number] (-1 padded) + count[T]; simonline: rows for frames B-1..T-1, FRAME numbers

@@ -170,6 +170,10 @@ struct MaskArgs {
     int64_t idx_batch_stride, cnt_batch_stride;   // mask_sim: elements between the clips' index lists / list lengths
     int64_t frame0;                          // mask_sim only: first frame row handled by this launch (streaming window)
     int64_t frame_end;                       // mask_sim only: one past the last frame row of this launch (0 = T)
+    // mask_sim, rank-domain median (rank.hip): 16-bit rank codes R[c][row][FS] (same row geometry as V, pad rows 0 /
+    // 0x7C00 at pad_row, pad_row+1) and the rank -> value table Vs[c][f][vs_pitch] of the first n_rank_cols bins of
+    // every channel. R == nullptr: select on the floats themselves.
+    const unsigned short* R; int64_t r_chan_stride; const float* Vs; int64_t vs_pitch; int32_t n_rank_cols;
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
@@ -184,6 +188,24 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
                               int32_t min_period, hipStream_t s);
+
+// Rank transform of V for the rank-domain median of `sim` (rank.hip): every column (bin f of channel c over the T
+// frames) is sorted once; R gets 0x0400 + the number of strictly smaller magnitudes of the column, Vs the sorted column.
+constexpr int kRankCodeBase = 0x0400;     // codes are positive normal f16 bit patterns (u16 order == f16 order)
+constexpr int kRankMinFrames = 1024;      // shorter clips: the selection on floats is cheap enough
+constexpr int kRankMaxFrames = 30720;     // 0x0400 + T - 1 must stay below 0x7C00 (+inf, the high pad)
+struct RankArgs {
+    const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t FS;
+    int32_t n_cols;                       // bins [0, n_cols) of every channel are ranked (a multiple of 128)
+    unsigned short* R; int64_t r_chan_stride;
+    float* Vs; int64_t vs_pitch;          // Vs[c * n_cols + f][vs_pitch], vs_pitch = round_up(T, 32)
+    unsigned short* codes;                // scratch: the codes column-major, [c * n_cols + f][vs_pitch]
+    int32_t ablate;                       // timing experiments (REPET_RANK_ABLATE): 1 = no merge phases, 2 = no rank search
+};
+bool rank_columns_supported(int64_t T);
+hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s);
+hipError_t launch_fill_rank_pad_rows(unsigned short* R, int64_t r_chan_stride, int32_t n_channels, int64_t pad_row,
+                                     int32_t FS, hipStream_t s);
 
 // elementwise helpers
 hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);

@@ -101,6 +101,9 @@ struct repet_ctx {
     DevBuf amax;                  // largest magnitude of the matrix being split (device scalar)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
+    DevBuf R, Vs, rank_codes;     // rank codes of V, the sorted columns and the column-major codes (rank-domain median of `sim`, rank.hip)
+    // geometry for which the constant median-pad rows of R are in place (they survive every run of that geometry)
+    const void* r_pads_ptr = nullptr; int64_t r_pads_stride = 0, r_pads_row = 0; int r_pads_channels = 0, r_pads_fs = 0;
     std::map<int, std::unique_ptr<Tables>> tables;
     DevBuf tiles;                 // Gram tile list of the last (nb, ndiag)
     int tiles_nb = -1, tiles_ndiag = -1, tiles_count = 0;
@@ -544,6 +547,37 @@ int sim_chunks(int64_t) {
     return forced > 1 ? forced : 1;
 }
 
+// REPET_MEDIAN=f32 keeps the selection of `sim` on the float magnitudes; default: the rank-domain form (rank.hip) when
+// the clip is long enough for it to pay (the column sort is a fixed cost, the saving grows with the list length).
+bool rank_median_enabled() {
+    static const bool on = [] { const char* e = getenv("REPET_MEDIAN"); return !(e && e[0] == 'f'); }();
+    return on;
+}
+constexpr int kRankMinList = 24;     // shortest list bound for which the column sort is worth its time
+
+// Sort every column of V and fill m's rank fields (bins [0, F-1); the lone Nyquist bin stays on the float kernel).
+int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m) {
+    const int n_cols = g.F - 1;
+    const int64_t vs_pitch = round_up(g.T, 32);
+    HIP_TRY(c->R.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned short)));
+    HIP_TRY(c->Vs.ensure((size_t)g.C * n_cols * vs_pitch * sizeof(float)));
+    HIP_TRY(c->rank_codes.ensure((size_t)g.C * n_cols * vs_pitch * sizeof(unsigned short)));
+    if (c->r_pads_ptr != c->R.p || c->r_pads_stride != g.chan_stride || c->r_pads_row != g.Tpad || c->r_pads_channels != g.C ||
+        c->r_pads_fs != g.FS) {
+        HIP_TRY(launch_fill_rank_pad_rows(c->R.as<unsigned short>(), g.chan_stride, g.C, g.Tpad, g.FS, c->stream));
+        c->r_pads_ptr = c->R.p; c->r_pads_stride = g.chan_stride; c->r_pads_row = g.Tpad; c->r_pads_channels = g.C; c->r_pads_fs = g.FS;
+    }
+    RankArgs a{};
+    a.V = c->V.as<float>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.n_cols = n_cols;
+    a.R = c->R.as<unsigned short>(); a.r_chan_stride = g.chan_stride; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
+    a.codes = c->rank_codes.as<unsigned short>();
+    HIP_TRY(launch_rank_columns(a, c->stream));
+    m->R = a.R; m->r_chan_stride = a.r_chan_stride; m->Vs = a.Vs; m->vs_pitch = vs_pitch; m->n_rank_cols = n_cols;
+    // V read, columns written / read twice / written sorted, codes written column-major, read, written frame-major
+    mark(c, "rank_columns", (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * n_cols * (double)g.T * g.C, 0);
+    return REPET_OK;
+}
+
 int exec_sim(repet_ctx* c, const repet_params* p) {
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, p->window_length, &tb));
@@ -574,7 +608,11 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
         mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
-        HIP_TRY(launch_mask_sim(mask_args(c, g, p->cutoff_bins), c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
+        MaskArgs m = mask_args(c, g, p->cutoff_bins);
+        const bool use_rank = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
+                              max_peaks >= kRankMinList && max_peaks <= 128;
+        if (use_rank) RP_TRY(run_rank_columns(c, g, &m));
+        HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
                                 c->fork_event, c->join_event));
         mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
     } else {
@@ -749,6 +787,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
+                      &c->refine_stats, &c->R, &c->Vs, &c->rank_codes,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
@@ -1317,6 +1356,28 @@ int repet_mask_sim(repet_ctx* c, const float* v, int64_t T, int32_t F, const int
     HIP_TRY(hipMemcpyAsync(c->cnt.p, count, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, number, c->stream));
     return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
+}
+
+int repet_rank_columns(repet_ctx* c, const float* v, int64_t T, int32_t F, uint16_t* codes_out, float* sorted_out) {
+    if (!c || !v || !codes_out || !sorted_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (F < 128) return fail(REPET_ERR_BAD_ARG, "needs at least 128 bins");
+    if (!rank_columns_supported(T)) return fail(REPET_ERR_LIMIT, "rank transform: 1024 < n_frames <= 30720");
+    DeviceGuard guard(c->device);
+    const int FS = (int)round_up(F, kFreqAlign), n_cols = F & ~127;
+    const int64_t rows = T + kPadRows, vs_pitch = round_up(T, 32);
+    RP_TRY(stage_matrix_in(c, c->V, v, T, F, FS, rows));
+    HIP_TRY(c->R.ensure((size_t)rows * FS * sizeof(unsigned short)));
+    c->r_pads_ptr = nullptr;                              // this export lays R out differently
+    HIP_TRY(c->Vs.ensure((size_t)n_cols * vs_pitch * sizeof(float)));
+    RankArgs a{};
+    a.V = c->V.as<float>(); a.chan_stride = rows * FS; a.n_channels = 1; a.T = T; a.FS = FS; a.n_cols = n_cols;
+    a.R = c->R.as<unsigned short>(); a.r_chan_stride = rows * FS; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
+    HIP_TRY(c->rank_codes.ensure((size_t)n_cols * vs_pitch * sizeof(unsigned short)));
+    a.codes = c->rank_codes.as<unsigned short>();
+    HIP_TRY(launch_rank_columns(a, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(codes_out, (size_t)n_cols * sizeof(uint16_t), c->R.p, (size_t)FS * sizeof(uint16_t),
+                             (size_t)n_cols * sizeof(uint16_t), T, hipMemcpyDeviceToHost, c->stream));
+    return d2h_pitched(c, sorted_out, c->Vs.as<float>(), vs_pitch, n_cols, T);
 }
 
 int repet_ctx_last_periods(repet_ctx* c, int32_t* out, int32_t capacity, int32_t* n_written) {

@@ -19,7 +19,33 @@
 
 namespace repet {
 
+#define REPET_NET MedianNet
+#define REPET_T float
+#define REPET_OP_MIN "v_min_i32"
+#define REPET_OP_MAX "v_max_i32"
+#define REPET_OP_MIN3 "v_min3_i32"
+#define REPET_OP_MAX3 "v_max3_i32"
 #include "median_networks.inc"
+#undef REPET_NET
+#undef REPET_T
+#undef REPET_OP_MIN
+#undef REPET_OP_MAX
+#undef REPET_OP_MIN3
+#undef REPET_OP_MAX3
+// the same networks on two 16-bit rank codes per register (rank.hip)
+#define REPET_NET MedianNetPk
+#define REPET_T unsigned
+#define REPET_OP_MIN "v_pk_min_u16"
+#define REPET_OP_MAX "v_pk_max_u16"
+#define REPET_OP_MIN3 "v_pk_minimum3_f16"
+#define REPET_OP_MAX3 "v_pk_maximum3_f16"
+#include "median_networks.inc"
+#undef REPET_NET
+#undef REPET_T
+#undef REPET_OP_MIN
+#undef REPET_OP_MAX
+#undef REPET_OP_MIN3
+#undef REPET_OP_MAX3
 
 // Median of n gathered values with the N-wire network. `load(k)` must return the k-th value for
 // k < n and, for n <= k < N, the pad of slot k: -1.0f for the first (N-n)/2 pad slots, +inf for the
@@ -189,6 +215,82 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
     }
 }
 
+// Rank-domain form of the kernel above (rank.hip): a wave owns 128 bins of a frame, two per lane. The gather reads one
+// dword = the 16-bit rank codes of bins (2 lane, 2 lane + 1) of a similar frame, the network runs on both bins at
+// once with packed 16-bit min/max, and the one or two middle codes of each bin are turned back into magnitudes through
+// the sorted-column table Vs. Selecting on "number of smaller values in the column" is selecting on the values, so the
+// mask is bit-identical to mask_sim_kernel's -- at half the instructions per bin and half the gather bytes.
+template <int NET, size_t... Q>
+__device__ __forceinline__ void gather_codes_in_network_order(unsigned (&w)[NET], __amdgpu_buffer_rsrc_t rsrc, int bin_bytes,
+                                                              const int* list, int n, int row_bytes, int pad_bytes,
+                                                              std::index_sequence<Q...>) {
+    ((w[MedianNetPk<NET>::kLoadOrder[Q]] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
+          rsrc, bin_bytes,
+          (int)MedianNetPk<NET>::kLoadOrder[Q] < n ? list[MedianNetPk<NET>::kLoadOrder[Q]] * row_bytes
+                                                     : pad_offset<NET>((int)MedianNetPk<NET>::kLoadOrder[Q], n, pad_bytes, row_bytes),
+          0)), ...);
+}
+
+// Scheduling: the unit of work is (channel, block of 128 bins, 4 consecutive frames) = one workgroup, one frame per
+// wave. Workgroups b and b + 8 land on the same XCD (round-robin placement), so XCD x is given the (channel, bin block)
+// combinations x, x + 8, ... one after the other, each over all frames: its L2 then holds the 2 MB of codes and the
+// 4 MB of sorted columns of ONE combination at a time instead of the whole 48 MB, and most gathers hit L2 rather than
+// the Infinity Cache. (Placement only decides speed; any placement gives the same result.)
+// Lookups: the frame's own code tells whether its magnitude is at or below the lower middle value -- then
+// min(V, median) = V and the mask is exactly 1 (about half of all cells: the frame is usually in its own list), and
+// the lane skips the scattered table reads.
+template <int NET>
+__global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
+                                                            const int* __restrict__ count, int n_quads) {
+    static_assert(NET >= 2, "the rank path has no bisection fallback");
+    // the wave number as a scalar: everything derived from it (frame, list, row offsets) then lives in SGPRs
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nfb = (a.F - 1) >> 7;                   // whole blocks of 128 bins; bin F-1: mask_sim_nyquist_kernel
+    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    const int combo = (i / n_quads) * 8 + x;
+    if (combo >= a.n_channels * nfb) return;
+    const int c = combo / nfb, fb = combo % nfb;
+    const int64_t t_end = a.frame_end > 0 ? a.frame_end : a.T;
+    const int64_t t = a.frame0 + 4 * (int64_t)(i % n_quads) + wave;
+    if (t >= t_end) return;
+    const float* Vc = a.V + c * a.chan_stride;
+    const int n = count[t];
+    const int* list = idx + t * (int64_t)idx_pitch;
+    const int row_bytes = a.FS * 2, pad_bytes = (int)a.pad_row * row_bytes;
+    const unsigned short* Rc = a.R + c * a.r_chan_stride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Rc), 0, (int)(a.r_chan_stride * 2), 0x00020000);
+    const unsigned t_last = (unsigned)(a.T - 1);
+    const int f0 = fb * 128 + 2 * lane;
+    const int64_t o = c * a.chan_stride + t * a.FS + f0;
+    const float2 v_own = *reinterpret_cast<const float2*>(Vc + t * a.FS + f0);
+    const unsigned own = *reinterpret_cast<const unsigned*>(Rc + t * a.FS + f0);
+    float4 x_own = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.X) x_own = *reinterpret_cast<const float4*>(a.X + o);
+    float med0 = __uint_as_float(0x7fc00000u), med1 = med0;              // np.median of an empty slice
+    if (n > 0) {
+        unsigned w[NET];
+        gather_codes_in_network_order<NET>(w, rsrc, f0 * 2, list, n, row_bytes, pad_bytes, std::make_index_sequence<NET>{});
+        MedianNetPk<NET>::run(w);
+        const float* vs = a.Vs + ((int64_t)c * a.n_rank_cols + f0) * a.vs_pitch;
+        const unsigned lo = w[NET / 2 - 1], hi = w[NET / 2];
+        const unsigned lo0 = lo & 0xffffu, lo1 = lo >> 16;
+        // lower middle value >= own value  =>  median >= own value  =>  mask = (V + eps) / (V + eps) = 1: any model >= V
+        // gives the same bits, so V itself stands in for it
+        med0 = v_own.x; med1 = v_own.y;
+        if (lo0 < (own & 0xffffu)) {
+            med0 = vs[min(lo0 - kRankCodeBase, t_last)];
+            if (!(n & 1)) med0 = 0.5f * (med0 + vs[min((hi & 0xffffu) - kRankCodeBase, t_last)]);
+        }
+        if (lo1 < (own >> 16)) {
+            med1 = vs[a.vs_pitch + min(lo1 - kRankCodeBase, t_last)];
+            if (!(n & 1)) med1 = 0.5f * (med1 + vs[a.vs_pitch + min((hi >> 16) - kRankCodeBase, t_last)]);
+        }
+    }
+    const float m0 = soft_mask(v_own.x, med0, f0, a.cutoff), m1 = soft_mask(v_own.y, med1, f0 + 1, a.cutoff);
+    if (a.mask) *reinterpret_cast<float2*>(a.mask + o) = make_float2(m0, m1);
+    if (a.X) *reinterpret_cast<float4*>(a.X + o) = make_float4(x_own.x * m0, x_own.y * m0, x_own.z * m1, x_own.w * m1);
+}
+
 // One lane per frame, bin F-1 only: the index list, its length and every row offset are per-lane here.
 template <int NET>
 __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
@@ -236,9 +338,21 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                                    dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
                 if (forked) (void)hipEventRecord(join, side);
             }
-            if (parts & 1)
-                hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
-                                   m, idx, idx_pitch, count, first_frame);
+            if (parts & 1) {
+                if constexpr (NET >= 2) {
+                    if (m.R != nullptr && ((m.F - 1) & 127) == 0 && nb == 1 && first_frame == 0) {
+                        const int n_quads = (int)ceil_div(n_launch, 4);
+                        const int combos = m.n_channels * ((m.F - 1) >> 7);
+                        hipLaunchKernelGGL(mask_sim_rank_kernel<NET>, dim3((unsigned)(8 * ceil_div(combos, 8) * n_quads)), dim3(256), 0, s,
+                                           m, idx, idx_pitch, count, n_quads);
+                    } else
+                        hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
+                                           m, idx, idx_pitch, count, first_frame);
+                } else {
+                    hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
+                                       m, idx, idx_pitch, count, first_frame);
+                }
+            }
             if (forked && rows > 0) (void)hipStreamWaitEvent(s, join, 0);
         } else if (parts & 1) {
             hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,

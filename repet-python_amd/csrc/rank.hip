@@ -1,0 +1,315 @@
+// Rank transform of the magnitude spectrogram for the rank-domain median of `sim` (mask.hip, mask_sim_rank_kernel).
+//
+// np.median over the similar frames of a bin (_simmask, repet.py:1511-1545) is a SELECTION: it only needs the order
+// of the values. So every column (one frequency bin over all T frames of a channel) is sorted once per clip:
+//   R[c][t][f]  = 0x0400 + number of frames whose magnitude in bin f is smaller than frame t's   (16-bit rank code)
+//   Vs[c][f][r] = the r-th smallest magnitude of bin f                                            (rank -> value)
+// The mask kernel then gathers 2-byte codes instead of 4-byte floats, runs the selection network on TWO bins per
+// register with packed 16-bit min/max (half the instructions per bin -- the kernel is VALU-issue-bound), and turns the
+// one or two middle codes back into magnitudes with a lookup in Vs. Equal magnitudes share a code (the count of
+// strictly smaller values), so the result is bit-identical to selecting on the floats. Codes start at 0x0400 so that
+// they are positive NORMAL f16 bit patterns: unsigned-integer order and f16 order agree and the three-input
+// v_pk_minimum3_f16 / v_pk_maximum3_f16 can be mixed with v_pk_min_u16 / v_pk_max_u16 (pads: 0 and 0x7C00 = +inf).
+//
+// One workgroup sorts one column: N = 2^LOG2N >= T keys (pads +inf), 32 keys per thread, bitonic network. A thread
+// first sorts its 32 contiguous keys in registers; every later merge phase runs in "trips" through LDS: a thread
+// fetches 32 keys whose indices differ in bits {0,1} and three higher bits (8 float4 loads), does up to three stages
+// in registers and stores them back; the closing trip of a phase takes bits 0..4 (five stages). The first stage of a
+// phase is the "flip" form (partner = index with all lower bits inverted), realised as an address inversion of the
+// loads, so that every comparator is ascending and no direction flags exist. LDS rows of 32 keys are padded by 4.
+#include "common.h"
+
+namespace repet {
+
+namespace {
+
+__device__ __forceinline__ void cex(unsigned& a, unsigned& b) {
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+// physical LDS index of key i: one float4 of padding behind every 32 keys (conflict-free for both trip shapes)
+__device__ __forceinline__ int phys(int i) { return i + ((i >> 5) << 2); }
+
+template <int QHI, int QLO, int HB>
+__device__ __forceinline__ void stages_high(unsigned (&r)[8][4]) {
+#pragma unroll
+    for (int q = QHI; q >= QLO; --q) {
+        const int bit = 1 << (q - HB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (!(u & bit)) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) cex(r[u][w], r[u | bit][w]);
+            }
+    }
+}
+
+// One trip over the stages QHI..QLO (all >= 5) of merge phase P. FLIP: QHI is the first stage of the phase.
+template <int LOG2N, int P, int QHI, int QLO, bool FLIP>
+__device__ __forceinline__ void trip_high(unsigned* s, int tid) {
+    constexpr int HB = QLO < LOG2N - 3 ? QLO : LOG2N - 3;      // the thread's three high bits are [HB, HB+3)
+    static_assert(HB >= 5 && QHI < HB + 3 && QLO >= HB, "stage bits must lie inside the thread's bit group");
+    const int low = tid & ((1 << (HB - 2)) - 1), high = tid >> (HB - 2);
+    const int base = (low << 2) | (high << (HB + 3));
+    unsigned r[8][4];
+    __syncthreads();                                           // the previous trip's stores
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i0 = base | (u << HB);
+        if (FLIP && ((u >> (P - 1 - HB)) & 1)) {               // upper half of a 2^P block: mirrored below bit P-1
+            const int src = (i0 ^ ((1 << (P - 1)) - 1)) & ~3;
+            const uint4 v = *reinterpret_cast<const uint4*>(s + phys(src));
+            r[u][0] = v.w; r[u][1] = v.z; r[u][2] = v.y; r[u][3] = v.x;
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4*>(s + phys(i0));
+            r[u][0] = v.x; r[u][1] = v.y; r[u][2] = v.z; r[u][3] = v.w;
+        }
+    }
+    if (FLIP) __syncthreads();                                 // mirrored reads touch other threads' keys: all read first
+    stages_high<QHI, QLO, HB>(r);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        *reinterpret_cast<uint4*>(s + phys(base | (u << HB))) = make_uint4(r[u][0], r[u][1], r[u][2], r[u][3]);
+}
+
+template <int LOG2N, int P, int QHI>
+struct HighTrips {
+    static __device__ __forceinline__ void run(unsigned* s, int tid) {
+        constexpr int QLO = QHI - 2 > 5 ? QHI - 2 : 5;
+        trip_high<LOG2N, P, QHI, QLO, QHI == P - 1>(s, tid);
+        if constexpr (QLO > 5) HighTrips<LOG2N, P, QLO - 1>::run(s, tid);
+    }
+};
+
+// stages 4..0 on 32 contiguous keys in registers
+__device__ __forceinline__ void stages_low(unsigned (&k)[32]) {
+#pragma unroll
+    for (int q = 4; q >= 0; --q) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (!(i & (1 << q))) cex(k[i], k[i | (1 << q)]);
+    }
+}
+
+__device__ __forceinline__ void load_run(const unsigned* s, int tid, unsigned (&k)[32]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const uint4 x = *reinterpret_cast<const uint4*>(s + phys(tid * 32 + v * 4));
+        k[4 * v] = x.x; k[4 * v + 1] = x.y; k[4 * v + 2] = x.z; k[4 * v + 3] = x.w;
+    }
+}
+__device__ __forceinline__ void store_run(unsigned* s, int tid, const unsigned (&k)[32]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+        *reinterpret_cast<uint4*>(s + phys(tid * 32 + v * 4)) = make_uint4(k[4 * v], k[4 * v + 1], k[4 * v + 2], k[4 * v + 3]);
+}
+
+template <int LOG2N, int P>
+struct Phases {
+    static __device__ __forceinline__ void run(unsigned* s, int tid, unsigned (&k)[32]) {
+        HighTrips<LOG2N, P, P - 1>::run(s, tid);
+        __syncthreads();
+        load_run(s, tid, k);
+        stages_low(k);
+        store_run(s, tid, k);
+        if constexpr (P < LOG2N) Phases<LOG2N, P + 1>::run(s, tid, k);
+    }
+};
+
+}  // namespace
+
+// Tiled transposes either side of the column sort: the spectrogram is frame-major (a column is one float every FS),
+// the sort wants whole columns. in[c][t][FS] -> out[c * n_cols + f][pitch] (fp32, 64 x 64 tiles through LDS).
+__global__ __launch_bounds__(256) void columns_from_rows_kernel(RankArgs a) {
+    __shared__ float tile[64][65];
+    const int c = blockIdx.z, f0 = blockIdx.y * 64;
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* in = a.V + c * a.chan_stride;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t t = t0 + ty + 4 * k;
+        tile[ty + 4 * k][tx] = t < a.T ? in[t * a.FS + f0 + tx] : 0.f;
+    }
+    __syncthreads();
+    float* out = a.Vs + ((int64_t)c * a.n_cols + f0) * a.vs_pitch;
+    if (t0 + tx < a.vs_pitch) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[(int64_t)(ty + 4 * k) * a.vs_pitch + t0 + tx] = tile[tx][ty + 4 * k];
+    }
+}
+
+// codes[c * n_cols + f][pitch] (u16, column-major) -> R[c][t][FS]. Work unit: a 2 x 2 block of codes = one dword in
+// (frames t, t+1 of bin f) and one dword out (bins f, f+1 of frame t); 64 x 64 dword tiles through LDS.
+__global__ __launch_bounds__(256) void rows_from_code_columns_kernel(RankArgs a) {
+    __shared__ unsigned tile[2][64][65];                // [bin parity][bin pair][frame pair]: conflict-free both ways
+    const int c = blockIdx.z, f0 = blockIdx.y * 128;
+    const int64_t t0 = (int64_t)blockIdx.x * 128;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const unsigned* in = reinterpret_cast<const unsigned*>(a.codes + ((int64_t)c * a.n_cols + f0) * a.vs_pitch + t0);
+    const bool in_range = t0 + 2 * tx < a.vs_pitch;      // vs_pitch is even; codes of frames >= T are never stored
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int fl = ty + 4 * k;
+        tile[fl & 1][fl >> 1][tx] = in_range ? in[(int64_t)fl * (a.vs_pitch / 2) + tx] : 0u;
+    }
+    __syncthreads();
+    unsigned* out = reinterpret_cast<unsigned*>(a.R + c * a.r_chan_stride + f0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int tp = ty + 4 * k;                       // frame pair of the tile; lane tx = bin pair (2 tx, 2 tx + 1)
+        const unsigned lo = tile[0][tx][tp], hi = tile[1][tx][tp];
+        const int64_t t = t0 + 2 * tp;
+        if (t < a.T) out[t * (a.FS / 2) + tx] = (lo & 0xffffu) | (hi << 16);
+        if (t + 1 < a.T) out[(t + 1) * (a.FS / 2) + tx] = (lo >> 16) | (hi & 0xffff0000u);
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArgs a) {
+    constexpr int N = 1 << LOG2N, THREADS = N / 32;
+    extern __shared__ uint4 rank_lds[];
+    unsigned* s = reinterpret_cast<unsigned*>(rank_lds);
+    const int64_t col = blockIdx.x;
+    const int tid = threadIdx.x;
+    // the column (T floats, contiguous after columns_from_rows_kernel) is replaced by its sorted self at the end.
+    // Thread tid takes keys 4 tid + 4 THREADS j + {0..3}, j < 8 (any 32 do for the first five merge phases): whole
+    // float4 loads, coalesced across the workgroup. Frames >= T lie outside the resource (0) and become +inf keys.
+    float* column = a.Vs + col * a.vs_pitch;
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(column, 0, (int)(a.T * 4), 0x00020000);
+    unsigned k[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 4 * tid + 4 * THREADS * j;
+        const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, t * 4, 0, 0));
+        k[4 * j] = t < a.T ? v.x : 0x7f800000u;          // magnitudes are >= 0: unsigned order == float order
+        k[4 * j + 1] = t + 1 < a.T ? v.y : 0x7f800000u;
+        k[4 * j + 2] = t + 2 < a.T ? v.z : 0x7f800000u;
+        k[4 * j + 3] = t + 3 < a.T ? v.w : 0x7f800000u;
+    }
+    // merge phases 1..5 inside the thread's 32 keys
+#pragma unroll
+    for (int p = 1; p <= 5; ++p) {
+#pragma unroll
+        for (int i2 = 0; i2 < 32; ++i2)
+            if (!(i2 & (1 << (p - 1)))) cex(k[i2], k[i2 ^ ((1 << p) - 1)]);
+#pragma unroll
+        for (int q = p - 2; q >= 0; --q) {
+#pragma unroll
+            for (int i2 = 0; i2 < 32; ++i2)
+                if (!(i2 & (1 << q))) cex(k[i2], k[i2 | (1 << q)]);
+        }
+    }
+    store_run(s, tid, k);
+    if (!(a.ablate & 1)) Phases<LOG2N, 6>::run(s, tid, k);
+    // code of every original key: 0x0400 + lower_bound(sorted, key), 32 independent binary searches per thread. The
+    // keys are fetched again (cache-resident: this workgroup read them a few microseconds ago) rather than held in 32
+    // registers through the whole sort.
+    unsigned orig[32], pos[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 4 * tid + 4 * THREADS * j;
+        const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, t * 4, 0, 0));
+        orig[4 * j] = v.x; orig[4 * j + 1] = v.y; orig[4 * j + 2] = v.z; orig[4 * j + 3] = v.w;
+    }
+    // pos[e] walks PHYSICAL LDS indices, biased by the offset of the level's probe: a step of 2^m >= 32 keys is
+    // 2^m + 2^m / 8 words further on (one pad float4 per 32 keys) and its probe (key pos + step - 1, in the row before
+    // pos + step) sits at +inc - 5; a step below 32 stays inside a padded row (probe at +step - 1). A probe is then a
+    // ds_read of pos[e] itself, a compare, a select and one three-input add (the move to the next level's bias).
+    int off = (N / 2 + N / 16) - 5;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) pos[e] = off;
+    __syncthreads();
+    if (!(a.ablate & 2)) {
+#pragma unroll 1
+        for (int m = LOG2N - 1; m >= 5; --m) {
+            const int step = 1 << m, inc = step + (step >> 3);
+            const int next_off = m > 5 ? (inc >> 1) - 5 : 15;
+            const int d = next_off - off;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const unsigned probe = s[pos[e]];
+                pos[e] += (probe < orig[e] ? inc : 0) + d;
+            }
+            off = next_off;
+        }
+#pragma unroll
+        for (int m = 4; m >= 0; --m) {
+            const int step = 1 << m, d = m > 0 ? -((step >> 1) + 0) : 0;      // (step/2 - 1) - (step - 1)
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const unsigned probe = s[pos[e]];
+                pos[e] += (probe < orig[e] ? step : 0) + d;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) pos[e] = 0;
+    }
+    // back to logical positions: physical p = i + 4 (i / 32)  =>  i = p - 4 (p / 36)
+#pragma unroll
+    for (int e = 0; e < 32; ++e) pos[e] -= 4 * (pos[e] / 36);
+    // codes of frames 4 tid + 4 THREADS j + {0..3}: one 8-byte store each (frames >= T are dropped by the resource)
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.codes + col * a.vs_pitch, 0, (int)(round_up(a.T, 4) * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 4 * tid + 4 * THREADS * j;
+        const unsigned lo = (kRankCodeBase + pos[4 * j]) | ((kRankCodeBase + pos[4 * j + 1]) << 16);
+        const unsigned hi = (kRankCodeBase + pos[4 * j + 2]) | ((kRankCodeBase + pos[4 * j + 3]) << 16);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, make_uint2(lo, hi)),
+                                              c_rsrc, t * 2, 0, 0);
+    }
+    // the sorted column over the original one: rank -> value table of the mask kernel (every thread has read its keys)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 4 * tid + 4 * THREADS * j;
+        if (t < a.vs_pitch) *reinterpret_cast<uint4*>(column + t) = *reinterpret_cast<const uint4*>(s + phys(t));
+    }
+}
+
+__global__ void fill_rank_pad_rows_kernel(unsigned short* R, int64_t r_chan_stride, int64_t pad_row, int FS) {
+    const int c = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * FS) return;
+    R[c * r_chan_stride + pad_row * FS + k] = (k < FS) ? (unsigned short)0 : (unsigned short)0x7C00;
+}
+
+hipError_t launch_fill_rank_pad_rows(unsigned short* R, int64_t r_chan_stride, int32_t n_channels, int64_t pad_row,
+                                     int32_t FS, hipStream_t s) {
+    hipLaunchKernelGGL(fill_rank_pad_rows_kernel, dim3((unsigned)ceil_div(2 * FS, 256), (unsigned)n_channels), dim3(256), 0, s,
+                       R, r_chan_stride, pad_row, FS);
+    return hipGetLastError();
+}
+
+bool rank_columns_supported(int64_t T) { return T > kRankMinFrames && T <= kRankMaxFrames; }
+
+template <int LOG2N>
+static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int lds = (N + N / 8) * 4;
+    const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N>);
+    hipError_t e = ensure_dynamic_lds(fn, lds);
+    if (e != hipSuccess) return e;
+    const int64_t cols = (int64_t)a.n_channels * a.n_cols;
+    hipLaunchKernelGGL(columns_from_rows_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
+                       dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rank_columns_kernel<LOG2N>, dim3((unsigned)cols), dim3(N / 32), lds, s, a);
+    hipLaunchKernelGGL(rows_from_code_columns_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 128), (unsigned)(a.n_cols / 128), (unsigned)a.n_channels),
+                       dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_columns(const RankArgs& a0, hipStream_t s) {
+    if (!rank_columns_supported(a0.T) || a0.n_cols <= 0 || (a0.n_cols & 127) || (a0.vs_pitch & 31) || (a0.FS & 1)) return hipErrorInvalidValue;
+    RankArgs a = a0;
+    static const int ablate = [] { const char* e = getenv("REPET_RANK_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only
+    a.ablate = ablate;
+    if (a.T <= 2048) return launch_rank_n<11>(a, s);
+    if (a.T <= 4096) return launch_rank_n<12>(a, s);
+    if (a.T <= 8192) return launch_rank_n<13>(a, s);
+    if (a.T <= 16384) return launch_rank_n<14>(a, s);
+    return launch_rank_n<15>(a, s);
+}
+
+}  // namespace repet

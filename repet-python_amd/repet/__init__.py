@@ -309,6 +309,20 @@ def _simmask(audio_spectrogram, similarity_indices):
     return out.T.astype(np.float64)
 
 
+def _rank_columns(audio_spectrogram):
+    """Rank transform behind the median of ``sim`` (no counterpart in the reference: np.median at repet.py:1535 only
+    needs the order of a bin's magnitudes). ``(F, T)`` -> (codes ``(n, T)`` uint16 = 0x0400 + number of strictly smaller
+    magnitudes of the bin, sorted ``(n, T)``) for the first ``n = F // 128 * 128`` bins."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    n = f // 128 * 128
+    codes = np.empty((t, n), dtype=np.uint16)
+    ordered = np.empty((n, t), dtype=np.float32)
+    _native.check(_native.lib().repet_rank_columns(_native.default_context(_device).handle, _native.ptr(rows), t, f,
+                                                   _native.ptr(codes), _native.ptr(ordered)))
+    return codes.T, ordered
+
+
 # ---- file / display utilities of the reference (host side, off the hot path) --------------------------------
 def wavread(audio_file):
     """Read a WAVE file, integers scaled to [-1, 1) by their bit depth (repet.py:914-931)."""

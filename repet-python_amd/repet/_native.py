@@ -82,6 +82,7 @@ _SIGNATURES = {
     "repet_mask_period": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "repet_mask_adaptive": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, _P]),
     "repet_mask_sim": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
+    "repet_rank_columns": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "repet_ctx_last_periods": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "repet_ctx_last_sim_indices": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "repet_ctx_last_frame_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),

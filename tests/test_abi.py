@@ -130,13 +130,18 @@ def test_device_code_has_no_packed_fp32_or_scratch(tmp_path):
     for b in bundles:
         text = subprocess.check_output([objdump, "-d", str(tmp_path / b)], text=True)
         assert not re.search(r"\bv_pk_(add|mul|fma)_f32\b|\bv_pk_mov_b32\b", text), f"packed fp32 op in {b}"
+        assert not re.search(r"\bscratch_(load|store)", text), f"scratch access in {b}"
+        # the kernel descriptors say it directly: no private segment, no spilled registers (a buffer access through
+        # s[0:3] is NOT evidence of scratch: kernels build their own buffer resources there)
+        notes = subprocess.check_output([objdump.replace("llvm-objdump", "llvm-readelf"), "--notes", str(tmp_path / b)], text=True)
         kernel = None
-        for line in text.splitlines():
-            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        for line in notes.splitlines():
+            m = re.search(r"\.name:\s+(\S+)", line)
             if m:
                 kernel = m.group(1)
-            elif kernel and re.search(r"\bscratch_(load|store)|\bbuffer_(load|store)\S* .*s\[0:3\].*offen", line):
-                spilling.add(kernel)
+            m = re.search(r"\.(private_segment_fixed_size|vgpr_spill_count):\s+(\d+)", line)
+            if m and int(m.group(2)) != 0:
+                spilling.add((kernel, m.group(1), int(m.group(2))))
     assert not spilling, spilling
 
 

@@ -180,3 +180,31 @@ def test_similaritymatrix_and_acorr_helpers(clip):
     assert got.shape == want.shape
     assert _rel(got, want) < 2e-5
     assert np.allclose(np.mean(got, axis=1), repet._beatspectrum(p.T), rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("t,f", [(1025, 128), (2048, 384), (2500, 129), (4097, 256), (7753, 257), (9000, 128), (17000, 128), (30720, 128)])
+def test_rank_columns_against_numpy(t, f):
+    """The rank transform behind sim's median (rank.hip): every column sorted by one workgroup (bitonic network,
+    32 keys per thread; sizes 2^11 .. 2^15), code = 0x0400 + number of strictly smaller values, ties share a code."""
+    rs = np.random.RandomState(t + f)
+    v = np.abs(rs.standard_normal((f, t))).astype(np.float32) * np.exp(rs.uniform(-12, 3, size=(f, 1))).astype(np.float32)
+    v[:, rs.randint(0, t, size=t // 7)] = v[:, rs.randint(0, t, size=t // 7)]      # ties between frames
+    v[0, :] = 0.25                                                                   # a constant bin: every code equal
+    v[1, : t // 2] = 0.0                                                             # zeros
+    codes, ordered = repet._rank_columns(v)
+    n = f // 128 * 128
+    assert codes.shape == (n, t) and ordered.shape == (n, t)
+    want_sorted = np.sort(v[:n], axis=1)
+    assert np.array_equal(ordered, want_sorted)
+    for b in range(n):
+        want = np.searchsorted(want_sorted[b], v[b], side="left") + 0x0400
+        assert np.array_equal(codes[b].astype(np.int64), want), b
+    # what the mask kernel relies on: looking a code up in the sorted column returns the value itself
+    assert np.array_equal(np.take_along_axis(ordered, codes.astype(np.int64) - 0x0400, axis=1), v[:n])
+
+
+def test_rank_columns_limits():
+    with pytest.raises(RuntimeError):
+        repet._rank_columns(np.ones((128, 1024), dtype=np.float32))      # too short: selecting on the floats is cheaper
+    with pytest.raises(RuntimeError):
+        repet._rank_columns(np.ones((128, 30721), dtype=np.float32))     # codes would reach +inf (0x7C00)

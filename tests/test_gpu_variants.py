@@ -346,6 +346,35 @@ def test_gram_paths_agree():
     assert rms_err(outs[0]["y"], outs[1]["y"]) < 5e-6
 
 
+@pytest.mark.parametrize("seconds,fs,channels,number,distance", [(50, 44100, 2, 100, 1.0), (110, 22050, 1, 100, 0.3),
+                                                                  (70, 16000, 3, 64, 0.2), (30, 44100, 2, 31, 0.1)])
+def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance):
+    """sim's median: the rank-domain form (default on clips of more than 1 024 frames: rank.hip + packed 16-bit
+    selection network) against the selection on the float magnitudes (REPET_MEDIAN=f32). A median is a selection, so
+    the two must agree BIT FOR BIT, not to a tolerance -- odd and even list lengths (the last case), short lists padded,
+    several network sizes, 1-3 channels."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "repet.similarity_number = {number}; repet.similarity_distance = {distance}; "
+            "x = synth({seconds}, {fs}, {channels}, 33); p = repet.derive_params({fs}); c = repet.Context(0); c.upload(x); "
+            "tm = c.execute('sim', p, timing=True); y = c.download(); _, cnt = c.last_sim_indices(c.last_frame_count(), p.sim_number); "
+            "np.savez(sys.argv[1], y=y, cnt=cnt, stages=np.array([s['name'] for s in tm['stages']]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (code % (os.path.join(root, "repet-python_amd"), root)).format(number=number, distance=distance, seconds=seconds, fs=fs, channels=channels)
+    outs = []
+    for path in ("rank", "f32"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_median_{path}_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MEDIAN=path))
+        with np.load(out) as z:
+            outs.append({k: z[k] for k in z.files})
+        os.remove(out)
+    assert "rank_columns" in outs[0]["stages"].tolist() and "rank_columns" not in outs[1]["stages"].tolist()
+    assert np.array_equal(outs[0]["y"], outs[1]["y"])
+    assert np.all(outs[0]["cnt"] % 2 == number % 2)                       # 100 / 64: even lists (mean of two), 31: odd
+
+
 def test_long_similarity_number_uses_bisection_path():
     """similarity_number > 128 takes the bisection median (no sorting network of that size)."""
     x, fs = golden_input("small_stereo")

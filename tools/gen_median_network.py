@@ -147,21 +147,26 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "repet-python_amd", "csrc",
                        "median_networks.inc")
     lines = ["// GENERATED by tools/gen_median_network.py -- do not edit.",
-             "// MedianNet<N>::run(a): afterwards a[N/2-1] <= a[N/2] are the two middle order statistics.",
+             "// REPET_NET<N>::run(a): afterwards a[N/2-1] <= a[N/2] are the two middle order statistics.",
              "// kLoadOrder lists the wires in the order the network first reads them: gathering in that order lets the",
              "// first comparators start while the tail of the gather is still in flight.",
-             "// A comparator is two integer min/max on the float bit patterns: every value is a non-negative float",
-             "// (a magnitude), +inf or the -1.0f pad, for which signed-integer order equals float order. The asm is",
-             "// volatile so the steps issue in network order: the live set stays at N values + 1 temporary (hipcc",
+             "// The file is included once per element type, with the includer defining",
+             "//   REPET_NET (struct name), REPET_T (register type) and REPET_OP_MIN / MAX / MIN3 / MAX3 (mnemonics):",
+             "//   * MedianNet   : float magnitudes compared as signed integers (v_min_i32 ...): every value is a non-negative",
+             "//                   float, +inf or the -1.0f pad, for which signed-integer order equals float order;",
+             "//   * MedianNetPk : TWO 16-bit rank codes per register (v_pk_min_u16 ... and gfx950's v_pk_minimum3_f16 /",
+             "//                   v_pk_maximum3_f16): codes are positive normal f16 bit patterns, 0 or +inf, for which",
+             "//                   unsigned-integer order equals f16 order, so both families agree.",
+             "// The asm is volatile so the steps issue in network order: the live set stays at N values + 1 temporary (hipcc",
              "// otherwise stretches live ranges to ~2N registers and halves the occupancy), and no NaN",
              "// canonicalisation ops are inserted in front of the min/max. Steps whose other output is dead keep",
-             "// one instruction; dependent min-only / max-only pairs are fused into v_min3_i32 / v_max3_i32.",
-             "#define REPET_CE(i, j) { float lo_, hi_; asm volatile(\"v_min_i32 %0, %2, %3\\n\\tv_max_i32 %1, %2, %3\" : \"=&v\"(lo_), \"=v\"(hi_) : \"v\"(a[i]), \"v\"(a[j])); a[i] = lo_; a[j] = hi_; }",
-             "#define REPET_MIN(d, i, j) { float r_; asm volatile(\"v_min_i32 %0, %1, %2\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j])); a[d] = r_; }",
-             "#define REPET_MAX(d, i, j) { float r_; asm volatile(\"v_max_i32 %0, %1, %2\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j])); a[d] = r_; }",
-             "#define REPET_MIN3(d, i, j, k) { float r_; asm volatile(\"v_min3_i32 %0, %1, %2, %3\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j]), \"v\"(a[k])); a[d] = r_; }",
-             "#define REPET_MAX3(d, i, j, k) { float r_; asm volatile(\"v_max3_i32 %0, %1, %2, %3\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j]), \"v\"(a[k])); a[d] = r_; }",
-             "template <int N> struct MedianNet;"]
+             "// one instruction; dependent min-only / max-only pairs are fused into the three-input forms.",
+             "#define REPET_CE(i, j) { REPET_T lo_, hi_; asm volatile(REPET_OP_MIN \" %0, %2, %3\\n\\t\" REPET_OP_MAX \" %1, %2, %3\" : \"=&v\"(lo_), \"=v\"(hi_) : \"v\"(a[i]), \"v\"(a[j])); a[i] = lo_; a[j] = hi_; }",
+             "#define REPET_MIN(d, i, j) { REPET_T r_; asm volatile(REPET_OP_MIN \" %0, %1, %2\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j])); a[d] = r_; }",
+             "#define REPET_MAX(d, i, j) { REPET_T r_; asm volatile(REPET_OP_MAX \" %0, %1, %2\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j])); a[d] = r_; }",
+             "#define REPET_MIN3(d, i, j, k) { REPET_T r_; asm volatile(REPET_OP_MIN3 \" %0, %1, %2, %3\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j]), \"v\"(a[k])); a[d] = r_; }",
+             "#define REPET_MAX3(d, i, j, k) { REPET_T r_; asm volatile(REPET_OP_MAX3 \" %0, %1, %2, %3\" : \"=v\"(r_) : \"v\"(a[i]), \"v\"(a[j]), \"v\"(a[k])); a[d] = r_; }",
+             "template <int N> struct REPET_NET;"]
     for n in SIZES:
         full = batcher(n)
         ces = prune(full, (n // 2 - 1, n // 2))
@@ -171,7 +176,7 @@ def main():
         n_instr = sum(2 if o[0] == "ce" else 1 for o in ops)
         print(f"N={n}: {len(full)} comparators, {len(ces)} after pruning, {n_instr} instructions "
               f"({2 * len(ces)} before output-level pruning and min3/max3 fusion)", file=sys.stderr)
-        lines.append(f"template <> struct MedianNet<{n}> {{")
+        lines.append(f"template <> struct REPET_NET<{n}> {{")
         lines.append(f"    static constexpr int kInstructions = {n_instr};")
         first = []
         for kind, dst, srcs in ops:                 # wires in the order the network first reads them
@@ -181,7 +186,7 @@ def main():
         first += [w for w in range(n) if w not in first]
         assert sorted(first) == list(range(n)), n
         lines.append(f"    static constexpr unsigned char kLoadOrder[{n}] = {{{', '.join(str(w) for w in first)}}};")
-        lines.append(f"    static __device__ __forceinline__ void run(float (&a)[{n}]) {{")
+        lines.append(f"    static __device__ __forceinline__ void run(REPET_T (&a)[{n}]) {{")
         row = []
         for kind, dst, srcs in ops:
             if kind == "ce":
@@ -200,6 +205,10 @@ def main():
     for m in ("CE", "MIN", "MAX", "MIN3", "MAX3"):
         lines.append(f"#undef REPET_{m}")
     text = "\n".join(lines) + "\n"
+    if "--check" in sys.argv:                 # build(): the committed file must be what this generator emits
+        if not os.path.exists(out) or open(out).read() != text:
+            raise SystemExit(f"{out} is not what tools/gen_median_network.py generates: regenerate and commit it")
+        return
     if not os.path.exists(out) or open(out).read() != text:   # keep the mtime when nothing changed
         with open(out, "w") as fh:
             fh.write(text)
