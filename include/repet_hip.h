@@ -19,6 +19,7 @@
 #ifndef REPET_HIP_H
 #define REPET_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -121,6 +122,14 @@ int repet_ctx_upload_batch(repet_ctx* ctx, const void* audio, int dtype, int64_t
                            int32_t n_clips);
 int repet_ctx_execute(repet_ctx* ctx, int algo, const repet_params* p, repet_timing* timing /* nullable */);
 int repet_ctx_download(repet_ctx* ctx, double* out);
+
+/* Pinned host buffers from a recycling pool, for results: repet_ctx_download / repet_run write into any memory, but a
+ * buffer that is already faulted in and pinned takes the copy at link speed (a fresh malloc / np.empty of a 3-minute
+ * clip page-faults 31 000 times on first touch). repet_host_free returns the buffer to the pool; NULL when the pool
+ * declines (use ordinary memory then). The Python module wraps these as the NumPy arrays it returns
+ * (the reference returns a fresh array per call, repet.py:176,302,540,683,829). */
+void* repet_host_alloc(size_t bytes);
+void repet_host_free(void* ptr);
 /* Non-blocking form of execute: enqueues the whole run on the context's stream and returns; contexts have
  * their own streams, so runs of different contexts overlap on the device. Errors detected at enqueue time are
  * returned here, device-side failures by repet_ctx_synchronize (or the next blocking call). */

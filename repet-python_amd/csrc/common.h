@@ -207,6 +207,25 @@ hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s);
 hipError_t launch_fill_rank_pad_rows(unsigned short* R, int64_t r_chan_stride, int32_t n_channels, int64_t pad_row,
                                      int32_t FS, hipStream_t s);
 
+// Host <-> device staging (hostio.hip): a ring of pinned fp32 chunks per context; worker threads convert between the
+// caller's array and the ring while earlier chunks are in flight.
+struct StagingRing {
+    static constexpr int kSlots = 6;
+    static constexpr size_t kSlotElems = (size_t)1 << 20;      // 4 MB of fp32 per slot
+    float* base = nullptr;
+    hipEvent_t event[kSlots] = {};
+    bool busy[kSlots] = {};
+    hipError_t ensure();
+    void release();
+    ~StagingRing();
+};
+// dtype: 0 float32, 1 float64, 2 int16 (REPET_F32 / F64 / I16)
+hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s);
+hipError_t staged_download(StagingRing& ring, const float* src, double* dst, size_t count, hipStream_t s);
+// pinned host buffers from a recycling pool (result arrays of the Python module); nullptr when the pool declines
+void* host_alloc(size_t bytes);
+void host_free(void* ptr);
+
 // elementwise helpers
 hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);
 hipError_t launch_convert_out(const float* src, double* dst, int64_t count, hipStream_t s);

@@ -89,6 +89,7 @@ struct repet_ctx {
     std::vector<hipEvent_t> chunk_events;
     // resident clip
     DevBuf staging, audio, out, out64;
+    StagingRing ring;             // pinned chunks the waveforms travel through (hostio.hip)
     int64_t n_samples = 0;        // per clip
     int32_t n_clips = 1;          // equal-shape clips back to back in `audio` / `out` (repet_ctx_upload_batch)
     int64_t clip_base = 0;        // first sample of the clip the single-clip pipelines currently work on
@@ -786,6 +787,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
+    c->ring.release();
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
                       &c->refine_stats, &c->R, &c->Vs, &c->rank_codes,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
@@ -843,18 +845,13 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     if (n_clips < 1) return fail(REPET_ERR_BAD_ARG, "n_clips must be >= 1");
     if (dtype < REPET_F32 || dtype > REPET_I16) return fail(REPET_ERR_BAD_ARG, "unsupported dtype");
     DeviceGuard guard(c->device);
-    const size_t esz = dtype == REPET_F64 ? 8 : (dtype == REPET_F32 ? 4 : 2);
     const int64_t count = n * ch * n_clips;
     HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
     HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
-    if (dtype == REPET_F32) {
-        HIP_TRY(hipMemcpyAsync(c->audio.p, audio, (size_t)count * esz, hipMemcpyHostToDevice, c->stream));
-    } else {
-        HIP_TRY(c->staging.ensure(std::max<size_t>((size_t)count * esz, 256)));
-        HIP_TRY(hipMemcpyAsync(c->staging.p, audio, (size_t)count * esz, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_convert_in(c->staging.p, dtype, c->audio.as<float>(), count, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // narrowed to fp32 by host threads into the pinned ring, chunk by chunk, each chunk DMA'd while the next is
+    // converted; the caller's array has been read completely when this returns (the last DMAs may still be in flight
+    // on the context's stream, which every later operation of the context is ordered behind)
+    HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream));
     c->n_samples = n;
     c->n_channels = ch;
     c->n_clips = n_clips;
@@ -1013,12 +1010,12 @@ int repet_ctx_download(repet_ctx* c, double* out) {
     DeviceGuard guard(c->device);
     const int64_t count = c->n_samples * c->n_channels * c->n_clips;
     if (count == 0) return REPET_OK;
-    HIP_TRY(c->out64.ensure((size_t)count * sizeof(double)));
-    HIP_TRY(launch_convert_out(c->out.as<float>(), c->out64.as<double>(), count, c->stream));
-    HIP_TRY(hipMemcpyAsync(out, c->out64.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(staged_download(c->ring, c->out.as<float>(), out, (size_t)count, c->stream));
     return REPET_OK;
 }
+
+void* repet_host_alloc(size_t bytes) { return host_alloc(bytes); }
+void repet_host_free(void* ptr) { host_free(ptr); }
 
 int repet_ctx_download_foreground(repet_ctx* c, double* out) {
     if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");

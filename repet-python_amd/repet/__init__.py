@@ -79,7 +79,7 @@ def _separate(algo, audio_signal, sampling_frequency):
     number_samples, number_channels = np.shape(audio_signal)   # 1-D input: ValueError, like repet.py:125
     params = derive_params(sampling_frequency)
     signal, code = _native.as_input(audio_signal)
-    background_signal = np.empty((number_samples, number_channels), dtype=np.float64)
+    background_signal = _native.result_array((number_samples, number_channels))
     lib = _native.lib()
     if lib.repet_device_count() < 1:
         raise RuntimeError("no HIP device visible: the REPET engine has no CPU fallback")
