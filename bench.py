@@ -27,6 +27,15 @@ for p in (os.path.join(ROOT, "repet-python_amd"), ROOT):
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_F16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: ~2.5 PF dense f16 / bf16
+# v_min / v_max / v_pk_min_u16-class VALU instructions: one wave64 instruction per 4 cycles per SIMD (measured 4.2-4.75,
+# tools/microbench/cex_rate.hip), 1 024 SIMDs, 2.4 GHz max clock (MI355X_MICROARCH.md) -> 614.4 G wave-instructions/s
+VALU_QUARTER_RATE_GINSTR = 1024 * 2.4 / 4.0
+PMC_FILE = "r02_pmc_traffic.json"
+# arithmetic type of the path: fp32 end to end, except that the similarity GEMM of sim / simonline runs on the f16 matrix
+# cores as a three-product split of the fp32 operands (22 significant bits per product, fp32 accumulate; gram_f16.hip)
+DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on 16-bit rank codes)",
+              "simonline": "f32 (similarity band: f16x3 split of the fp32 unit rows, fp32 accumulate)"}
 
 
 def cpu_baseline(fs, channels, seconds):
@@ -91,9 +100,11 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
 
+    import ctypes
     import numpy as np
     import torch
     import repet
+    from repet import _native
     from repet_synth import synth
 
     if not torch.cuda.is_available():
@@ -162,35 +173,81 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)                   # stage figures are per clip
+        T, F, C = int(ctx.last_frame_count()), params.window_length // 2 + 1, channels
+        rank_path = "rank_columns" in stage_ms
+        sim_like = args.algo in ("sim", "simonline")
+        k_mean = net_size = net_instr = None
+        if sim_like:
+            rows = T if args.algo == "sim" else max(T - params.buffer_frames + 1, 0)
+            _, cnt = ctxs[0].last_sim_indices(rows, params.sim_number)       # outside the timed region
+            k_mean = float(np.mean(cnt)) if rows else 0.0
+            span = T if args.algo == "sim" else params.buffer_frames
+            bound = min(params.sim_number, -(-span // (params.sim_distance_frames + 1)))    # what the engine sizes the network for
+            ns, ni = ctypes.c_int32(), ctypes.c_int32()
+            _native.lib().repet_median_network_info(int(bound), ctypes.byref(ns), ctypes.byref(ni))
+            net_size, net_instr = ns.value, ni.value
         stages = []
         for name, total in stage_ms.items():
             ms = total / steps
             meta = stage_meta[name]
-            entry = {"name": name, "ms": round(ms, 4), "GB/s": round(meta["bytes"] / (ms * 1e-3) / 1e9, 1)}
-            if meta["flops"] > 0:
-                entry["TFLOP/s"] = round(meta["flops"] / (ms * 1e-3) / 1e12, 2)
+            sec = ms * 1e-3
+            entry = {"name": name, "ms": round(ms, 4)}
+            if name.startswith("mask_sim") and net_instr:
+                # VALU-issue-bound: one selection network per wave and block of bins. A wave covers 64 bins
+                # on the float path, 128 (two 16-bit rank codes per lane) on the rank path; v_min/v_max-class
+                # instructions issue at one per 4 cycles per SIMD (1 024 SIMDs, 2.4 GHz max clock).
+                bins_per_wave = 128 if rank_path else 64
+                waves = (rows * C * ((F - 1) // bins_per_wave) + -(-rows // 64) * C) * (args.clips if batched else 1)   # + one-lane-per-frame Nyquist kernel
+                ach = net_instr * waves / sec / 1e9
+                entry.update({"bound": "valu", "achieved": round(ach, 1), "peak": VALU_QUARTER_RATE_GINSTR, "unit": "G wave-instr/s",
+                              "frac": round(ach / VALU_QUARTER_RATE_GINSTR, 4), "algorithmic": net_instr * waves,
+                              "network": {"wires": net_size, "instructions": net_instr, "waves": waves, "codes": "2 x u16 per lane" if rank_path else "f32"}})
+                # the byte view SURVEY 8d defines for K5 (reads 4FTC + gathers 4FTC*Kmean, writes 4FTC), beside it:
+                # cache-resident gathers, so this is NOT the roof that binds
+                b8d = 4.0 * F * rows * C * (1.0 + k_mean + 1.0) * (args.clips if batched else 1)
+                entry["survey_8d_bytes"] = {"algorithmic": b8d, "GB/s": round(b8d / sec / 1e9, 1), "frac_of_hbm_peak": round(b8d / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                            "k_mean": round(k_mean, 2), "note": "gathers are served by L2 / Infinity Cache" + ("; the rank path moves 2 bytes per gathered value, not 4" if rank_path else "")}
+            elif meta["flops"] > 0 and "f16x3" in name:
+                # f16-split matrix-core kernel: three f16 MFMA products per fp32 term, fp32 accumulate. Priced on EXECUTED
+                # f16 flops against the dense f16 MFMA peak; the fp32-equivalent algorithmic rate is stated beside it.
+                ach = meta["flops"] / sec / 1e12 if "similarity_gemm" in name else 3.0 * meta["flops"] / sec / 1e12
+                executed = meta["flops"] if "similarity_gemm" in name else 3.0 * meta["flops"]
+                alg = 2.0 * F * float(T) * T if "similarity_gemm" in name else meta["flops"]
+                entry.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TF,
+                              "unit": "TFLOP/s (f16, executed)" if "similarity_gemm" in name else "TFLOP/s (f16, 3 products per algorithmic term)",
+                              "frac": round(ach / MFMA_F16_PEAK_TF, 4), "algorithmic": executed,
+                              "fp32_equivalent": {"flops": alg, "TFLOP/s": round(alg / sec / 1e12, 1), "note": "2*F*T^2 (symmetric half skipped), not comparable with a peak"}})
+            elif meta["flops"] > 0 and meta["flops"] / (MFMA_F32_PEAK_TF * 1e12) > meta["bytes"] / (HBM_PEAK_GBS * 1e9):
+                ach = meta["flops"] / sec / 1e12
+                entry.update({"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s (fp32)",
+                              "frac": round(ach / MFMA_F32_PEAK_TF, 4), "algorithmic": meta["flops"]})
+            else:
+                ach = meta["bytes"] / sec / 1e9
+                entry.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic": meta["bytes"]})
+                if name == "rank_columns":
+                    entry["note"] = "three kernels (transpose, per-column sort + rank search in LDS, transpose back); the sort is LDS/VALU-bound"
             stages.append(entry)
         dom = max(stages, key=lambda s: s["ms"])
-        meta = stage_meta[dom["name"]]
-        if meta["flops"] > 0 and meta["flops"] / (MFMA_F32_PEAK_TF * 1e12) > meta["bytes"] / (HBM_PEAK_GBS * 1e9):
-            ach = meta["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None}
-        else:
-            ach = meta["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        # HBM bytes per launch from the committed PMC pass of this same workload (profiles/), if it is this workload
+        roof = {"kernel": dom["name"]}
+        roof.update({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in dom})
+        roof["traffic"] = None
+        # HBM-side bytes per launch of the dominant kernel: NOT measured by this run -- read from the committed PMC pass of
+        # this same workload and build (profiles/), if there is one for it
         try:
             if args.config == 2 and args.algo == "sim" and args.duration == 180.0:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    pmc = json.load(fh)["stages"][dom["name"]]
+                with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
+                    pmc = json.load(fh)["stages"][dom["name"].replace("_f16x3", "")]
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                roof["traffic_note"] = "FETCH_SIZE*1024*k + WRITE_SIZE*1024 per launch, fetch correction " + pmc["fetch_correction"]
+                roof["traffic_source"] = f"profiles/{PMC_FILE} (committed rocprofv3 --pmc pass of this workload; static, not measured in this run); " \
+                                         "FETCH_SIZE*1024*k + WRITE_SIZE*1024 per launch, fetch correction " + pmc["fetch_correction"]
         except (OSError, KeyError, ValueError):
             pass
         roof["ms_per_launch"] = dom["ms"]
-        roof["algorithmic_per_launch"] = meta["flops"] if roof["bound"] == "mfma" else meta["bytes"]
+        roof["algorithmic_per_launch"] = dom.get("algorithmic")
+        for extra in ("network", "survey_8d_bytes", "fp32_equivalent"):
+            if extra in dom:
+                roof[extra] = dom[extra]
         line = {
             "metric": f"audio-seconds/sec (x real-time) for repet.{args.algo}, {fs / 1000:g} kHz {'stereo' if channels == 2 else str(channels) + '-ch'}",
             "value": round(args.duration * args.clips * args.steps * world / elapsed, 2),
@@ -198,7 +255,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if example_clip is None else "the reference's example clip (audio_file.wav, read in place)",
+            "dtype": DTYPE_NOTE.get(args.algo, "f32"), "data": "synthetic" if example_clip is None else "the reference's example clip (audio_file.wav, read in place)",
             "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
                                    f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
                        "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
@@ -218,7 +275,7 @@ def main():
                 wall.append(time.perf_counter() - t1)
             line["array_in_array_out"] = {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
                                           "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2),
-                                          "note": "repet.%s(audio_signal, fs) wall time, pageable float64 host arrays both ways" % args.algo}
+                                          "note": "repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads narrow/widen through a pinned ring, fp32 over PCIe)" % args.algo}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -152,6 +152,15 @@ int repet_ctx_execute_extended_range(repet_ctx* ctx, const repet_params* p, int6
                                      repet_timing* timing /* nullable */);
 
 /* ---- one-shot drop-in: replaces repet.<algo>(audio_signal, fs) (repet.py:67,205,422,571,712) -- */
+/* Measurement aid (bench.py's roofline): the median of a list of at most list_bound values is a compare-exchange
+ * selection network evaluated per lane (np.median, repet.py:1535); *network_size = wires of the compiled network
+ * (0: lists longer than 128 use bisection), *instructions = min/max instructions per evaluation. */
+int repet_median_network_info(int32_t list_bound, int32_t* network_size, int32_t* instructions);
+
+/* repet_run keeps one context per calling thread and device (stream, tables, grow-only workspaces -- for `sim` the
+ * T x T similarity matrix) so that repeated calls reuse them; it is destroyed when the thread exits. This releases the
+ * calling thread's contexts now (e.g. after a one-off long clip). */
+int repet_release_thread_ctx(void);
 int repet_run(int algo, const void* audio, int dtype, int64_t n_samples, int32_t n_channels,
               const repet_params* p, double* out, int device, repet_timing* timing /* nullable */);
 

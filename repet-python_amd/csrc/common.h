@@ -185,6 +185,7 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
                            hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3);
+int median_network_instructions(int max_n, int* net_size);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
                               int32_t min_period, hipStream_t s);

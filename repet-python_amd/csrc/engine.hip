@@ -116,6 +116,7 @@ struct repet_ctx {
     int32_t last_idx_pitch = 0;
     int32_t last_idx_number = 0;
     int32_t last_idx_batch = 1;   // clips whose lists sit back to back in idx / cnt (batch contexts)
+    bool band_on_f16 = false;     // the last banded Gram ran on the f16-split kernel (stage label / roofline of bench.py)
     // timing
     std::vector<hipEvent_t> events;
     repet_timing* timing = nullptr;
@@ -223,7 +224,9 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
     // power spectra (beat spectrum): any range, so the split is scaled by the matrix's largest magnitude. Two extra
     // passes over the matrix (max, split): worth it from about two rounds of tiles on (the batched segments of
     // `extended`: 0.58 -> 0.43 ms at cfg 3), not for one clip's narrow band (0.16 -> 0.17 ms at cfg 2 / cfg 4 sizes)
+    c->band_on_f16 = false;
     if (!unit_rows && scaled && gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS)) {
+        c->band_on_f16 = true;
         const int64_t per_clip = round_up(T, kTile) * FS;
         const int64_t count = per_clip * B;
         HIP_TRY(c->Vh.ensure((size_t)count * 4));
@@ -234,6 +237,7 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
         return REPET_OK;
     }
     if (unit_rows && gram_f16_enabled()) {
+        c->band_on_f16 = true;
         const int64_t per_clip = round_up(T, kTile) * FS;
         if (B > 1 && a_stride != per_clip) return fail(REPET_ERR_BAD_ARG, "internal: batch stride of the unit rows");
         const int64_t count = per_clip * B;
@@ -376,7 +380,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     HIP_TRY(c->band.ensure((size_t)B * band_stride * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)B * LP * sizeof(float)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, false, B, mean_stride, band_stride));
-    mark(c, "gram_band", B * (4.0 * g.F * T + 4.0 * T * hi), B * 2.0 * g.F * T * hi);
+    mark(c, c->band_on_f16 ? "gram_band_f16x3" : "gram_band", B * (4.0 * g.F * T + 4.0 * T * hi), B * 2.0 * g.F * T * hi);
     RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, B, band_stride, LP));
     HIP_TRY(launch_periods(c->beat.as<float>(), B, LP, (int)T, p->period_lo, p->period_hi, period_slots, c->stream));
     mark(c, "beat_period", B * 4.0 * T * hi, 0);
@@ -492,7 +496,7 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->win_periods.ensure((size_t)n_win * sizeof(int32_t)));
     HIP_TRY(c->periods.ensure((size_t)T * sizeof(int32_t)));
     RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
-    mark(c, "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
+    mark(c, c->band_on_f16 ? "gram_band_f16x3" : "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
     const int64_t left = (Ls - 1 + 1) / 2;    // ceil((Ls-1)/2), repet.py:1182
     RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0));
     HIP_TRY(launch_periods(c->beat.as<float>(), n_win, LP, Ls, p->period_lo, p->period_hi, c->win_periods.as<int32_t>(), c->stream));
@@ -591,7 +595,15 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int64_t TS = round_up(T, 64);
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
     RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true));
-    mark(c, "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T, 2.0 * g.F * (double)T * T);
+    {
+        // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
+        // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
+        // states the algorithmic 2 F T^2 beside it
+        const double n_tiles = 0.5 * (double)ceil_div(T, kTile) * (double)(ceil_div(T, kTile) + 1);
+        const bool f16 = gram_f16_enabled();
+        mark(c, f16 ? "similarity_gemm_f16x3" : "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T,
+             (f16 ? 3.0 : 1.0) * 2.0 * g.FS * n_tiles * kTile * kTile);
+    }
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
@@ -672,7 +684,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP, spec_stride = (int64_t)g.C * g.chan_stride;
     HIP_TRY(c->band.ensure((size_t)nb * band_stride * sizeof(float)));
     RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride));
-    mark(c, "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
+    mark(c, c->band_on_f16 ? "similarity_band_f16x3" : "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;
     const int64_t rows_alloc = std::max<int64_t>(rows, 1);
@@ -737,7 +749,14 @@ int d2h_pitched(repet_ctx* c, float* dst, const float* src, int64_t spitch, int6
     return REPET_OK;
 }
 
-thread_local std::map<int, repet_ctx*> g_thread_ctx;
+// Contexts of the one-shot entry points (repet_run), one per host thread and device. The holder destroys them when the
+// thread exits (streams, events and the grow-only workspaces -- for `sim` that includes the T x T similarity matrix);
+// repet_release_thread_ctx does it on request.
+struct ThreadContexts {
+    std::map<int, repet_ctx*> by_device;
+    ~ThreadContexts();
+};
+thread_local ThreadContexts g_thread_ctx;
 
 }  // namespace
 
@@ -1056,14 +1075,34 @@ int repet_ctx_spectrogram(repet_ctx* c, int which, int32_t window_length, float*
 }
 
 static int thread_ctx(int device, repet_ctx** out) {
-    auto it = g_thread_ctx.find(device);
-    if (it != g_thread_ctx.end()) { *out = it->second; return REPET_OK; }
+    auto it = g_thread_ctx.by_device.find(device);
+    if (it != g_thread_ctx.by_device.end()) { *out = it->second; return REPET_OK; }
     repet_ctx* c = nullptr;
     RP_TRY(repet_ctx_create(device, &c));
-    g_thread_ctx[device] = c;
+    g_thread_ctx.by_device[device] = c;
     *out = c;
     return REPET_OK;
 }
+
+int repet_median_network_info(int32_t list_bound, int32_t* network_size, int32_t* instructions) {
+    int size = 0;
+    const int n = median_network_instructions(list_bound, &size);
+    if (network_size) *network_size = size;
+    if (instructions) *instructions = n;
+    return REPET_OK;
+}
+
+int repet_release_thread_ctx(void) {
+    for (auto& kv : g_thread_ctx.by_device) repet_ctx_destroy(kv.second);
+    g_thread_ctx.by_device.clear();
+    return REPET_OK;
+}
+
+}  // extern "C"
+ThreadContexts::~ThreadContexts() {
+    for (auto& kv : by_device) repet_ctx_destroy(kv.second);
+}
+extern "C" {
 
 int repet_run(int algo, const void* audio, int dtype, int64_t n, int32_t ch, const repet_params* p, double* out,
               int device, repet_timing* timing) {

@@ -149,6 +149,18 @@ static void dispatch_net(int max_n, Fn&& fn) {
     else fn(std::integral_constant<int, 0>{});
 }
 
+// instructions of the selection network compiled for lists of at most max_n entries (0: bisection, no network)
+int median_network_instructions(int max_n, int* net_size) {
+    int out = 0, size = 0;
+    dispatch_net(max_n, [&](auto net) {
+        constexpr int NET = decltype(net)::value;
+        size = NET;
+        if constexpr (NET > 0) out = MedianNet<NET>::kInstructions;
+    });
+    if (net_size) *net_size = size;
+    return out;
+}
+
 __global__ void fill_pad_rows_kernel(float* V, int64_t chan_stride, int64_t pad_row, int FS) {
     const int c = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -75,6 +75,13 @@ def derive_params(sampling_frequency):
     return p
 
 
+def release_workspaces():
+    """Free the device workspaces the one-shot calls of THIS thread keep between calls (the reference has no such
+    notion: its arrays die with the call). Worth calling after a one-off long ``sim``: the similarity matrix of a
+    10-minute clip is several GB of HBM."""
+    _native.check(_native.lib().repet_release_thread_ctx())
+
+
 def _separate(algo, audio_signal, sampling_frequency):
     number_samples, number_channels = np.shape(audio_signal)   # 1-D input: ValueError, like repet.py:125
     params = derive_params(sampling_frequency)

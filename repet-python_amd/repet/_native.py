@@ -68,6 +68,8 @@ _SIGNATURES = {
     "repet_ctx_spectrogram": (C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_int64]),
     "repet_extended_segment_count": (C.c_int64, [C.c_int64, C.POINTER(Params)]),
     "repet_ctx_execute_extended_range": (C.c_int, [_P, C.POINTER(Params), C.c_int64, C.c_int64, C.POINTER(Timing)]),
+    "repet_release_thread_ctx": (C.c_int, []),
+    "repet_median_network_info": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "repet_run": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int32, C.POINTER(Params), _P, C.c_int,
                             C.POINTER(Timing)]),
     "repet_run_batch": (C.c_int, [C.c_int, C.c_int32, C.POINTER(_P), C.c_int, C.POINTER(C.c_int64),

@@ -143,8 +143,8 @@ def test_integer_intermediates_through_the_context():
 
     timing = ctx.execute("sim", p, timing=True)
     names = [s["name"] for s in timing["stages"]]
-    assert names in (["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"],
-                     ["stft", "similarity_gemm", "peaks+mask", "istft_ola"])
+    assert [n.replace("_f16x3", "") for n in names if n != "rank_columns"] in (
+        ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"], ["stft", "similarity_gemm", "peaks+mask", "istft_ola"])
     assert timing["total_ms"] > 0
     ctx.close()
 

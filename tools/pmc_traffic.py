@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_profile.sh into profiles/rNN_pmc_traffic.json: HBM-side bytes
+per launch of every stage of bench.py's default workload (repet.sim, 180 s, 44.1 kHz stereo).
+usage: tools/pmc_traffic.py <pmc dir> <out json>
+
+Units and corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE
+reports HALF the bytes of wide (16 B per lane) coalesced streaming reads, so kernels whose reads are such streams get
+k = 2; 2-8 B per lane gathers and loads are uncalibrated (k = 1). WRITE_SIZE is exact for 16 B per lane stores."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root, out = sys.argv[1], sys.argv[2]
+# kernel name fragment -> (stage, fetch correction k, note)
+KERNELS = [
+    ("stft_pair_kernel", "stft", 1, "4-8 B/lane"), ("stft_kernel", "stft", 1, "4-8 B/lane"), ("stft_reg_kernel", "stft", 1, "4-8 B/lane"),
+    ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
+    ("gram_kernel", "similarity_gemm", 2, "16 B/lane"),
+    ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
+    ("columns_from_rows_kernel", "rank_columns", 1, "4 B/lane"), ("rank_columns_kernel", "rank_columns", 2, "16 B/lane"),
+    ("rows_from_code_columns_kernel", "rank_columns", 1, "4 B/lane"),
+    ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
+    ("mask_sim_kernel", "mask_sim", 1, "4 B/lane gathers"),
+    ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
+]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+stages = {}
+for kernel, counters in acc.items():
+    hit = next((k for k in KERNELS if k[0] in kernel), None)
+    if hit is None:
+        continue
+    _, stage, k, width = hit
+    fetch = sum(counters.get("FETCH_SIZE", [0.0])) / max(len(counters.get("FETCH_SIZE", [0.0])), 1) * 1024.0
+    write = sum(counters.get("WRITE_SIZE", [0.0])) / max(len(counters.get("WRITE_SIZE", [0.0])), 1) * 1024.0
+    st = stages.setdefault(stage, {"hbm_bytes_per_launch": 0.0, "fetch_bytes": 0.0, "write_bytes": 0.0, "kernels": [], "fetch_correction": ""})
+    st["fetch_bytes"] += fetch * k
+    st["write_bytes"] += write
+    st["hbm_bytes_per_launch"] += fetch * k + write
+    st["kernels"].append({"kernel": kernel.split("(")[0][-60:], "fetch_counted": fetch, "k": k, "write": write})
+    st["fetch_correction"] = (st["fetch_correction"] + "; " if st["fetch_correction"] else "") + f"x{k} ({width})"
+doc = {"_about": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_profile.sh) for bench.py's default workload "
+                 "(repet.sim, 180 s, 44.1 kHz stereo), mean per launch. Bytes = WRITE_SIZE*1024 + FETCH_SIZE*1024*k, k = 2 for kernels whose "
+                 "reads are 16-byte-per-lane streams (gfx950 counts those at one half), k = 1 (uncalibrated) for narrower loads and gathers. "
+                 "Infinity-Cache hits are included in FETCH_SIZE (MI355X_MICROARCH.md), so this is an upper bound on HBM traffic.",
+       "stages": stages}
+json.dump(doc, open(out, "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in stages.items()}))
