@@ -58,6 +58,38 @@ def cpu_baseline(fs, channels, seconds):
                       f"matmul ({blas} BLAS threads); host has {os.cpu_count()} logical cores"}
 
 
+def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, seconds, n_clips):
+    """The multi-GPU data path as a user meets it (repet/parallel.py): the root holds `n_clips` clips in host
+    RAM as float64, deals them over the ranks (fp32 over RCCL/xGMI; a worker's samples stay on its device), every rank
+    separates its share, the root ends with all results in host RAM. Wall time of that whole collective on the root,
+    after one warm-up round (RCCL point-to-point channels, contexts, workspaces). Outside the headline's timed region."""
+    import numpy as np
+    import repet
+    from repet import parallel
+    from repet_synth import synth
+    clips = [synth(seconds, fs, channels, seed=s) for s in range(n_clips)] if rank == 0 else None
+
+    def one_round():
+        if dist is None:                     # one process, one GPU: the root's own share is everything
+            repet.set_device(local_rank)
+            return [getattr(repet, algo)(c, fs) for c in clips]
+        return parallel.separate_clips(algo, clips, fs, device=local_rank)
+
+    one_round()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    out = one_round()
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    assert len(out) == n_clips and all(o.shape == c.shape and np.all(np.isfinite(o)) for o, c in zip(out, clips))
+    return {"value": round(seconds * n_clips / dt, 1), "unit": "audio-seconds/sec", "ms": round(dt * 1e3, 2), "clips": n_clips,
+            "note": f"{n_clips} x {seconds:g}-s clips in the root's host RAM (float64) -> scattered as fp32 over "
+                    f"{'RCCL point-to-point' if dist is not None else 'PCIe only (one GPU)'} -> repet.{algo} on {world} GPU(s) -> "
+                    "gathered back into the root's host RAM (float64); wall time on the root, second round"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +106,7 @@ def main():
                          "mono, 5 simonline 30-s clips (64 over all ranks)")
     ap.add_argument("--wav", default="/root/reference/audio_file.wav", help="config 1: the reference's example clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scatter", action="store_true", help="skip the scatter -> separate -> gather leg (8 clips from the root's host RAM)")
     ap.add_argument("--no-batch", action="store_true", help="config 5: one context and stream per clip instead of one batch context")
     ap.add_argument("--cpu-seconds", type=float, default=180.0,
                     help="length of the CPU-baseline clip (default: the whole config-2 clip, ~25 s of host time)")
@@ -112,6 +145,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or (os.environ.get("REPET_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ):   # the switch: 1-rank check of the RCCL path
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
+            os.environ["NCCL_DEBUG"] = "WARN"        # RCCL prints its version banner on stdout: keep stdout to the one JSON line
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -170,6 +205,11 @@ def main():
 
     out = ctxs[-1].download()
     assert out.shape[-2:] == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
+    scatter = None
+    if not args.no_scatter and args.config == 2 and example_clip is None:
+        for ctx_ in ctxs[1:]:
+            ctx_.close()
+        scatter = scatter_gather_leg(dist, rank, world, local_rank, args.algo, fs, channels, args.duration, 8)
 
     if rank == 0:
         steps = max(args.steps, 1)                   # stage figures are per clip
@@ -276,12 +316,15 @@ def main():
             line["array_in_array_out"] = {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
                                           "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2),
                                           "note": "repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads narrow/widen through a pinned ring, fp32 over PCIe)" % args.algo}
+        if scatter is not None:
+            line["scatter_gather"] = scatter
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)          # the ONE line, after everything that might write to stdout
 
 
 if __name__ == "__main__":

@@ -123,6 +123,18 @@ int repet_ctx_upload_batch(repet_ctx* ctx, const void* audio, int dtype, int64_t
 int repet_ctx_execute(repet_ctx* ctx, int algo, const repet_params* p, repet_timing* timing /* nullable */);
 int repet_ctx_download(repet_ctx* ctx, double* out);
 
+/* Device-resident ingest / egress (multi-GPU: a waveform received over RCCL/xGMI lands in device memory and goes
+ * straight into the engine, no host bounce -- SURVEY 8e; the reference has no counterpart, its arrays live in host RAM):
+ * fp32 interleaved [n_clips][n_samples][n_channels], device (or peer-accessible) memory, complete on return (the
+ * producer of dev_audio must have finished; dev_out may be handed to a collective right away). */
+int repet_ctx_upload_device(repet_ctx* ctx, const float* dev_audio, int64_t n_samples, int32_t n_channels, int32_t n_clips);
+int repet_ctx_download_device(repet_ctx* ctx, float* dev_out);
+/* Declare the resident samples to be [sample0, sample0 + n_samples) of a clip of n_total samples, for
+ * repet_ctx_execute_extended_range: a rank of a multi-GPU `extended` then holds (and returns) only the samples its own
+ * segments cover -- (count + 1) segment steps instead of the whole clip (repet.py:306-414 touches nothing else).
+ * Cleared by every upload; (0, 0) clears it. */
+int repet_ctx_set_window(repet_ctx* ctx, int64_t n_total, int64_t sample0);
+
 /* Pinned host buffers from a recycling pool, for results: repet_ctx_download / repet_run write into any memory, but a
  * buffer that is already faulted in and pinned takes the copy at link speed (a fresh malloc / np.empty of a 3-minute
  * clip page-faults 31 000 times on first touch). repet_host_free returns the buffer to the pool; NULL when the pool

@@ -93,6 +93,10 @@ struct repet_ctx {
     int64_t n_samples = 0;        // per clip
     int32_t n_clips = 1;          // equal-shape clips back to back in `audio` / `out` (repet_ctx_upload_batch)
     int64_t clip_base = 0;        // first sample of the clip the single-clip pipelines currently work on
+    // repet_ctx_set_window: the resident samples are [win_offset, win_offset + n_samples) of a clip of win_total samples
+    // (multi-GPU `extended`: a rank holds only the samples of its own segment range); 0 = the resident clip is whole
+    int64_t win_total = 0, win_offset = 0;
+    bool win_skip_clear = false;  // exec_extended cleared `out` itself (window mode)
     bool clip_loop = false;       // true while run_algo works through the clips one by one
     int32_t n_channels = 0;
     // workspaces
@@ -446,20 +450,46 @@ int64_t extended_segment_count(int64_t N, const repet_params* p) {
 // so partial results of disjoint ranges simply add up (repet.py:380-414 is linear in the segments).
 // All segments but the last have the same length and run as ONE batch per stage; the last one
 // (it absorbs the remainder, repet.py:320-322) runs on its own.
+int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64_t n_seg, int64_t N);
+
 int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_t n_seg = -1) {
-    const int64_t N = c->n_samples, L = p->seg_len_samples, Hs = p->seg_step_samples;
+    if (c->win_total <= 0) return exec_extended_plan(c, p, first, n_seg, c->n_samples);
+    // a window of a longer clip: the plan is the whole clip's, sample s of it lives at s - win_offset here. clip_base is
+    // the (signed) origin every read and write of the single-clip pipelines is relative to.
+    const int64_t N = c->win_total, L = p->seg_len_samples, Hs = p->seg_step_samples;
+    const int64_t count = extended_segment_count(N, p);
+    if (count < 0) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step (Window length M must be a non-negative integer)");
+    if (n_seg < 0) n_seg = count - first;
+    if (first < 0 || n_seg < 1 || first + n_seg > count) return fail(REPET_ERR_BAD_ARG, "extended: segment range outside the plan");
+    const int64_t lo = count == 1 ? 0 : first * Hs;
+    const int64_t hi = (first + n_seg == count) ? N : (first + n_seg - 1) * Hs + L;
+    if (lo < c->win_offset || hi > c->win_offset + c->n_samples)
+        return fail(REPET_ERR_BAD_ARG, "extended: the resident window does not hold the samples of this segment range");
+    HIP_TRY(hipMemsetAsync(c->out.p, 0, (size_t)c->n_samples * c->n_channels * sizeof(float), c->stream));
+    c->clip_base = -c->win_offset;
+    c->win_skip_clear = true;
+    const int rc = exec_extended_plan(c, p, first, n_seg, N);
+    c->win_skip_clear = false;
+    c->clip_base = 0;
+    return rc;
+}
+
+int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64_t n_seg, int64_t N) {
+    const int64_t L = p->seg_len_samples, Hs = p->seg_step_samples;
     const int64_t count = extended_segment_count(N, p);
     if (count < 0) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step (Window length M must be a non-negative integer)");
     if (n_seg < 0) n_seg = count - first;
     if (first < 0 || n_seg < 0 || first + n_seg > count) return fail(REPET_ERR_BAD_ARG, "extended: segment range outside the plan");
     if (count == 1) {                                               // repet.py:271
         if (n_seg == 1) return exec_original(c, p);
-        HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
+        if (!c->win_skip_clear)
+            HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
         return REPET_OK;
     }
     const int64_t O = L - Hs;
     HIP_TRY(c->periods.ensure((size_t)std::max<int64_t>(n_seg, 1) * sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
+    if (!c->win_skip_clear)
+        HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
     const int64_t last = count - 1;
     const int64_t uniform = std::min(first + n_seg, last) - first;  // equal-length segments in the range
     if (uniform > 0)
@@ -875,6 +905,41 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     c->n_channels = ch;
     c->n_clips = n_clips;
     c->clip_base = 0;
+    c->win_total = 0; c->win_offset = 0;
+    return REPET_OK;
+}
+
+int repet_ctx_upload_device(repet_ctx* c, const float* dev_audio, int64_t n, int32_t ch, int32_t n_clips) {
+    if (!c || !dev_audio) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n < 0 || ch < 1 || n_clips < 1) return fail(REPET_ERR_BAD_ARG, "audio_signal must be (number_samples, number_channels)");
+    DeviceGuard guard(c->device);
+    const int64_t count = n * ch * n_clips;
+    HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    // device -> device (peer memory works as well); the source may be reused when this returns
+    HIP_TRY(hipMemcpyAsync(c->audio.p, dev_audio, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_samples = n; c->n_channels = ch; c->n_clips = n_clips; c->clip_base = 0;
+    c->win_total = 0; c->win_offset = 0;
+    return REPET_OK;
+}
+
+int repet_ctx_download_device(repet_ctx* c, float* dev_out) {
+    if (!c || !dev_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    const int64_t count = c->n_samples * c->n_channels * c->n_clips;
+    if (count == 0) return REPET_OK;
+    HIP_TRY(hipMemcpyAsync(dev_out, c->out.p, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+int repet_ctx_set_window(repet_ctx* c, int64_t n_total, int64_t sample0) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    if (c->n_channels < 1 || c->n_clips != 1) return fail(REPET_ERR_BAD_ARG, "set_window applies to a single resident clip");
+    if (n_total == 0 && sample0 == 0) { c->win_total = 0; c->win_offset = 0; return REPET_OK; }
+    if (sample0 < 0 || n_total < sample0 + c->n_samples) return fail(REPET_ERR_BAD_ARG, "window outside the clip");
+    c->win_total = n_total; c->win_offset = sample0;
     return REPET_OK;
 }
 
@@ -940,6 +1005,7 @@ int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
 // the resident clips one after the other (their intermediates -- periods, index lists -- are those of the last).
 int run_algo(repet_ctx* c, int algo, const repet_params* p) {
     c->clip_base = 0;
+    if (c->win_total > 0) return fail(REPET_ERR_BAD_ARG, "the resident samples are a window of a longer clip: only repet_ctx_execute_extended_range applies");
     if (c->n_clips <= 1 || algo == REPET_SIMONLINE || algo == REPET_ORIGINAL) return run_algo_one(c, algo, p);
     repet_timing* timing = c->timing;
     c->timing = nullptr;                       // per-stage marks would repeat per clip: only the total is reported

@@ -60,6 +60,9 @@ _SIGNATURES = {
     "repet_ctx_upload_batch": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int32, C.c_int32]),
     "repet_ctx_execute": (C.c_int, [_P, C.c_int, C.POINTER(Params), C.POINTER(Timing)]),
     "repet_ctx_download": (C.c_int, [_P, _P]),
+    "repet_ctx_upload_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
+    "repet_ctx_download_device": (C.c_int, [_P, _P]),
+    "repet_ctx_set_window": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "repet_host_alloc": (C.c_void_p, [C.c_size_t]),
     "repet_host_free": (None, [C.c_void_p]),
     "repet_ctx_execute_async": (C.c_int, [_P, C.c_int, C.POINTER(Params)]),
@@ -102,6 +105,29 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64 with the system library's soname, so
+    whichever is loaded first serves both; with the system one first, a later ``import torch`` finds no GPU (its other
+    bundled libraries do not match). When a PyTorch-ROCm is installed its runtime is therefore loaded first -- found on
+    disk, not imported. REPET_HIP_RUNTIME=system skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("REPET_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load librepet_hip.so once. Raises RuntimeError if it has not been built."""
     global _lib
@@ -110,6 +136,7 @@ def lib():
             raise RuntimeError(
                 f"librepet_hip.so not found at {LIB_PATH}: build it with `make -C repet-python_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        _preload_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
@@ -211,6 +238,21 @@ class Context:
         a, code = as_input(clips.reshape(b * n, c))
         check(lib().repet_ctx_upload_batch(self._h, ptr(a), code, n, c, b))
         self.shape = (b, n, c)
+
+    def upload_device(self, data_ptr, number_samples, number_channels, number_clips=1):
+        """fp32 interleaved samples already in device memory (e.g. ``tensor.data_ptr()`` of what an RCCL recv filled;
+        its producer must have finished: synchronise that stream first). No host bounce."""
+        check(lib().repet_ctx_upload_device(self._h, C.c_void_p(int(data_ptr)), int(number_samples), int(number_channels), int(number_clips)))
+        self.shape = (number_samples, number_channels) if number_clips == 1 else (number_clips, number_samples, number_channels)
+
+    def download_device(self, data_ptr):
+        """The result as fp32 interleaved samples into device memory of at least ``prod(self.shape)`` floats."""
+        check(lib().repet_ctx_download_device(self._h, C.c_void_p(int(data_ptr))))
+
+    def set_window(self, number_samples_total, first_sample):
+        """The resident samples are ``[first_sample, first_sample + N)`` of a clip of ``number_samples_total`` samples
+        (for ``execute_extended_range`` on a rank that holds only its own segments' samples)."""
+        check(lib().repet_ctx_set_window(self._h, int(number_samples_total), int(first_sample)))
 
     def execute(self, algo, params, timing=False):
         t = Timing() if timing else None

@@ -4,7 +4,12 @@ the MI355X node, "gloo" in the CPU tests).
 The REPET path shards without any exchange during compute: a batch of clips is a set of independent
 units, and the segments of ``extended`` are independent ``original`` problems whose cross-faded outputs
 add up (repet.py:380-414 is linear in the segments). The only communication is the scatter of
-waveforms from the root and the gather of results back -- point-to-point sends of a few MB each.
+waveforms from the root and the gather of results back -- point-to-point sends of fp32 samples (the
+engine computes in fp32, so nothing is lost by narrowing on the root; half the bytes travel).
+
+On the RCCL backend the received samples stay on the device: ``dist.recv`` fills a device tensor, the engine
+ingests its pointer (``repet_ctx_upload_device``), the result leaves through ``repet_ctx_download_device``
+into the tensor that is sent back -- no host bounce on the worker ranks.
 
 ``separate_fn`` / ``range_fn`` default to the HIP engine on this rank's device; the CPU tests inject
 stand-ins so the sharding and merge logic runs under gloo without a GPU.
@@ -29,35 +34,107 @@ def segment_ranges(n_segments, world_size):
     return out
 
 
+def extended_plan(number_samples, segment_length, segment_step):
+    """(number of segments, list of (start, length)) of ``extended`` for sizes in samples (repet.py:266-281,306-322):
+    one segment when the clip is shorter than a segment plus a step; else segments every ``segment_step`` samples, the
+    last one taking everything that is left."""
+    n, length, step = int(number_samples), int(segment_length), int(segment_step)
+    if n < length + step:
+        return 1, [(0, n)]
+    count = 1 + (n - length) // step
+    segments = [(j * step, length) for j in range(count - 1)]
+    segments.append(((count - 1) * step, n - (count - 1) * step))
+    return count, segments
+
+
+def segment_window(segments, first, count):
+    """Samples [lo, hi) that segments ``first .. first+count-1`` read and write: all a rank needs of the clip."""
+    if count <= 0:
+        return 0, 0
+    lo = segments[first][0]
+    start, length = segments[first + count - 1]
+    return lo, start + length
+
+
+# ---- the HIP engine on this rank's device ---------------------------------------------------------------------------
+_contexts = {}
+
+
+def _context(device):
+    import repet
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = repet.Context(device)
+    return ctx
+
+
 def _engine_separate(algo, device):
+    """clip -> background, for host arrays (float64 in, float64 out) and for fp32 device tensors (tensor in, tensor out:
+    device-resident ingest and egress, no host bounce)."""
     import repet
 
     def run(x, fs):
+        import torch
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            ctx = _context(x.device.index)
+            torch.cuda.current_stream(x.device).synchronize()          # the recv that filled x has completed
+            ctx.upload_device(x.data_ptr(), x.shape[0], x.shape[1])
+            ctx.execute(algo, repet.derive_params(fs))
+            out = torch.empty_like(x)
+            ctx.download_device(out.data_ptr())
+            return out
         repet.set_device(device)
         return getattr(repet, algo)(x, fs)
     return run
 
 
-def _send(t, dst, dist, device):
-    dist.send(t.to(device), dst=dst)
+def _engine_extended_range(device):
+    """(window of the clip, fs, first, count, total samples, first sample of the window) -> the window's share of
+    ``extended``: fp32 device tensor in/out on the RCCL path, host arrays otherwise."""
+    import repet
+
+    def run(window, fs, first, count, number_samples_total, first_sample):
+        import torch
+        ctx = _context(window.device.index if isinstance(window, torch.Tensor) and window.is_cuda else device)
+        params = repet.derive_params(fs)
+        if isinstance(window, torch.Tensor) and window.is_cuda:
+            torch.cuda.current_stream(window.device).synchronize()
+            ctx.upload_device(window.data_ptr(), window.shape[0], window.shape[1])
+            ctx.set_window(number_samples_total, first_sample)
+            ctx.execute_extended_range(params, first, count)
+            out = torch.empty_like(window)
+            ctx.download_device(out.data_ptr())
+            return out
+        ctx.upload(np.asarray(window))
+        ctx.set_window(number_samples_total, first_sample)
+        ctx.execute_extended_range(params, first, count)
+        return ctx.download()
+    return run
 
 
-def _recv(shape, dtype, src, dist, device):
+# ---- transport ------------------------------------------------------------------------------------------------------
+def _wire(array, dtype, dev):
+    """A host array as a tensor of the wire dtype on the communication device."""
     import torch
-    t = torch.empty(shape, dtype=dtype, device=device)
-    dist.recv(t, src=src)
-    return t.cpu()
+    return torch.from_numpy(np.ascontiguousarray(array, dtype=dtype)).to(dev)
 
 
-def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=None, root=0):
+def _host(t):
+    return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+
+
+def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=None, root=0, wire_dtype=np.float32):
     """Collective over the default process group. ``clips`` (list of (N_i, C_i) float arrays) is read on
-    ``root`` only; every rank separates its share; ``root`` returns the list of background signals in
-    the original order, the other ranks return None."""
+    ``root`` only; every rank separates its share; ``root`` returns the list of background signals (float64) in
+    the original order, the other ranks return None. Samples travel as ``wire_dtype`` (fp32: what the engine computes
+    in); on the RCCL backend a worker rank's clips never leave the device."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", device if device is not None else rank)
+    on_gpu = dist.get_backend() != "gloo"
+    dev = torch.device("cuda", device if device is not None else rank) if on_gpu else torch.device("cpu")
     fn = separate_fn or _engine_separate(algo, dev.index or 0)
+    tdtype = torch.float32 if np.dtype(wire_dtype) == np.float32 else torch.float64
 
     meta = [None]
     if rank == root:
@@ -66,59 +143,97 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     shapes = meta[0]
     shares = deal_clips([s[0] for s in shapes], world)
 
-    mine = {}
     if rank == root:
-        for r, ids in enumerate(shares):
-            for i in ids:
-                x = torch.from_numpy(np.ascontiguousarray(clips[i], dtype=np.float64))
-                if r == root:
-                    mine[i] = x.numpy()
-                else:
-                    _send(x, r, dist, dev)
-    else:
-        for i in shares[rank]:
-            mine[i] = _recv(shapes[i], torch.float64, root, dist, dev).numpy()
-
-    done = {i: np.ascontiguousarray(fn(x, sampling_frequency), dtype=np.float64) for i, x in mine.items()}
-
-    if rank == root:
+        pending = []
+        for r, ids in enumerate(shares):                       # the workers' clips leave first, then the root computes
+            if r != root:
+                for i in ids:
+                    pending.append(dist.isend(_wire(clips[i], wire_dtype, dev), dst=r))
         out = [None] * len(shapes)
+        for i in shares[root]:
+            out[i] = np.ascontiguousarray(_host(fn(np.asarray(clips[i]), sampling_frequency)), dtype=np.float64)
+        for req in pending:
+            req.wait()
         for r, ids in enumerate(shares):
-            for i in ids:
-                out[i] = done[i] if r == root else _recv(shapes[i], torch.float64, r, dist, dev).numpy()
+            if r != root:
+                for i in ids:
+                    t = torch.empty(shapes[i], dtype=tdtype, device=dev)
+                    dist.recv(t, src=r)
+                    out[i] = _host(t).astype(np.float64)
         return out
+
+    received = []
     for i in shares[rank]:
-        _send(torch.from_numpy(done[i]), root, dist, dev)
+        t = torch.empty(shapes[i], dtype=tdtype, device=dev)
+        dist.recv(t, src=root)
+        received.append(t)
+    for t in received:
+        y = fn(t if on_gpu else t.numpy(), sampling_frequency)
+        if not isinstance(y, torch.Tensor):
+            y = _wire(y, wire_dtype, dev)
+        dist.send(y.to(tdtype), dst=root)
     return None
 
 
-def _engine_extended_range(device):
-    import repet
-
-    def run(x, fs, first, count):
-        ctx = repet.Context(device)
-        try:
-            ctx.upload(x)
-            ctx.execute_extended_range(repet.derive_params(fs), first, count)
-            return ctx.download()
-        finally:
-            ctx.close()
-    return run
-
-
-def extended_sharded(audio_signal, sampling_frequency, n_segments, range_fn=None, device=None, root=0):
+def extended_sharded(audio_signal, sampling_frequency, segment_length, segment_step, range_fn=None, device=None, root=0,
+                     wire_dtype=np.float32):
     """``repet.extended`` of one long clip with its segments split over the ranks.
 
-    Every rank holds ``audio_signal`` (broadcast it first if only the root has it), runs its contiguous
-    range of segments and returns a full-length array that is zero outside its range; the partial results
-    are summed onto ``root`` (one reduce of the waveform, the only collective on this path)."""
+    ``audio_signal`` is read on ``root`` only; ``segment_length`` / ``segment_step`` are in SAMPLES
+    (``round(repet.segment_length * fs)``, repet.py:266-267). Rank r gets a contiguous range of segments and is sent
+    only the samples those segments cover -- (count + 1) segment steps with the default 50 % overlap, about 1/world of
+    the clip -- runs them with the whole clip's cross-fade weights (``repet_ctx_set_window``) and returns
+    its window; the root adds the windows into place, which touches each of the world-1 shard borders' overlap once.
+    Returns the float64 background on ``root``, None elsewhere."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", device if device is not None else rank)
+    on_gpu = dist.get_backend() != "gloo"
+    dev = torch.device("cuda", device if device is not None else rank) if on_gpu else torch.device("cpu")
     fn = range_fn or _engine_extended_range(dev.index or 0)
-    first, count = segment_ranges(n_segments, world)[rank]
-    part = fn(audio_signal, sampling_frequency, first, count) if count > 0 else np.zeros(np.shape(audio_signal))
-    t = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float64)).to(dev)
-    dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy() if rank == root else None
+    tdtype = torch.float32 if np.dtype(wire_dtype) == np.float32 else torch.float64
+
+    meta = [None]
+    if rank == root:
+        meta = [(int(np.shape(audio_signal)[0]), int(np.shape(audio_signal)[1]))]
+    dist.broadcast_object_list(meta, src=root)
+    n, channels = meta[0]
+    n_segments, segments = extended_plan(n, segment_length, segment_step)
+    ranges = segment_ranges(n_segments, world)
+    windows = [segment_window(segments, first, count) for first, count in ranges]
+
+    def run_mine(window):
+        first, count = ranges[rank]
+        return fn(window, sampling_frequency, first, count, n, windows[rank][0])
+
+    if rank == root:
+        x = np.asarray(audio_signal)
+        pending = []
+        for r in range(world):
+            lo, hi = windows[r]
+            if r != root and hi > lo:
+                pending.append(dist.isend(_wire(x[lo:hi], wire_dtype, dev), dst=r))
+        total = torch.zeros((n, channels), dtype=tdtype, device=dev)
+        lo, hi = windows[root]
+        if hi > lo:
+            mine = run_mine(_wire(x[lo:hi], wire_dtype, dev) if on_gpu else np.ascontiguousarray(x[lo:hi], dtype=wire_dtype))
+            total[lo:hi] += mine if isinstance(mine, torch.Tensor) else _wire(mine, wire_dtype, dev)
+        for req in pending:
+            req.wait()
+        for r in range(world):                                  # fixed order: the sums do not depend on arrival times
+            lo, hi = windows[r]
+            if r != root and hi > lo:
+                part = torch.empty((hi - lo, channels), dtype=tdtype, device=dev)
+                dist.recv(part, src=r)
+                total[lo:hi] += part
+        return _host(total).astype(np.float64)
+
+    lo, hi = windows[rank]
+    if hi > lo:
+        window = torch.empty((hi - lo, channels), dtype=tdtype, device=dev)
+        dist.recv(window, src=root)
+        part = run_mine(window if on_gpu else window.numpy())
+        if not isinstance(part, torch.Tensor):
+            part = _wire(part, wire_dtype, dev)
+        dist.send(part.to(tdtype), dst=root)
+    return None

@@ -50,17 +50,39 @@ def _clips():
 
 def _case_clips(rank, world):
     clips = _clips() if rank == 0 else None
-    got = parallel.separate_clips("original", clips, FS, separate_fn=lambda x, fs: orc.original(x, fs))
-    if rank != 0:
-        return None
-    return {f"clip{i}": y for i, y in enumerate(got)}
+    out = {}
+    for name, wire in (("f64", np.float64), ("f32", np.float32)):
+        got = parallel.separate_clips("original", clips, FS, separate_fn=lambda x, fs: orc.original(np.asarray(x, dtype=np.float64), fs),
+                                      wire_dtype=wire)
+        if rank == 0:
+            out.update({f"{name}_clip{i}": y for i, y in enumerate(got)})
+    return out if rank == 0 else None
+
+
+def _window_range(window, fs, first, count, n_total, first_sample, p=None):
+    """Stand-in for the engine on a rank: the rank holds only `window` = samples [first_sample, first_sample + len) of the
+    clip; the oracle wants a whole clip, and reads nothing outside the window for these segments."""
+    window = np.asarray(window, dtype=np.float64)
+    x = np.zeros((n_total, window.shape[1]))
+    x[first_sample:first_sample + len(window)] = window
+    return orc.extended_range(x, fs, first, count, p)[first_sample:first_sample + len(window)]
 
 
 def _case_extended(rank, world):
-    x = synth(27.0, FS, 2, 31)
-    n_seg = len(orc.extended_plan(len(x), FS, orc.Params())[0])
-    got = parallel.extended_sharded(x, FS, n_seg, range_fn=lambda a, fs, first, count: orc.extended_range(a, fs, first, count))
-    return {"y": got, "n_seg": np.int64(n_seg)} if rank == 0 else None
+    x = synth(27.0, FS, 2, 31) if rank == 0 else None
+    p = orc.Params()
+    out = {}
+    for name, wire in (("f64", np.float64), ("f32", np.float32)):
+        got = parallel.extended_sharded(x, FS, round(p.segment_length * FS), round(p.segment_step * FS), range_fn=_window_range, wire_dtype=wire)
+        if rank == 0:
+            out[name] = got
+    # a step shorter than the overlap: windows of neighbouring ranks overlap by several segments' worth
+    p2 = orc.Params(segment_length=8, segment_step=2)
+    got = parallel.extended_sharded(x, FS, 8 * FS, 2 * FS, wire_dtype=np.float64,
+                                    range_fn=lambda w, fs, first, count, n, s0: _window_range(w, fs, first, count, n, s0, p2))
+    if rank == 0:
+        out["short_step"] = got
+    return out if rank == 0 else None
 
 
 def test_deal_clips_longest_first_round_robin():
@@ -91,14 +113,34 @@ def test_extended_is_the_sum_of_segment_ranges():
     assert np.max(np.abs(parts - full)) < 1e-12
 
 
+def test_extended_plan_and_windows_match_the_oracle():
+    """parallel.extended_plan restates repet.py:266-281,306-322 for the host logic; a rank's window is what its segments
+    touch: (count + 1) steps with the default 50 % overlap -- about 1/world of the clip, not the clip."""
+    for seconds, length, step in [(27.0, 10, 5), (14.9, 10, 5), (15.1, 10, 5), (31.7, 8, 2), (36.0, 10, 7.5)]:
+        n = round(seconds * FS)
+        p = orc.Params(segment_length=length, segment_step=step)
+        segs, _ = orc.extended_plan(n, FS, p)
+        count, mine = parallel.extended_plan(n, round(length * FS), round(step * FS))
+        assert count == len(segs) and mine == [(int(a), int(b)) for a, b in segs]
+    count, segs = parallel.extended_plan(26460000, 441000, 220500)             # cfg 3: 600 s at 44.1 kHz
+    assert count == 119
+    windows = [parallel.segment_window(segs, f, c) for f, c in parallel.segment_ranges(count, 8)]
+    assert windows[0] == (0, 16 * 220500) and windows[7] == (105 * 220500, 26460000)
+    assert all(hi - lo <= 16 * 220500 + 220500 for lo, hi in windows)          # <= (15 + 1) steps (+ the last segment's remainder)
+    assert parallel.segment_window(segs, 5, 0) == (0, 0)
+
+
 def test_scatter_separate_gather_two_ranks(tmp_path):
     got = _run("_case_clips", tmp_path)
     for i, x in enumerate(_clips()):
-        assert np.array_equal(got[f"clip{i}"], orc.original(x, FS))
+        assert np.array_equal(got[f"f64_clip{i}"], orc.original(x, FS))
+        # fp32 on the wire (what the engine computes in): a worker's clips are narrowed on the way out and back
+        assert np.max(np.abs(got[f"f32_clip{i}"] - orc.original(x, FS))) < 1e-5
 
 
 def test_extended_segments_sharded_over_two_ranks(tmp_path):
     got = _run("_case_extended", tmp_path)
     x = synth(27.0, FS, 2, 31)
-    assert int(got["n_seg"]) == 4
-    assert np.max(np.abs(got["y"] - orc.extended(x, FS))) < 1e-12
+    assert np.max(np.abs(got["f64"] - orc.extended(x, FS))) < 1e-12
+    assert np.max(np.abs(got["f32"] - orc.extended(x, FS))) < 2e-6              # fp32 on the wire and in the root's sums
+    assert np.max(np.abs(got["short_step"] - orc.extended(x, FS, orc.Params(segment_length=8, segment_step=2)))) < 1e-12

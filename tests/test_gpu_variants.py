@@ -169,6 +169,68 @@ def test_extended_segment_ranges_add_up():
         repet.Context(0).execute_extended_range(p, 0, 1)      # nothing uploaded
 
 
+def test_device_resident_ingest_and_egress():
+    """repet_ctx_upload_device / repet_ctx_download_device: fp32 samples that are already in device memory (what an RCCL
+    recv leaves there) go in and come out without a host bounce, bit-identical to the host path."""
+    import torch
+    fs = 22050
+    x = synth(14.0, fs, 2, 5)
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    for algo in ("sim", "original", "simonline"):
+        ctx.upload(x)
+        ctx.execute(algo, p)
+        want = ctx.download()
+        t = torch.from_numpy(x.astype(np.float32)).to("cuda:0")
+        torch.cuda.synchronize()
+        ctx.upload_device(t.data_ptr(), t.shape[0], t.shape[1])
+        t.zero_()                                                   # the source may be reused at once
+        ctx.execute(algo, p)
+        out = torch.empty((len(x), 2), dtype=torch.float32, device="cuda:0")
+        ctx.download_device(out.data_ptr())
+        assert np.array_equal(out.cpu().numpy().astype(np.float64), want), algo
+        assert np.array_equal(ctx.download(), want)
+    ctx.close()
+    # and through the multi-GPU host logic's engine adapters (the functions a worker rank runs on what it received)
+    run = parallel._engine_separate("sim", 0)
+    t = torch.from_numpy(x.astype(np.float32)).to("cuda:0")
+    assert np.array_equal(run(t, fs).cpu().numpy().astype(np.float64), repet.sim(x, fs))
+
+
+@pytest.mark.parametrize("seg_len,seg_step,seconds,fs", [(10.0, 5.0, 47.3, 16000), (6.0, 1.5, 29.0, 8000), (10.0, 7.5, 52.0, 22050)])
+def test_extended_on_windows_of_the_clip(seg_len, seg_step, seconds, fs, monkeypatch):
+    """Multi-GPU `extended` as SURVEY 8e specifies it: a rank holds only the samples its own segments cover
+    (repet_ctx_set_window), runs them with the WHOLE clip's cross-fade weights and returns its window; the windows added
+    into place give repet.extended of the clip to fp32 rounding."""
+    import torch
+    monkeypatch.setattr(repet, "segment_length", seg_len)
+    monkeypatch.setattr(repet, "segment_step", seg_step)
+    x = synth(seconds, fs, 2, 12)
+    want = repet.extended(x, fs)
+    p = repet.derive_params(fs)
+    n_seg, segs = parallel.extended_plan(len(x), p.seg_len_samples, p.seg_step_samples)
+    assert n_seg == _native.lib().repet_extended_segment_count(len(x), p) and n_seg >= 4
+    run = parallel._engine_extended_range(0)
+    total = np.zeros(x.shape, dtype=np.float32)
+    for first, count in parallel.segment_ranges(n_seg, 3):
+        lo, hi = parallel.segment_window(segs, first, count)
+        assert hi - lo < 0.6 * len(x)
+        window = torch.from_numpy(x[lo:hi].astype(np.float32)).to("cuda:0")
+        total[lo:hi] += run(window, fs, first, count, len(x), lo).cpu().numpy()          # device tensor in, device tensor out
+        host = run(x[lo:hi], fs, first, count, len(x), lo)                                 # the host-array form of the same
+        assert np.array_equal(host, run(window, fs, first, count, len(x), lo).cpu().numpy().astype(np.float64))
+    # one fp32 rounding of difference where two ranks' windows overlap (the single-GPU accumulation is a fused multiply-add)
+    assert rms_err(total, want) < 1e-7 and np.max(np.abs(total - want)) < 1e-6
+    ctx = repet.Context(0)
+    ctx.upload(x[:len(x) // 2])
+    ctx.set_window(len(x), 0)
+    with pytest.raises(ValueError):
+        ctx.execute_extended_range(p, n_seg - 1, 1)                 # the last segment's samples are not in this window
+    with pytest.raises(ValueError):
+        ctx.execute("original", p)                                  # a window is only good for segment ranges
+    ctx.close()
+
+
 @pytest.mark.parametrize("seg_len,seg_step,fs,channels,seconds", [(5.0, 1.25, 44100, 3, 24.65), (8.0, 2.0, 16000, 2, 31.0),
                                                                   (10.0, 7.5, 22050, 1, 36.0), (6.0, 1.0, 8000, 2, 23.0)])
 def test_extended_with_other_overlaps(seg_len, seg_step, fs, channels, seconds, monkeypatch):
