@@ -135,6 +135,32 @@ int repet_ctx_download_device(repet_ctx* ctx, float* dev_out);
  * Cleared by every upload; (0, 0) clears it. */
 int repet_ctx_set_window(repet_ctx* ctx, int64_t n_total, int64_t sample0);
 
+/* ---- WAVE files either side of the path (wavread / wavwrite, repet.py:914-946; README.md:62-72) -------------------
+ * repet_wav_parse      : header of a RIFF/WAVE file image (PCM 8/16/24/32-bit, IEEE float 32/64-bit, plain or
+ *                        WAVE_FORMAT_EXTENSIBLE); REPET_ERR_BAD_ARG with a message for anything else.
+ * repet_ctx_upload_wav : the file's samples become the resident clip: the RAW bytes cross PCIe (2-3 bytes per sample, not
+ *                        8), are decoded on the device and normalised exactly as wavread does -- divided by
+ *                        2^(8*itemsize-1) of the array scipy.io.wavfile.read returns (repet.py:929; 24-bit PCM counts
+ *                        as int32, float files are divided as well).
+ * repet_ctx_result_wav : image of the file wavwrite(background | audio - background, fs, file) writes for a float64
+ *                        (dtype REPET_F64) or float32 (REPET_F32) array: IEEE-float WAVE, fmt + fact + data chunks.
+ *                        which: 1 background, 2 foreground. capacity >= 58 + n_samples*n_channels*itemsize. */
+typedef struct repet_wav_info {
+    int32_t format;              /* 1 PCM, 3 IEEE float (the sub-format of an extensible header) */
+    int32_t n_channels;
+    int32_t sampling_frequency;
+    int32_t bits_per_sample;
+    int32_t bytes_per_sample;    /* container width: block_align / n_channels */
+    int32_t reserved0;
+    int64_t data_offset;         /* first byte of the samples in the file image */
+    int64_t n_samples;           /* per channel */
+} repet_wav_info;
+int repet_wav_parse(const void* file_bytes, int64_t n_bytes, repet_wav_info* info);
+int repet_ctx_upload_wav(repet_ctx* ctx, const void* file_bytes, int64_t n_bytes, repet_wav_info* info_out);
+int repet_ctx_result_wav(repet_ctx* ctx, int which, int dtype, void* file_out, int64_t capacity, int64_t* n_written);
+/* sampling frequency repet_ctx_result_wav writes into the header when the clip did not come from repet_ctx_upload_wav */
+int repet_ctx_set_sampling_frequency(repet_ctx* ctx, int32_t sampling_frequency);
+
 /* Pinned host buffers from a recycling pool, for results: repet_ctx_download / repet_run write into any memory, but a
  * buffer that is already faulted in and pinned takes the copy at link speed (a fresh malloc / np.empty of a 3-minute
  * clip page-faults 31 000 times on first touch). repet_host_free returns the buffer to the pool; NULL when the pool

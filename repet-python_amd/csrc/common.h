@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/repet_hip.h"
 #include <vector>
 
 namespace repet {
@@ -223,6 +224,12 @@ struct StagingRing {
 // dtype: 0 float32, 1 float64, 2 int16 (REPET_F32 / F64 / I16)
 hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s);
 hipError_t staged_download(StagingRing& ring, const float* src, double* dst, size_t count, hipStream_t s);
+hipError_t staged_upload_bytes(StagingRing& ring, const void* src, void* dst, size_t n_bytes, hipStream_t s);
+// WAVE files (wav.hip): header parsing on the host, PCM decode + wavread's normalisation on the device
+const char* wav_parse(const void* file, int64_t n_bytes, ::repet_wav_info* info);
+int wav_itemsize(const ::repet_wav_info& w);
+hipError_t launch_decode_pcm(const void* raw, int format, int width, float* dst, int64_t n, hipStream_t s);
+int64_t wav_float_header(unsigned char* out, int sampling_frequency, int n_channels, int64_t n_samples, int item_bytes);
 // pinned host buffers from a recycling pool (result arrays of the Python module); nullptr when the pool declines
 void* host_alloc(size_t bytes);
 void host_free(void* ptr);
@@ -231,6 +238,7 @@ void host_free(void* ptr);
 hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);
 hipError_t launch_convert_out(const float* src, double* dst, int64_t count, hipStream_t s);
 hipError_t launch_foreground(const float* audio, const float* background, double* dst, int64_t count, hipStream_t s);
+hipError_t launch_foreground_f32(const float* audio, const float* background, float* dst, int64_t count, hipStream_t s);
 hipError_t launch_channel_mean(const float* audio, const float* background, int which, int n_channels, float* dst,
                                int64_t n_samples, hipStream_t s);
 hipError_t launch_square(const float* src, float* dst, int64_t count, hipStream_t s);

@@ -97,6 +97,7 @@ struct repet_ctx {
     // (multi-GPU `extended`: a rank holds only the samples of its own segment range); 0 = the resident clip is whole
     int64_t win_total = 0, win_offset = 0;
     bool win_skip_clear = false;  // exec_extended cleared `out` itself (window mode)
+    int32_t last_fs = 0;          // sampling frequency of the resident clip when it came from a WAVE file (for repet_ctx_result_wav)
     bool clip_loop = false;       // true while run_algo works through the clips one by one
     int32_t n_channels = 0;
     // workspaces
@@ -1096,6 +1097,81 @@ int repet_ctx_download(repet_ctx* c, double* out) {
     const int64_t count = c->n_samples * c->n_channels * c->n_clips;
     if (count == 0) return REPET_OK;
     HIP_TRY(staged_download(c->ring, c->out.as<float>(), out, (size_t)count, c->stream));
+    return REPET_OK;
+}
+
+int repet_wav_parse(const void* file_bytes, int64_t n_bytes, repet_wav_info* info) {
+    const char* err = wav_parse(file_bytes, n_bytes, info);
+    return err ? fail(REPET_ERR_BAD_ARG, err) : REPET_OK;
+}
+
+int repet_ctx_upload_wav(repet_ctx* c, const void* file_bytes, int64_t n_bytes, repet_wav_info* info_out) {
+    if (!c || !file_bytes) return fail(REPET_ERR_BAD_ARG, "null argument");
+    repet_wav_info w;
+    RP_TRY(repet_wav_parse(file_bytes, n_bytes, &w));
+    if (info_out) *info_out = w;
+    DeviceGuard guard(c->device);
+    const int64_t count = w.n_samples * w.n_channels;
+    const size_t raw_bytes = (size_t)count * w.bytes_per_sample;
+    HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    HIP_TRY(c->staging.ensure(std::max<size_t>(raw_bytes, 256)));
+    HIP_TRY(staged_upload_bytes(c->ring, static_cast<const unsigned char*>(file_bytes) + w.data_offset, c->staging.p, raw_bytes, c->stream));
+    HIP_TRY(launch_decode_pcm(c->staging.p, w.format, w.bytes_per_sample, c->audio.as<float>(), count, c->stream));
+    c->n_samples = w.n_samples; c->n_channels = w.n_channels; c->n_clips = 1; c->clip_base = 0;
+    c->win_total = 0; c->win_offset = 0;
+    c->last_fs = w.sampling_frequency;
+    return REPET_OK;
+}
+
+int repet_ctx_result_wav(repet_ctx* c, int which, int dtype, void* file_out, int64_t capacity, int64_t* n_written) {
+    if (!c || !file_out || !n_written) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (which != 1 && which != 2) return fail(REPET_ERR_BAD_ARG, "which must be 1 (background) or 2 (foreground)");
+    if (dtype != REPET_F64 && dtype != REPET_F32) return fail(REPET_ERR_BAD_ARG, "float64 or float32 results");
+    if (c->last_algo < 0 || c->n_clips != 1) return fail(REPET_ERR_BAD_ARG, "no separation of a single clip has been run on this context");
+    if (c->last_fs <= 0) return fail(REPET_ERR_BAD_ARG, "the sampling frequency is unknown: the clip did not come from repet_ctx_upload_wav (set it with repet_ctx_set_sampling_frequency)");
+    const int item = dtype == REPET_F64 ? 8 : 4;
+    const int64_t count = c->n_samples * c->n_channels;
+    const int64_t need = 58 + count * item;
+    if (capacity < need) return fail(REPET_ERR_BAD_ARG, "capacity too small for the file image");
+    DeviceGuard guard(c->device);
+    unsigned char* out = static_cast<unsigned char*>(file_out);
+    const int64_t hdr = wav_float_header(out, c->last_fs, c->n_channels, c->n_samples, item);
+    if (count > 0) {
+        if (dtype == REPET_F64) {
+            // the header is 58 bytes, so the samples are 2-byte aligned in the image: widen into an aligned bounce of the
+            // pinned pool and copy (the copy is cheap next to the transfer)
+            double* tmp = static_cast<double*>(host_alloc((size_t)count * 8));
+            double* dst = tmp ? tmp : static_cast<double*>(malloc((size_t)count * 8));
+            if (!dst) return fail(REPET_ERR_OOM, "host memory");
+            int rc = REPET_OK;
+            if (which == 1) {
+                hipError_t e = staged_download(c->ring, c->out.as<float>(), dst, (size_t)count, c->stream);
+                if (e != hipSuccess) rc = fail(REPET_ERR_HIP, hipGetErrorString(e));
+            } else {
+                rc = repet_ctx_download_foreground(c, dst);
+            }
+            if (rc == REPET_OK) std::memcpy(out + hdr, dst, (size_t)count * 8);
+            if (tmp) host_free(tmp); else free(dst);
+            if (rc != REPET_OK) return rc;
+        } else {
+            const float* src = c->out.as<float>();
+            if (which == 2) {
+                HIP_TRY(c->tmp_a.ensure((size_t)count * sizeof(float)));
+                HIP_TRY(launch_foreground_f32(c->audio.as<float>(), c->out.as<float>(), c->tmp_a.as<float>(), count, c->stream));
+                src = c->tmp_a.as<float>();
+            }
+            HIP_TRY(hipMemcpyAsync(out + hdr, src, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    *n_written = need;
+    return REPET_OK;
+}
+
+int repet_ctx_set_sampling_frequency(repet_ctx* c, int32_t sampling_frequency) {
+    if (!c || sampling_frequency <= 0) return fail(REPET_ERR_BAD_ARG, "bad argument");
+    c->last_fs = sampling_frequency;
     return REPET_OK;
 }
 

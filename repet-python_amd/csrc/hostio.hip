@@ -145,6 +145,31 @@ hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* d
     return hipSuccess;
 }
 
+// raw bytes (a file's PCM payload) -> device, through the same ring
+hipError_t staged_upload_bytes(StagingRing& ring, const void* src, void* dst, size_t n_bytes, hipStream_t s) {
+    hipError_t e = ring.ensure();
+    if (e != hipSuccess) return e;
+    HostWorkers& pool = HostWorkers::get();
+    const size_t slot_bytes = StagingRing::kSlotElems * sizeof(float);
+    const size_t n_chunks = (n_bytes + slot_bytes - 1) / slot_bytes;
+    for (size_t c = 0; c < n_chunks; ++c) {
+        const int slot = (int)(c % StagingRing::kSlots);
+        if (ring.busy[slot]) { e = hipEventSynchronize(ring.event[slot]); if (e != hipSuccess) return e; }
+        const size_t lo = c * slot_bytes, cnt = std::min(slot_bytes, n_bytes - lo);
+        unsigned char* stage = reinterpret_cast<unsigned char*>(ring.base + (size_t)slot * StagingRing::kSlotElems);
+        pool.run([&](int part, int parts) {
+            const size_t a = cnt * part / parts, b = cnt * (part + 1) / parts;
+            std::memcpy(stage + a, static_cast<const unsigned char*>(src) + lo + a, b - a);
+        }, cnt / 4);
+        e = hipMemcpyAsync(static_cast<unsigned char*>(dst) + lo, stage, cnt, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(ring.event[slot], s);
+        if (e != hipSuccess) return e;
+        ring.busy[slot] = true;
+    }
+    return hipSuccess;
+}
+
 // src (device fp32, produced by work already enqueued on `s`) -> dst (host float64); returns when dst is complete.
 hipError_t staged_download(StagingRing& ring, const float* src, double* dst, size_t count, hipStream_t s) {
     hipError_t e = ring.ensure();

@@ -1260,6 +1260,16 @@ hipError_t launch_foreground(const float* audio, const float* background, double
     hipLaunchKernelGGL(foreground_kernel, dim3(stream_grid(n)), dim3(256), 0, s, audio, background, dst, n);
     return hipGetLastError();
 }
+__global__ void foreground_f32_kernel(const float* audio, const float* background, float* dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (float)((double)audio[i] - (double)background[i]);
+}
+hipError_t launch_foreground_f32(const float* audio, const float* background, float* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(foreground_f32_kernel, dim3(stream_grid(n)), dim3(256), 0, s, audio, background, dst, n);
+    return hipGetLastError();
+}
 hipError_t launch_channel_mean(const float* audio, const float* background, int which, int C, float* dst, int64_t n,
                                hipStream_t s) {
     if (n <= 0) return hipSuccess;

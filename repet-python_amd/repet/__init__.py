@@ -332,16 +332,72 @@ def _rank_columns(audio_spectrogram):
 
 # ---- file / display utilities of the reference (host side, off the hot path) --------------------------------
 def wavread(audio_file):
-    """Read a WAVE file, integers scaled to [-1, 1) by their bit depth (repet.py:914-931)."""
-    import scipy.io.wavfile
-    sampling_frequency, samples = scipy.io.wavfile.read(audio_file)
-    return samples / pow(2, samples.itemsize * 8 - 1), sampling_frequency
+    """Read a WAVE file, integers scaled to [-1, 1) by their bit depth (repet.py:914-931): the array SciPy would return,
+    divided by ``2 ** (8 * itemsize - 1)`` -- 24-bit PCM counts as int32 (sample in the top three bytes), 8-bit PCM is
+    unsigned, and float files are divided too (a quirk of the reference, kept). The header is parsed by the library
+    (``repet_wav_parse``); formats it does not handle go through ``scipy.io.wavfile`` like the reference."""
+    image = np.fromfile(audio_file, dtype=np.uint8)
+    info = _native.WavInfo()
+    lib = _native.lib()
+    if lib.repet_wav_parse(_native.ptr(image), image.size, info) != 0:
+        import scipy.io.wavfile
+        sampling_frequency, samples = scipy.io.wavfile.read(audio_file)
+        return samples / pow(2, samples.itemsize * 8 - 1), sampling_frequency
+    count = info.n_samples * info.n_channels
+    width = info.bytes_per_sample
+    raw = image[info.data_offset:info.data_offset + count * width]
+    if info.format == 3:
+        samples = raw.view("<f4" if width == 4 else "<f8")
+    elif width == 1:
+        samples = raw
+    elif width == 3:                                          # packed 24-bit -> int32 with the sample in the top bytes
+        wide = np.zeros((count, 4), dtype=np.uint8)
+        wide[:, 1:] = raw.reshape(count, 3)
+        samples = wide.view("<i4").ravel()
+    else:
+        samples = raw.view("<i2" if width == 2 else "<i4")
+    samples = samples.reshape(info.n_samples, info.n_channels) if info.n_channels > 1 else samples.reshape(info.n_samples)
+    return samples / pow(2, samples.itemsize * 8 - 1), int(info.sampling_frequency)
 
 
 def wavwrite(audio_signal, sampling_frequency, audio_file):
-    """Write a WAVE file with SciPy, dtype as given (repet.py:934-946)."""
-    import scipy.io.wavfile
-    scipy.io.wavfile.write(audio_file, sampling_frequency, audio_signal)
+    """Write a WAVE file with the dtype as given (repet.py:934-946): byte for byte what ``scipy.io.wavfile.write``
+    produces for float64 / float32 (IEEE-float format: 18-byte fmt chunk, fact chunk) and int16 / int32 / uint8 (PCM)
+    arrays; other dtypes go to SciPy (which raises for most of them, as in the reference)."""
+    import struct
+    data = np.asarray(audio_signal)
+    if data.dtype.name not in ("float64", "float32", "int16", "int32", "uint8") or data.ndim not in (1, 2) or data.nbytes > 0xFFFFFF00:
+        import scipy.io.wavfile
+        scipy.io.wavfile.write(audio_file, sampling_frequency, audio_signal)
+        return
+    channels = 1 if data.ndim == 1 else data.shape[1]
+    item = data.dtype.itemsize
+    is_float = data.dtype.kind == "f"
+    fmt = struct.pack("<HHIIHH", 3 if is_float else 1, channels, int(sampling_frequency), int(sampling_frequency) * item * channels,
+                      channels * item, item * 8) + (b"\x00\x00" if is_float else b"")
+    head = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if is_float:
+        head += b"fact" + struct.pack("<II", 4, data.shape[0])
+    head += b"data" + struct.pack("<I", data.nbytes)
+    body = np.ascontiguousarray(data.astype(data.dtype.newbyteorder("<"), copy=False))
+    with open(audio_file, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 4 + len(head) + data.nbytes) + b"WAVE" + head)
+        body.tofile(fh)
+
+
+def separate_file(algo, audio_file, background_file=None, foreground_file=None, dtype=np.float64):
+    """``wavread`` -> ``algo`` -> ``wavwrite`` of the README example (README.md:62-72) without the samples visiting host
+    arrays in between: the file's raw PCM goes to the device, is decoded and normalised there, separated, and the
+    background / foreground (``audio - background``) come back as finished file images. Returns the sampling frequency.
+    The files equal ``wavwrite(algo(*wavread(audio_file)))`` resp. the same for ``audio - background``."""
+    ctx = _native.default_context(_device)
+    sampling_frequency = ctx.upload_wav(audio_file)
+    ctx.execute(algo, derive_params(sampling_frequency))
+    if background_file is not None:
+        ctx.write_wav(background_file, "background", dtype)
+    if foreground_file is not None:
+        ctx.write_wav(foreground_file, "foreground", dtype)
+    return sampling_frequency
 
 
 def specshow(audio_spectrogram, time_duration, maximum_frequency, xtick_step=1, ytick_step=1000):

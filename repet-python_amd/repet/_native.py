@@ -34,6 +34,13 @@ class Settings(C.Structure):
                 ("buffer_length", C.c_double), ("filter_order", C.c_int32), ("similarity_number", C.c_int32)]
 
 
+class WavInfo(C.Structure):
+    """repet_wav_info of include/repet_hip.h."""
+    _fields_ = [("format", C.c_int32), ("n_channels", C.c_int32), ("sampling_frequency", C.c_int32),
+                ("bits_per_sample", C.c_int32), ("bytes_per_sample", C.c_int32), ("reserved0", C.c_int32),
+                ("data_offset", C.c_int64), ("n_samples", C.c_int64)]
+
+
 class Timing(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("reserved0", C.c_int32), ("total_ms", C.c_float),
                 ("stage_ms", C.c_float * MAX_STAGES), ("stage_name", (C.c_char * 24) * MAX_STAGES),
@@ -63,6 +70,10 @@ _SIGNATURES = {
     "repet_ctx_upload_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
     "repet_ctx_download_device": (C.c_int, [_P, _P]),
     "repet_ctx_set_window": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "repet_wav_parse": (C.c_int, [_P, C.c_int64, C.POINTER(WavInfo)]),
+    "repet_ctx_upload_wav": (C.c_int, [_P, _P, C.c_int64, C.POINTER(WavInfo)]),
+    "repet_ctx_result_wav": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "repet_ctx_set_sampling_frequency": (C.c_int, [_P, C.c_int32]),
     "repet_host_alloc": (C.c_void_p, [C.c_size_t]),
     "repet_host_free": (None, [C.c_void_p]),
     "repet_ctx_execute_async": (C.c_int, [_P, C.c_int, C.POINTER(Params)]),
@@ -253,6 +264,27 @@ class Context:
         """The resident samples are ``[first_sample, first_sample + N)`` of a clip of ``number_samples_total`` samples
         (for ``execute_extended_range`` on a rank that holds only its own segments' samples)."""
         check(lib().repet_ctx_set_window(self._h, int(number_samples_total), int(first_sample)))
+
+    def upload_wav(self, audio_file):
+        """A WAVE file becomes the resident clip: its raw PCM bytes cross PCIe and are decoded and normalised on the
+        device exactly as ``repet.wavread`` would (repet.py:914-931). Returns the sampling frequency."""
+        image = np.fromfile(audio_file, dtype=np.uint8)
+        info = WavInfo()
+        check(lib().repet_ctx_upload_wav(self._h, ptr(image), image.size, C.byref(info)))
+        self.shape = (info.n_samples, info.n_channels)
+        return info.sampling_frequency
+
+    def write_wav(self, audio_file, which="background", dtype=np.float64, sampling_frequency=None):
+        """Write the background (or ``audio - background``) of the last run as the file ``repet.wavwrite`` writes for
+        an array of ``dtype`` float64 / float32 (repet.py:934-946), straight from the device result."""
+        if sampling_frequency is not None:
+            check(lib().repet_ctx_set_sampling_frequency(self._h, int(sampling_frequency)))
+        code = {"background": 1, "foreground": 2}[which]
+        item = np.dtype(dtype).itemsize
+        image = np.empty(58 + int(np.prod(self.shape)) * item, dtype=np.uint8)
+        written = C.c_int64()
+        check(lib().repet_ctx_result_wav(self._h, code, F64 if item == 8 else F32, ptr(image), image.size, C.byref(written)))
+        image[:written.value].tofile(audio_file)
 
     def execute(self, algo, params, timing=False):
         t = Timing() if timing else None
