@@ -103,15 +103,18 @@ hipError_t launch_gram_full(const float* A, int64_t T, int32_t FS, float* S, int
 // K3h (gram_f16.hip): the same S from the f16 matrix cores: the fp32 rows are split once into f16 halves hi, lo
 // (`planes`: 2 * count halves, interleaved per 32 components) and S = hi hi' + hi lo' + lo hi': fp32-class accuracy
 // at 3/16 of the fp32 MFMA time.
-// amax (nullable, device float): null = unit rows (fixed scale 2^7); else the matrix is scanned for its largest magnitude
-// first and scaled by the power of two that brings it to [2^13, 2^14); pass the same pointer to the band launcher.
-hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s, float* amax = nullptr);
+// launch_split_f16: unit rows (fixed scale 2^7). launch_split_f16_rows: a general matrix [n_rows][FS], every row scaled
+// by its own power of two (row_inv[row] = 1 / scale, to be passed to the band launcher).
+hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s);
+hipError_t launch_split_f16_rows(const float* src, void* planes, int64_t n_rows, int32_t FS, float* row_inv, hipStream_t s);
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s);
-// banded form (simonline: unit rows): band[t][l] = row t . row t+l; plane_batch_stride in halves (2 * Tpad * FS)
+// banded form: band[t][l] = row t . row t+l; plane_batch_stride in halves (2 * Tpad * FS); row_inv (nullable): per-row
+// inverse scales of launch_split_f16_rows, inv_batch_stride floats between clips
 hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
-                                int64_t band_batch_stride, hipStream_t s, const float* amax = nullptr);
+                                int64_t band_batch_stride, hipStream_t s, const float* row_inv = nullptr,
+                                int64_t inv_batch_stride = 0);
 // K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                             const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t a_batch_stride,

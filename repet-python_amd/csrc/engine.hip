@@ -104,7 +104,7 @@ struct repet_ctx {
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
     DevBuf peak_scratch;          // per-segment candidates of long similarity rows (launch_local_maxima)
     DevBuf beat_partial;          // chunk sums of the beat-spectrum windows (launch_band_window_sum)
-    DevBuf amax;                  // largest magnitude of the matrix being split (device scalar)
+    DevBuf amax;                  // inverse scale of every row of the matrix being split (scaled f16-split band Gram)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
     DevBuf R, Vs, rank_codes;     // rank codes of V, the sorted columns and the column-major codes (rank-domain median of `sim`, rank.hip)
@@ -235,10 +235,11 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
         const int64_t per_clip = round_up(T, kTile) * FS;
         const int64_t count = per_clip * B;
         HIP_TRY(c->Vh.ensure((size_t)count * 4));
-        HIP_TRY(c->amax.ensure(sizeof(float)));
-        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream, c->amax.as<float>()));
+        const int64_t rows_per_clip = round_up(T, kTile);
+        HIP_TRY(c->amax.ensure((size_t)rows_per_clip * B * sizeof(float)));          // one inverse scale per row
+        HIP_TRY(launch_split_f16_rows(A, c->Vh.p, rows_per_clip * B, FS, c->amax.as<float>(), c->stream));
         HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream,
-                                     c->amax.as<float>()));
+                                     c->amax.as<float>(), rows_per_clip));
         return REPET_OK;
     }
     if (unit_rows && gram_f16_enabled()) {
@@ -493,8 +494,18 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
     const int64_t last = count - 1;
     const int64_t uniform = std::min(first + n_seg, last) - first;  // equal-length segments in the range
-    if (uniform > 0)
-        RP_TRY(run_original(c, p, first * Hs, L, (int)uniform, Hs, c->periods.as<int32_t>(), true, (int)first, (int)count, O));
+    // the equal-length segments go through every stage as ONE batch -- in bounded batches, so that the workspaces of an
+    // hours-long recording stay at a few GB (a segment's spectra are about 15 MB at 44.1 kHz stereo)
+    constexpr int64_t kMaxSegmentBatch = 256;
+    for (int64_t done = 0; done < uniform; done += kMaxSegmentBatch) {
+        const int64_t nb = std::min(kMaxSegmentBatch, uniform - done);
+        repet_timing* timing = c->timing;
+        if (done > 0) c->timing = nullptr;                          // stages are listed once, for the first batch
+        const int rc = run_original(c, p, (first + done) * Hs, L, (int)nb, Hs, c->periods.as<int32_t>() + done, true,
+                                    (int)(first + done), (int)count, O);
+        c->timing = timing;
+        if (rc != REPET_OK) return rc;
+    }
     if (first + n_seg == count) {                                   // the longer last segment, repet.py:320-322
         repet_timing* timing = c->timing;                           // its stages are not listed separately
         if (uniform > 0) c->timing = nullptr;

@@ -44,34 +44,19 @@ constexpr float kSplitScale = 128.0f;          // 2^7
 // planes[row][kb][hi | lo][32]: the hi and the lo halves of the 32 components kb*32 .. kb*32+31 of a row sit side by
 // side, 64 + 64 bytes = one 128-byte cache line per (row, K-tile). With two separate planes a K-tile touched only
 // half of every line it pulled into L1 and the other half was gone again by the next K-tile.
-// Scale of a matrix whose largest magnitude is `amax` (device scalar): the power of two that brings it to [2^13, 2^14),
-// well inside the f16 range; exact to apply and to remove. Unit rows (amax == null) use the fixed 2^7.
-__device__ __forceinline__ float split_scale(const float* amax) {
-    if (!amax) return kSplitScale;
-    const float m = *amax;
+// General matrices (power spectra for the beat spectrum: any dynamic range) are scaled ROW BY ROW: row t by the power of
+// two that brings its largest magnitude to [2^13, 2^14), well inside the f16 range; exact to apply and to remove (the
+// epilogue multiplies entry (i, j) by inv[i] * inv[j]). One scale for the whole matrix would flush a passage 60-100 dB
+// below the loudest one to f16 zeros -- for a power spectrum that is 30-50 dB of level -- and hand its frames an all-zero
+// beat spectrum. Unit rows (row_inv == null) use the fixed 2^7.
+__device__ __forceinline__ float row_scale(float m) {
     if (!(m > 0.f) || !(m < INFINITY)) return 1.f;
     int e;
     (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1
     return ldexpf(1.f, 14 - e);
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, int64_t count, unsigned int* __restrict__ out) {
-    float m = 0.f;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += (int64_t)gridDim.x * blockDim.x * 4) {
-        const float4 x = *reinterpret_cast<const float4*>(src + i);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));   // fmaxf drops NaN
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
-}
-
-__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ planes,
-                                                        int64_t count, const float* __restrict__ amax) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;     // FS is a multiple of 32: never straddles
-    if (i >= count) return;
-    const float sc = split_scale(amax);
-    const float4 x = *reinterpret_cast<const float4*>(src + i);
+__device__ __forceinline__ void split4(const float4 x, float sc, _Float16* __restrict__ planes, int64_t i) {
     const float v[4] = {x.x * sc, x.y * sc, x.z * sc, x.w * sc};
     _Float16 h[4], l[4];
 #pragma unroll
@@ -85,6 +70,32 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     *reinterpret_cast<uint2*>(dst + 32) = *reinterpret_cast<const uint2*>(l);
 }
 
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ planes, int64_t count) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;     // FS is a multiple of 32: never straddles
+    if (i >= count) return;
+    split4(*reinterpret_cast<const float4*>(src + i), kSplitScale, planes, i);
+}
+
+// one wavefront per row: largest magnitude, scale, split (the second read of the row hits the cache)
+__global__ __launch_bounds__(256) void split_f16_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ planes,
+                                                             int64_t n_rows, int FS, float* __restrict__ row_inv) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const float4* r4 = reinterpret_cast<const float4*>(src + row * FS);
+    const int n4 = FS >> 2;
+    float m = 0.f;
+    for (int k = lane; k < n4; k += 64) {
+        const float4 x = r4[k];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));   // fmaxf drops NaN
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float sc = row_scale(m);
+    if (lane == 0) row_inv[row] = 1.0f / sc;
+    for (int k = lane; k < n4; k += 64) split4(r4[k], sc, planes, row * FS + 4 * k);
+}
+
 // BAND: out[t][l] = row t . row t+l for 0 <= l < n_lags (pitch = band pitch), only the tiles that touch those lags;
 // blockIdx.y = clip of a batch (strides in halves / floats).
 template <bool BAND>
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
                                                        float* __restrict__ out, int64_t pitch,
                                                        const int2* __restrict__ tiles, int n_lags,
                                                        int64_t plane_batch_stride, int64_t out_batch_stride,
-                                                       const float* __restrict__ amax) {
+                                                       const float* __restrict__ row_inv, int64_t inv_batch_stride) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     planes += blockIdx.y * plane_batch_stride;
     out += blockIdx.y * out_batch_stride;
@@ -219,14 +230,28 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
     // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
     const int64_t gi0 = a_row0 + wr * 64;
     const int64_t gj0 = b_row0 + wc * 64;
-    const float sc = split_scale(amax);
-    const float unscale = 1.0f / (sc * sc);            // a power of two: exact
+    if (row_inv) {                                     // per-row scales: entry (i, j) carries scale[i] * scale[j]
+        const float* inv = row_inv + blockIdx.y * inv_batch_stride;
+        float cj[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) cj[n] = inv[gj0 + n * 32 + lr];
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] *= unscale;
+            for (int r = 0; r < 16; ++r) {
+                const float ci = inv[gi0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n][r] *= ci * cj[n];       // powers of two: exact
+            }
+    } else {
+        constexpr float unscale = 1.0f / (kSplitScale * kSplitScale);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] *= unscale;
+    }
     if (BAND || bi != bj) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -286,16 +311,17 @@ constexpr int kGramF16LdsAsk = 4 * 64 * 65 * 4 > kGramF16Lds ? 4 * 64 * 65 * 4 :
 
 }  // namespace
 
-hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s, float* amax) {
+hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipStream_t s) {
     if (count <= 0) return hipSuccess;
-    if (amax) {      // general matrix: find its largest magnitude first (device scalar, no host round trip)
-        hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), s);
-        if (e != hipSuccess) return e;
-        const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(count, 1024), 2048);
-        hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, count, reinterpret_cast<unsigned int*>(amax));
-    }
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(count, 1024)), dim3(256), 0, s, src,
-                       reinterpret_cast<_Float16*>(planes), count, amax);
+                       reinterpret_cast<_Float16*>(planes), count);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_f16_rows(const float* src, void* planes, int64_t n_rows, int32_t FS, float* row_inv, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(split_f16_rows_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, s, src,
+                       reinterpret_cast<_Float16*>(planes), n_rows, FS, row_inv);
     return hipGetLastError();
 }
 
@@ -306,19 +332,19 @@ hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_f16_kernel<false>, dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
                        reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
-                       (const float*)nullptr);
+                       (const float*)nullptr, (int64_t)0);
     return hipGetLastError();
 }
 
 hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
-                                int64_t band_batch_stride, hipStream_t s, const float* amax) {
+                                int64_t band_batch_stride, hipStream_t s, const float* row_inv, int64_t inv_batch_stride) {
     if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
     hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_f16_kernel<true>, dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
                        kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
-                       plane_batch_stride, band_batch_stride, amax);
+                       plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride);
     return hipGetLastError();
 }
 

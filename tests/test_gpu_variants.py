@@ -169,6 +169,41 @@ def test_extended_segment_ranges_add_up():
         repet.Context(0).execute_extended_range(p, 0, 1)      # nothing uploaded
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("algo", ["extended", "original", "adaptive"])
+def test_quiet_passages_keep_their_own_periods(algo):
+    """A clip whose second half is 70 dB below the first (power spectrum: 140 dB). The beat-spectrum Grams of long clips and
+    of batched `extended` segments run on the f16-split matrix-core kernel; with ONE scale for the whole matrix the quiet
+    half underflowed f16, its beat spectra came out all zero and its periods degenerated to period_lo + 1 although the
+    float64 reference finds the real period. Rows are scaled one by one now: periods of every segment / frame equal
+    the oracle's."""
+    fs = 44100
+    x = synth(400.0 if algo != "adaptive" else 60.0, fs, 1, 17)   # long enough for the f16-split band kernel (>= 512 tiles)
+    gain = np.ones(len(x))
+    gain[len(x) // 2:] = 10 ** (-70 / 20)
+    x = x * gain[:, np.newaxis]
+    tr = orc.Trace()
+    want = orc.ALGORITHMS[algo](x, fs, None, tr)
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    tm = ctx.execute(algo, p, timing=True)
+    got = ctx.download()
+    names = [s["name"] for s in tm["stages"]]
+    if algo == "extended":
+        assert "gram_band_f16x3" in names                           # the path under test really ran
+        assert np.array_equal(ctx.last_periods(256), tr.items["segment_periods"])
+    elif algo == "original":
+        assert "gram_band_f16x3" in names
+        assert ctx.last_periods(1)[0] == tr.items["repeating_period"]
+    else:                                                           # short windows: the exact-fp32 band kernel; same bar
+        assert np.array_equal(ctx.last_periods(ctx.last_frame_count()), tr.items["repeating_periods"])
+    ctx.close()
+    quiet = slice(len(x) // 2 + 4 * fs, None)
+    assert rms_err(got, want) <= RMS_TOL
+    assert rms_err(got[quiet], want[quiet]) <= 1e-3 * np.sqrt(np.mean(want[quiet] ** 2)) + 1e-9      # relative, in the quiet half
+
+
 def test_device_resident_ingest_and_egress():
     """repet_ctx_upload_device / repet_ctx_download_device: fp32 samples that are already in device memory (what an RCCL
     recv leaves there) go in and come out without a host bounce, bit-identical to the host path."""

@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
     hipStream_t sv, sa;
     CHECK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
     CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-    CHECK(launch_split_f16(d_rows, d_planes, (int64_t)rows.size(), sa, nullptr));
+    CHECK(launch_split_f16(d_rows, d_planes, (int64_t)rows.size(), sa));
     CHECK(hipStreamSynchronize(sa));
 
     auto launch_victim = [&]() -> hipError_t {
@@ -208,7 +208,7 @@ int main(int argc, char** argv) {
     int64_t first_bad_elem = -1, bad_elems = 0;
     for (int it = 0; it < iters; ++it) {
         for (int rep = 0; rep < 2; ++rep) {
-            if (aggressor == 1 || aggressor == 2) CHECK(launch_split_f16(d_rows, d_planes, (int64_t)rows.size(), sa, nullptr));
+            if (aggressor == 1 || aggressor == 2) CHECK(launch_split_f16(d_rows, d_planes, (int64_t)rows.size(), sa));
             if (aggressor == 1 || aggressor == 3) CHECK(launch_gram_full_f16(d_planes, TA, FS, d_S, TS, d_tiles, n_tiles, sa));
             if (aggressor == 4) CHECK(launch_gram_full(d_rows, TA, FS, d_S, TS, d_tiles, n_tiles, sa));
             if (aggressor == 5) hipLaunchKernelGGL(mfma_only<0>, dim3(1024), dim3(256), 0, sa, d_S, 400);
