@@ -1,0 +1,528 @@
+// K4 / K4b, wavefront-per-row form: peak picking of REPET-SIM (_localmaxima / _indices, repet.py:1294-1383) with ONE
+// WAVEFRONT per row and no workgroup barrier anywhere.
+//
+// The workgroup-per-row kernel (peaks.hip) spends its time waiting: nine barriers per row, four workgroups per CU (its
+// row lives in 31 KB of LDS), every phase a chain of memory / LDS latencies -- 70 000 cycles per row for about 4 000
+// cycles of arithmetic. Here a wave walks its row in chunks of 1 024 elements (16 per lane, with a halo of d on both
+// sides), so that sixteen rows are in flight per CU and nothing ever waits for another wave:
+//   * a chunk is loaded with coalesced 16-byte loads, turned lane-contiguous through a padded wave-private LDS buffer;
+//   * the window maxima M_w[i] = max(v[i .. i+w-1]), w = 2^floor(log2 d), are doubled up IN REGISTERS: a partner that
+//     sits in the next lane's registers comes in through a DPP wave shift (v_max_f32_dpp ... wave_shl:1), no LDS;
+//   * M_w goes back to the LDS buffer once, and the strict test reads its four windows from there as in peaks.hip:
+//         left = max(M_w[i-d], M_w[i-w]),  right = max(M_w[i+1], M_w[i+d-w+1]);
+//   * survivors and near-ties are compacted with wave ballots into wave-private lists (counters live in SGPRs, no
+//     atomics); rivals of a near-tie are looked for in the row itself (cache-resident), the float64 re-decision and
+//     the ranking are the ones of peaks.hip, run by the wave alone.
+// Same decisions, element for element, as peaks.hip (tests compare both against the oracle); used for windows of up to
+// 63 elements (every default configuration: d = 31, 43, 47) and candidate lists of up to 640 entries, otherwise the
+// launcher falls back to the workgroup kernel.
+#include "peaks.h"
+
+#include <type_traits>
+
+namespace repet {
+
+#ifdef REPET_PEAK_STAMPS
+__device__ unsigned long long g_wave_stamps[8 * 8];
+#define WSTAMP_DECL unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#define WSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] += now_ - last_; last_ = now_; }
+#define WSTAMP_OUT if (lane == 0 && (r % 997) == 5 && r / 997 < 8) { for (int k_ = 0; k_ < 8; ++k_) g_wave_stamps[(r / 997) * 8 + k_] = acc_[k_]; }
+#else
+#define WSTAMP_DECL
+#define WSTAMP(k)
+#define WSTAMP_OUT
+#endif
+
+namespace {
+
+constexpr int kChunkElems = 1024;                 // elements loaded per chunk: 64 lanes x 16
+constexpr int kChunkGroups = kChunkElems / 4;     // float4 groups
+constexpr int kBufGroups = kChunkGroups + kChunkGroups / 4 + 4;   // one pad group per 4 (a lane's 4 groups sit 5 apart) + slack
+constexpr int kMaxWaveCap = 640;
+
+__device__ __forceinline__ int phys4(int g) { return g + (g >> 2); }
+
+// value of lane + 1 (lane 63: `old`)
+__device__ __forceinline__ float from_next_lane(float v, float old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// slot of this lane among the lanes with `flag`, counted from `base` (wave-uniform); returns the new base in *next
+__device__ __forceinline__ int ballot_slot(bool flag, int base, int lane, int* next) {
+    const unsigned long long ballot = __ballot(flag);
+    *next = base + __popcll(ballot);
+    return base + __popcll(ballot & ((1ull << lane) - 1ull));
+}
+
+constexpr int kCandCap = 192;         // flagged elements buffered between the cheap sweep and the full decision
+
+struct WaveLds {
+    float4* buf;            // kBufGroups float4: raw chunk, then its window maxima; later the candidate ranks
+    float* pval; int* pidx; // candidates (cap)
+    double* amb_exact; double* riv_exact;
+    int* amb_idx; int* riv_idx; float* amb_val;
+    short* riv_owner; short* riv_ref; short* unl_list;
+    unsigned char* amb_ok; unsigned char* amb_lose;
+    float* cutv;
+    // elements the sweep could not rule out: (index, value, max of its two windows). Overlays amb_exact .. unl_list,
+    // which are only used after the sweep.
+    int* cand_i; float* cand_v; float* cand_m;
+};
+
+__host__ __device__ inline size_t wave_lds_bytes(int cap) {
+    return (size_t)kBufGroups * 16 + (size_t)cap * 8 + kAmbCap * 8 + kRivalCap * 8 + kAmbCap * 4 + kRivalCap * 4 + kAmbCap * 4 +
+           3 * kRivalCap * 2 + 2 * kAmbCap + 16;
+}
+
+__device__ __forceinline__ WaveLds carve(unsigned char* base, int cap) {
+    WaveLds w;
+    unsigned char* p = base;
+    w.buf = reinterpret_cast<float4*>(p); p += (size_t)kBufGroups * 16;
+    unsigned char* post = p;                                  // 2 496 bytes used only after the sweep
+    w.amb_exact = reinterpret_cast<double*>(p); p += kAmbCap * 8;
+    w.riv_exact = reinterpret_cast<double*>(p); p += kRivalCap * 8;
+    w.riv_idx = reinterpret_cast<int*>(p); p += kRivalCap * 4;
+    w.riv_owner = reinterpret_cast<short*>(p); p += kRivalCap * 2;
+    w.riv_ref = reinterpret_cast<short*>(p); p += kRivalCap * 2;
+    w.unl_list = reinterpret_cast<short*>(p); p += kRivalCap * 2;
+    static_assert(kAmbCap * 8 + kRivalCap * 8 + kRivalCap * 4 + 3 * kRivalCap * 2 >= kCandCap * 12, "candidate buffer must fit its overlay");
+    w.cand_i = reinterpret_cast<int*>(post);
+    w.cand_v = reinterpret_cast<float*>(post + kCandCap * 4);
+    w.cand_m = reinterpret_cast<float*>(post + kCandCap * 8);
+    w.pval = reinterpret_cast<float*>(p); p += (size_t)cap * 4;
+    w.pidx = reinterpret_cast<int*>(p); p += (size_t)cap * 4;
+    w.amb_idx = reinterpret_cast<int*>(p); p += kAmbCap * 4;
+    w.amb_val = reinterpret_cast<float*>(p); p += kAmbCap * 4;
+    w.cutv = reinterpret_cast<float*>(p); p += 16;
+    w.amb_ok = p; p += kAmbCap;
+    w.amb_lose = p;
+    return w;
+}
+
+// LDS traffic of one wave is ordered by the hardware; this only stops the compiler from moving accesses across
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace
+
+// RD = d & 3: the two window reads at run-time offsets (-d and d-w+1) then have compile-time float4 remainders
+template <int RD>
+__global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int64_t n_rows, int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wave_smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;        // row within this launch
+    if (r >= n_rows) return;
+    const WaveLds L = carve(wave_smem + (size_t)wave * lds_per_wave, a.peak_cap);
+    const int n = a.n, d = a.d;
+    a.M += blockIdx.y * a.m_stride;
+    a.idx += blockIdx.y * a.idx_stride;
+    a.count += blockIdx.y * a.cnt_stride;
+    if (a.unit) a.unit += blockIdx.y * a.unit_stride;
+    const int64_t j = a.row0 + r;                            // absolute row (mode 1: current frame)
+    float dlt = a.delta;                                     // 0: no refinement
+
+    auto fetch = [&](int i) -> float {                       // element i of the row, -inf outside [0, n)
+        if (i < 0 || i >= n) return -INFINITY;
+        if (a.mode == 0) return nan_to_inf(a.M[j * a.pitch + i]);
+        int l = (int)(j - i) % n;                            // circular-buffer order of the online variant
+        if (l < 0) l += n;
+        return nan_to_inf(a.M[(j - l - a.shift) * a.pitch + l]);
+    };
+    auto elem_row = [&](int i) -> const float* {             // unit row of the frame behind element i
+        int64_t fr = i;
+        if (a.mode == 1) {
+            int l = (int)(j - i) % n;
+            if (l < 0) l += n;
+            fr = j - l - a.shift;
+        }
+        return a.unit + fr * (int64_t)a.unit_pitch;
+    };
+    auto out_index = [&](int i) -> int {                     // what the list holds for element i
+        if (a.mode == 0) return i;
+        int l = (int)(j - i) % n;
+        if (l < 0) l += n;
+        return (int)(j - l - a.shift);
+    };
+
+    const bool vec_ok = (a.mode == 0) && ((a.pitch & 3) == 0);
+    const float* src = a.M + j * a.pitch;
+    int w = 1;
+    while (2 * w <= d) w *= 2;                               // w = 2^floor(log2 d) (1 when d <= 1), at most 32 here
+    const int halo = a.dl;                                   // round_up(d, 4), both sides
+    const int step = kChunkElems - 2 * halo;                 // elements tested per chunk
+    const int n_chunks = (n + step - 1) / step;
+    const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+
+    // M[4g+off .. 4g+off+3] of the chunk for an offset off = 4 q + RR with a compile-time remainder RR
+    auto read4 = [&](int gq, auto rr_tag) -> float4 {
+        constexpr int RR = decltype(rr_tag)::value;
+        const float4 x = L.buf[phys4(gq)];
+        if constexpr (RR == 0) return x;
+        const float4 y = L.buf[phys4(gq + 1)];
+        if constexpr (RR == 1) return make_float4(x.y, x.z, x.w, y.x);
+        if constexpr (RR == 2) return make_float4(x.z, x.w, y.x, y.y);
+        return make_float4(x.w, y.x, y.y, y.z);
+    };
+    constexpr int RR_LEFT = (4 - RD) & 3;                    // (-d) & 3
+    constexpr int RR_RIGHT = (RD + 1) & 3;                   // (d - w + 1) & 3, w a multiple of 4
+    const int q_left = (-d) >> 2, q_wl = -(w >> 2), q_right = (d - w + 1) >> 2;
+
+    // Full decision for the elements the sweep could not rule out (the arithmetic of peaks.hip on value v and the larger
+    // of its two window maxima): survivors to pval / pidx, decisions inside the rounding band to the near-tie list.
+    int n_peak = 0, n_amb = 0, n_cand = 0;
+    auto decide = [&]() {
+        wave_sync();
+        for (int k0 = 0; k0 < n_cand; k0 += 64) {
+            const int k = k0 + lane;
+            const bool have = k < n_cand;
+            const int i = have ? L.cand_i[k] : 0;
+            const float v = have ? L.cand_v[k] : 0.f, mx = have ? L.cand_m[k] : 0.f;
+            bool ok = have && (v >= a.min_value) && (v > mx);
+            bool near = false;
+            const bool was_ok = ok;
+            if (dlt > 0.0f) {
+                const bool sure_yes = (v >= a.min_value + dlt) && (v > mx + dlt);
+                const bool sure_no = (v < a.min_value - dlt) || (v < mx - dlt);
+                near = have && !sure_yes && !sure_no;
+                ok = ok && !near;
+            }
+            if (__any(near)) {
+                int next;
+                const int slot = ballot_slot(near, n_amb, lane, &next);
+                if (near && slot < kAmbCap) { L.amb_idx[slot] = i; L.amb_val[slot] = v; L.amb_ok[slot] = was_ok; }
+                n_amb = next;
+            }
+            if (__any(ok)) {
+                int next;
+                const int slot = ballot_slot(ok, n_peak, lane, &next);
+                if (ok && slot < a.peak_cap) { L.pval[slot] = v; L.pidx[slot] = i; }
+                n_peak = next;
+            }
+        }
+        n_cand = 0;
+        wave_sync();
+    };
+
+    int n_riv = 0, n_unl = 0;
+    WSTAMP_DECL
+    for (;;) {
+        n_peak = 0; n_amb = 0; n_cand = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int s0 = c * step - halo;                  // first element of the chunk (a multiple of 4; may be negative)
+            const int t_lo = c * step, t_hi = (t_lo + step < n) ? t_lo + step : n;     // elements tested: [t_lo, t_hi)
+            wave_sync();                                     // the previous chunk's reads of the buffer are done
+            // coalesced 16-byte loads -> padded LDS
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = 64 * q + lane;
+                const int i0 = s0 + 4 * g;
+                float4 v;
+                if (vec_ok && i0 >= 0 && i0 + 3 < n) {
+                    v = *reinterpret_cast<const float4*>(src + i0);
+                    v = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
+                } else {
+                    v = make_float4(fetch(i0), fetch(i0 + 1), fetch(i0 + 2), fetch(i0 + 3));
+                }
+                L.buf[phys4(g)] = v;
+            }
+            wave_sync();
+            WSTAMP(0)
+            // lane-contiguous: this lane owns chunk elements 16 lane .. 16 lane + 15
+            float raw[16], m[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = L.buf[5 * lane + k];        // phys4(4 lane + k)
+                raw[4 * k] = v.x; raw[4 * k + 1] = v.y; raw[4 * k + 2] = v.z; raw[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m[e] = raw[e];
+            // window maxima by doubling, partners beyond the lane's 16 elements from the next lane's registers
+#pragma unroll
+            for (int h = 1; h <= 8; h *= 2) {
+                if (h < w) {                                 // wave-uniform
+                    float t[8];
+#pragma unroll
+                    for (int k = 0; k < h; ++k) t[k] = from_next_lane(m[k], -INFINITY);
+#pragma unroll
+                    for (int e = 0; e + h < 16; ++e) m[e] = fmaxf(m[e], m[e + h]);
+#pragma unroll
+                    for (int e = 16 - h; e < 16; ++e) m[e] = fmaxf(m[e], t[e + h - 16]);
+                }
+            }
+            if (w > 16) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m[e] = fmaxf(m[e], from_next_lane(m[e], -INFINITY));
+            }
+            wave_sync();                                     // every lane has read its raw values
+#pragma unroll
+            for (int k = 0; k < 4; ++k) L.buf[5 * lane + k] = make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+            wave_sync();
+            WSTAMP(1)
+            // The sweep: almost every element is below the larger of its window maxima by more than delta -- a safe "no".
+            // Only the others (peaks and near-ties: one element in forty) are written down for the full decision.
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gl = 4 * lane + k;                 // chunk-local group
+                const int i0 = s0 + 4 * gl;
+                const bool real = i0 >= t_lo && i0 < t_hi;   // t_lo, halo, s0 are multiples of 4: a group is all tested or not at all
+                float4 mx = ninf;
+                if (real && d > 0) {
+                    const float4 left = max4(read4(gl + q_left, std::integral_constant<int, RR_LEFT>{}), read4(gl + q_wl, std::integral_constant<int, 0>{}));
+                    const float4 right = max4(read4(gl, std::integral_constant<int, 1>{}), read4(gl + q_right, std::integral_constant<int, RR_RIGHT>{}));
+                    mx = max4(left, right);
+                }
+                const float vals[4] = {raw[4 * k], raw[4 * k + 1], raw[4 * k + 2], raw[4 * k + 3]};
+                const float mxs[4] = {mx.x, mx.y, mx.z, mx.w};
+                bool open[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = vals[e];
+                    const bool valid = real && i0 + e < t_hi && (v < INFINITY);
+                    open[e] = valid && !((v < a.min_value - dlt) || (v < mxs[e] - dlt));           // not a safe "no"
+                }
+                // peaks lie more than d >= 4 apart: a group of four holds at most one, so one compaction serves the group;
+                // a second open element in a group (two near-ties side by side) takes the per-element path
+                const bool any_open = open[0] || open[1] || open[2] || open[3];
+                if (__any(any_open)) {
+                    const int first = open[0] ? 0 : (open[1] ? 1 : (open[2] ? 2 : 3));
+                    if (n_cand > kCandCap - 64) decide();
+                    int next;
+                    const int slot = ballot_slot(any_open, n_cand, lane, &next);
+                    if (any_open) {
+                        L.cand_i[slot] = i0 + first;
+                        L.cand_v[slot] = open[0] ? vals[0] : (open[1] ? vals[1] : (open[2] ? vals[2] : vals[3]));
+                        L.cand_m[slot] = open[0] ? mxs[0] : (open[1] ? mxs[1] : (open[2] ? mxs[2] : mxs[3]));
+                    }
+                    n_cand = next;
+                    const int n_open = (int)open[0] + (int)open[1] + (int)open[2] + (int)open[3];
+                    if (__any(n_open > 1)) {
+#pragma unroll
+                        for (int e = 1; e < 4; ++e) {
+                            const bool more = open[e] && e != first;
+                            if (__any(more)) {
+                                if (n_cand > kCandCap - 64) decide();
+                                int nx;
+                                const int sl = ballot_slot(more, n_cand, lane, &nx);
+                                if (more) { L.cand_i[sl] = i0 + e; L.cand_v[sl] = vals[e]; L.cand_m[sl] = mxs[e]; }
+                                n_cand = nx;
+                            }
+                        }
+                    }
+                }
+            }
+            WSTAMP(2)
+        }
+        decide();
+        WSTAMP(3)
+        wave_sync();
+        bool redo = false;
+        n_riv = 0; n_unl = 0;
+        if (dlt > 0.0f && n_amb > 0) {
+            if (n_amb > kAmbCap) redo = true;                // a flat row: more near-ties than the list holds
+            else {
+                // Rivals of the near-tied elements: element k is a rival of near-tied i when it lies in i's window and
+                // within delta below it (nothing in the window is more than delta above i, or i would have been a safe
+                // "no"). The row is read again where it lies (it went through this CU's caches a moment ago).
+                const int n_near = n_amb;
+                for (int k = lane; k < n_near; k += 64) L.amb_lose[k] = 0;
+                for (int s = 0; s < n_near && n_riv <= kRivalCap; ++s) {
+                    const int i = L.amb_idx[s];
+                    const float lim = L.amb_val[s] - dlt;
+                    for (int k0 = i - d; k0 <= i + d; k0 += 64) {
+                        const int k = k0 + lane;
+                        const bool rival = k != i && k <= i + d && k >= 0 && k < n && fetch(k) >= lim;
+                        if (__any(rival)) {
+                            int next, next_u;
+                            const int entry = ballot_slot(rival, n_riv, lane, &next);
+                            int ref = -1;
+                            const bool stored = rival && entry < kRivalCap;
+                            if (stored) {
+                                for (int t = 0; t < n_near; ++t) if (L.amb_idx[t] == k) ref = t;
+                                L.riv_owner[entry] = (short)s; L.riv_ref[entry] = (short)ref; L.riv_idx[entry] = k;
+                            }
+                            // a rival that is not a near-tied element itself gets a float64 value of its own
+                            const bool unlisted = stored && ref < 0;
+                            const int us = ballot_slot(unlisted, n_unl, lane, &next_u);
+                            if (unlisted) L.unl_list[us] = (short)entry;
+                            n_unl = next_u;
+                            n_riv = next;
+                        }
+                    }
+                }
+                if (n_riv > kRivalCap) redo = true;
+            }
+        }
+        if (!redo) break;
+        if (a.stats && lane == 0) atomicAdd(&a.stats[3], 1u);      // redo the test with the plain fp32 decisions
+        dlt = 0.0f;
+    }
+    wave_sync();
+
+    if (dlt > 0.0f && n_amb > 0) {
+        // Near-tie refinement (see peaks.hip): float64 similarities of the same fp32 spectra decide.
+        const int n_near = n_amb, n_rival = n_riv, n_items = n_near + n_unl;
+        const int len4 = a.unit_pitch >> 2;
+        const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
+        auto item_row = [&](int it) -> const float* {
+            return elem_row(it < n_near ? L.amb_idx[it] : L.riv_idx[L.unl_list[it - n_near]]);
+        };
+        for (int it = 0; it < n_items; it += 2) {
+            const bool two = it + 1 < n_items;
+            double e0, e1;
+            exact_similarity2(self_row, item_row(it), item_row(two ? it + 1 : it), len4, lane, &e0, &e1);
+            if (lane == 0) {
+                if (it < n_near) L.amb_exact[it] = e0; else L.riv_exact[L.unl_list[it - n_near]] = e0;
+                if (two) { if (it + 1 < n_near) L.amb_exact[it + 1] = e1; else L.riv_exact[L.unl_list[it + 1 - n_near]] = e1; }
+            }
+        }
+        wave_sync();
+        for (int e = lane; e < n_rival; e += 64) {
+            const int s = L.riv_owner[e], ref = L.riv_ref[e];
+            const double er = ref >= 0 ? L.amb_exact[ref] : L.riv_exact[e];
+            if (!(L.amb_exact[s] > er)) L.amb_lose[s] = 1;
+        }
+        wave_sync();
+        int changed = 0;
+        for (int k0 = 0; k0 < n_near; k0 += 64) {
+            const int k = k0 + lane;
+            bool win = false;
+            if (k < n_near) {
+                const double ek = L.amb_exact[k];
+                win = !L.amb_lose[k] && ek >= a.min_value64;
+                changed += (win != (L.amb_ok[k] != 0));
+            }
+            int next;
+            const int slot = ballot_slot(win, n_peak, lane, &next);
+            if (win && slot < a.peak_cap) { L.pval[slot] = (float)L.amb_exact[k]; L.pidx[slot] = L.amb_idx[k]; }
+            n_peak = next;
+        }
+        if (a.stats) {
+            if (lane == 0) { atomicAdd(&a.stats[0], 1u); atomicAdd(&a.stats[1], (unsigned)n_near); }
+            if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+        }
+        wave_sync();
+    }
+
+    WSTAMP(4)
+    // rank by counting: value descending, higher index first on ties (np.argsort(...)[::-1])
+    int np_ = n_peak;
+    if (np_ > a.peak_cap) np_ = a.peak_cap;
+    const int kept = np_ < a.number ? np_ : a.number;
+    for (int k = np_ + lane; k < ((np_ + 3) & ~3); k += 64) L.pval[k] = -INFINITY;       // pad to a float4 boundary
+    wave_sync();
+    int* out = a.idx + r * (int64_t)a.idx_pitch;
+    const float4* pv4 = reinterpret_cast<const float4*>(L.pval);
+    const bool cut_check = dlt > 0.0f && np_ > a.number;
+    int* prank = reinterpret_cast<int*>(L.buf);               // the window maxima are no longer needed (cap <= 640 ints fit)
+    for (int p = lane; p < np_; p += 64) {
+        const float v = L.pval[p];
+        const int i = L.pidx[p];
+        int rank = 0;
+#pragma unroll 4
+        for (int q4 = 0; 4 * q4 < np_; ++q4) {
+            const float4 u = pv4[q4];
+            rank += (u.x > v) + (u.y > v) + (u.z > v) + (u.w > v);
+            if (u.x == v || u.y == v || u.z == v || u.w == v) {     // exact ties: rare
+                rank += (u.x == v && L.pidx[4 * q4] > i) + (u.y == v && L.pidx[4 * q4 + 1] > i) +
+                        (u.z == v && L.pidx[4 * q4 + 2] > i) + (u.w == v && L.pidx[4 * q4 + 3] > i);
+            }
+        }
+        if (rank < a.number) out[rank] = out_index(i);
+        if (cut_check) prank[p] = rank;
+    }
+    if (cut_check) {
+        // Top-`number` cut with more candidates than slots (see peaks.hip): candidates within delta of the boundary
+        // are re-ranked by float64 similarity.
+        wave_sync();
+        for (int p = lane; p < np_; p += 64) {
+            if (prank[p] == a.number - 1) L.cutv[0] = L.pval[p];
+            if (prank[p] == a.number) L.cutv[1] = L.pval[p];
+        }
+        wave_sync();
+        const float c_in = L.cutv[0], c_out = L.cutv[1];
+        if (c_in - c_out <= dlt) {
+            const float lo = c_out - dlt, hi = c_in + dlt;
+            int n_band = 0, n_above = 0;
+            for (int p0 = 0; p0 < np_; p0 += 64) {
+                const int p = p0 + lane;
+                const float v = p < np_ ? L.pval[p] : -INFINITY;
+                const bool above = p < np_ && v > hi, band = p < np_ && !above && v >= lo;
+                n_above += __popcll(__ballot(above));
+                int next;
+                const int slot = ballot_slot(band, n_band, lane, &next);
+                if (band && slot < kAmbCap) { L.amb_idx[slot] = L.pidx[p]; L.amb_ok[slot] = prank[p] < a.number; }
+                n_band = next;
+            }
+            wave_sync();
+            if (n_band <= kAmbCap) {
+                const int len4 = a.unit_pitch >> 2;
+                const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
+                for (int it = 0; it < n_band; it += 2) {
+                    const bool two = it + 1 < n_band;
+                    double e0, e1;
+                    exact_similarity2(self_row, elem_row(L.amb_idx[it]), elem_row(L.amb_idx[two ? it + 1 : it]), len4, lane, &e0, &e1);
+                    if (lane == 0) { L.amb_exact[it] = e0; if (two) L.amb_exact[it + 1] = e1; }
+                }
+                wave_sync();
+                int changed = 0;
+                for (int k = lane; k < n_band; k += 64) {
+                    const double e = L.amb_exact[k];
+                    const int i = L.amb_idx[k];
+                    int crank = 0;
+                    for (int t = 0; t < n_band; ++t) crank += (L.amb_exact[t] > e) || (L.amb_exact[t] == e && L.amb_idx[t] > i);
+                    const bool keep = n_above + crank < a.number;
+                    if (keep) out[n_above + crank] = out_index(i);
+                    changed += (keep != (L.amb_ok[k] != 0));
+                }
+                if (a.stats) {
+                    if (lane == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
+                    if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+                }
+            } else if (a.stats && lane == 0) atomicAdd(&a.stats[3], 1u);
+        }
+    }
+    for (int k = kept + lane; k < a.number; k += 64) out[k] = -1;
+    if (lane == 0) a.count[r] = kept;
+    WSTAMP(5)
+    WSTAMP_OUT
+}
+
+#ifdef REPET_PEAK_STAMPS
+extern "C" int repet_debug_wave_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+
+template <int RD>
+static hipError_t launch_wave_rd(const PeakArgs& a, int64_t n_rows, int n_batch, int bytes, int per_wave, hipStream_t s) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_wave_kernel<RD>), bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(local_maxima_wave_kernel<RD>, dim3((unsigned)ceil_div(n_rows, 4), (unsigned)n_batch), dim3(256), bytes, s, a, n_rows, per_wave);
+    return hipGetLastError();
+}
+
+hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_batch, hipStream_t s) {
+    static const bool off = [] { const char* e = getenv("REPET_PEAKS"); return e && e[0] == 'b'; }();   // REPET_PEAKS=block: the workgroup kernel
+    if (off) return hipErrorNotSupported;
+    PeakArgs a = a0;
+    // windows of 4 .. 32 elements per doubling chain (4 <= d <= 63), lists that fit the wave's LDS share
+    if (a.d < 4 || a.d > 63 || a.n < 1) return hipErrorNotSupported;
+    a.dl = (int)round_up(a.d, 4);
+    const int cap = (int)round_up(a.n / (a.d + 1) + 2, 4);
+    if (cap > kMaxWaveCap) return hipErrorNotSupported;
+    a.peak_cap = cap;
+    const int per_wave = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
+    const int bytes = 4 * per_wave;
+    switch (a.d & 3) {
+        case 0: return launch_wave_rd<0>(a, n_rows, n_batch, bytes, per_wave, s);
+        case 1: return launch_wave_rd<1>(a, n_rows, n_batch, bytes, per_wave, s);
+        case 2: return launch_wave_rd<2>(a, n_rows, n_batch, bytes, per_wave, s);
+        default: return launch_wave_rd<3>(a, n_rows, n_batch, bytes, per_wave, s);
+    }
+}
+
+}  // namespace repet

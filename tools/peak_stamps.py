@@ -11,5 +11,13 @@ buf = (ctypes.c_ulonglong * 64)()
 print("rc", lib.repet_debug_peak_stamps(buf))
 a = np.array(buf[:], dtype=np.int64).reshape(8, 8)
 for row in a:
-    d = np.diff(row[:5])
-    print("load %6d  passes %6d  test %6d  rank %6d  | total %6d cycles" % (d[0], d[1], d[2], d[3], row[4] - row[0]))
+    print("load %6d  passes %6d  test %6d  refine %6d  rank %6d  | total %6d cycles" % (
+        row[1] - row[0], row[2] - row[1], row[5] - row[2], row[3] - row[5], row[4] - row[3], row[4] - row[0]))
+
+if hasattr(lib, "repet_debug_wave_stamps"):
+    print("wave kernel (peaks_wave.hip), cycles summed over the chunks of one row:")
+    print("rc", lib.repet_debug_wave_stamps(buf))
+    a = np.array(buf[:], dtype=np.int64).reshape(8, 8)
+    for row in a:
+        print("load+transpose %6d  doubling %6d  sweep %6d  decide %6d  rivals+refine %6d  rank %6d | total %6d" % (
+            row[0], row[1], row[2], row[3], row[4], row[5], row[:6].sum()))
