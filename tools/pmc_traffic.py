@@ -19,7 +19,7 @@ KERNELS = [
     ("stft_pair_kernel", "stft", 1, "4-8 B/lane"), ("stft_kernel", "stft", 1, "4-8 B/lane"), ("stft_reg_kernel", "stft", 1, "4-8 B/lane"),
     ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_kernel", "similarity_gemm", 2, "16 B/lane"),
-    ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
+    ("local_maxima_wave_kernel", "local_maxima", 2, "16 B/lane"), ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
     ("columns_from_rows_kernel", "rank_columns", 1, "4 B/lane"), ("rank_columns_kernel", "rank_columns", 2, "16 B/lane"),
     ("rows_from_code_columns_kernel", "rank_columns", 1, "4 B/lane"),
     ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
