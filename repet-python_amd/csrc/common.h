@@ -109,6 +109,11 @@ hipError_t launch_split_f16(const float* src, void* planes, int64_t count, hipSt
 hipError_t launch_split_f16_rows(const float* src, void* planes, int64_t n_rows, int32_t FS, float* row_inv, hipStream_t s);
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s);
+// the same full matrix with 256 x 256 tiles and LDS-DMA staging (gram_f16_big.hip); tiles from gram_tile_list(ceil(T / 256), all);
+// `planes` must be readable up to row round_up(T, 256)
+int gram_big_tile();
+hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
+                                    const int2* tiles, int32_t n_tiles, hipStream_t s);
 // banded form: band[t][l] = row t . row t+l; plane_batch_stride in halves (2 * Tpad * FS); row_inv (nullable): per-row
 // inverse scales of launch_split_f16_rows, inv_batch_stride floats between clips
 hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,

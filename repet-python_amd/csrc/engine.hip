@@ -113,6 +113,8 @@ struct repet_ctx {
     std::map<int, std::unique_ptr<Tables>> tables;
     DevBuf tiles;                 // Gram tile list of the last (nb, ndiag)
     int tiles_nb = -1, tiles_ndiag = -1, tiles_count = 0;
+    DevBuf tiles_big;             // upper-triangle list of 256 x 256 tiles (gram_f16_big.hip)
+    int tiles_big_nb = -1, tiles_big_count = 0;
     // last run
     int last_algo = -1;
     int64_t last_T = 0;
@@ -206,7 +208,34 @@ bool gram_f16_enabled() {
     return on;
 }
 
+// REPET_GRAM_TILE=128 keeps the full similarity matrix on the 128 x 128-tile kernel (default: 256 x 256 tiles with LDS-DMA
+// staging from 8 tile rows on, i.e. clips of about 45 s at 44.1 kHz)
+bool gram_big_enabled() {
+    static const bool on = [] { const char* e = getenv("REPET_GRAM_TILE"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS, bool unit_rows = false) {
+    if (unit_rows && gram_f16_enabled() && gram_big_enabled() && T >= 8 * gram_big_tile()) {
+        const int bt = gram_big_tile();
+        const int nb = (int)ceil_div(T, bt);
+        if (c->tiles_big_nb != nb) {
+            std::vector<int2> host;
+            const int n = gram_tile_list(nb, 1 << 30, &host);
+            HIP_TRY(hipStreamSynchronize(c->stream));          // the previous list may still be in use
+            HIP_TRY(c->tiles_big.ensure(std::max<size_t>(host.size() * sizeof(int2), 256)));
+            HIP_TRY(hipMemcpyAsync(c->tiles_big.p, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->tiles_big_nb = nb; c->tiles_big_count = n;
+        }
+        // the planes of rows [round_up(T, 128), round_up(T, 256)) are read by the last tile row and never used: the
+        // buffer only has to be that long
+        const int64_t count = round_up(T, kTile) * FS;
+        HIP_TRY(c->Vh.ensure((size_t)round_up(T, bt) * FS * 4));
+        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        HIP_TRY(launch_gram_full_f16_big(c->Vh.p, T, FS, S, TS, c->tiles_big.as<int2>(), c->tiles_big_count, c->stream));
+        return REPET_OK;
+    }
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, 1 << 30, &tiles, &n));
     if (unit_rows && gram_f16_enabled()) {      // rows are unit vectors (components in [0, 1]): safe for the f16 split
@@ -641,10 +670,11 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
         // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
         // states the algorithmic 2 F T^2 beside it
-        const double n_tiles = 0.5 * (double)ceil_div(T, kTile) * (double)(ceil_div(T, kTile) + 1);
         const bool f16 = gram_f16_enabled();
+        const int edge = (f16 && gram_big_enabled() && T >= 8 * gram_big_tile()) ? gram_big_tile() : kTile;
+        const double n_tiles = 0.5 * (double)ceil_div(T, edge) * (double)(ceil_div(T, edge) + 1);
         mark(c, f16 ? "similarity_gemm_f16x3" : "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T,
-             (f16 ? 3.0 : 1.0) * 2.0 * g.FS * n_tiles * kTile * kTile);
+             (f16 ? 3.0 : 1.0) * 2.0 * g.FS * n_tiles * edge * edge);
     }
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
@@ -850,7 +880,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     c->ring.release();
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
-                      &c->refine_stats, &c->R, &c->Vs, &c->rank_codes,
+                      &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }

@@ -1,0 +1,227 @@
+// K3h, large-tile form: the cosine self-similarity matrix of REPET-SIM (repet.py:1223) on the f16 matrix cores with a
+// 256 x 256 tile per 512-thread workgroup and LDS-DMA staging.
+//
+// Same arithmetic as gram_f16.hip (every fp32 unit-row component as hi + lo f16 halves, hi hi' + hi lo' + lo hi' on
+// v_mfma_f32_32x32x16_f16, fp32 accumulators, the three products of a K-step in the same order), so the matrix is
+// bit-identical to that kernel's. What changes is what the 128 x 128 kernel was bound by -- the LDS, not the matrix cores:
+//   per K-tile of 32 components it wrote 32 KB to LDS (415 cycles of the CU's 79 B/clk ds_write_b128 path) and its four
+//   waves read 64 KB of fragments back (256 cycles) for 768 cycles of MFMA per SIMD; two workgroups per CU made that
+//   1 340 LDS cycles against 768 MFMA cycles.
+// A 256 x 256 tile (8 waves as 2 x 4, 128 x 64 of output per wave = 4 x 2 MFMA blocks) stages 64 KB per K-tile for FOUR
+// times the flops and reads 24 KB of fragments per wave for 48 MFMAs: 1 600 LDS cycles against 3 072 MFMA cycles per
+// SIMD. The staging itself goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write);
+// the XOR-swizzled LDS image of gram_f16.hip is kept by permuting the per-lane SOURCE addresses (the LDS side of an
+// LDS-DMA is lane-linear). Two LDS buffers, one barrier per K-tile: the DMA of tile k+1 flies during the 3 072-cycle
+// compute of tile k. Upper-triangle tiles only, mirrored through per-wave LDS patches; diagonal tiles store the values
+// computed for i <= j on both sides, so S is exactly symmetric.
+#include "common.h"
+
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+
+namespace repet {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+
+#ifdef REPET_GRAM_STAMPS
+__device__ unsigned long long g_gram_stamps[4 * 8];
+#define GSTAMP(k) if (tid == 0 && (blockIdx.x % 61) == 7 && blockIdx.x / 61 < 8) g_gram_stamps[(blockIdx.x / 61) * 4 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define GSTAMP(k)
+#endif
+
+namespace {
+
+constexpr int BT = 256;                       // tile edge
+constexpr int HBK = 32;                       // K elements per K-tile
+constexpr int kPlane = BT * HBK;              // halves of one plane tile in LDS: 256 rows x 32 halves = 16 KB
+constexpr int kBuffer = 4 * kPlane;           // A hi, A lo, B hi, B lo = 64 KB
+constexpr int kLoopLds = 2 * kBuffer * 2;     // bytes: two buffers = 131 072
+constexpr int kPatchPitch = 68;               // floats per patch row: 16-byte aligned rows for float4 reads
+constexpr int kPatchLds = 8 * 64 * kPatchPitch * 4;   // bytes: one 64 x 68 float patch per wave = 139 264
+constexpr int kBigLds = kPatchLds > kLoopLds ? kPatchLds : kLoopLds;
+
+__global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
+                                                           float* __restrict__ out, int64_t pitch,
+                                                           const int2* __restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds_big[];
+    const int2 tile = tiles[blockIdx.x];
+    const int bi = tile.x, bj = tile.y;
+    if (bi < 0) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                      // 2 x 4 waves: rows wr*128, columns wc*64
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int64_t a_row0 = (int64_t)bi * BT, b_row0 = (int64_t)bj * BT;
+    const unsigned grow = (unsigned)(2 * FS);                     // halves per row of the interleaved global image
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // LDS-DMA pieces: 64 per K-tile (2 operands x 2 planes x 16 blocks of 16 rows), 8 per wave. A piece is 1 KiB =
+    // 16 rows x 64 bytes of one plane, written lane-linearly: lane l lands on row l >> 2, 16-byte slot l & 3, which must
+    // hold the row's chunk (l & 3) ^ ((row >> 2) & 3) -- so that is the chunk this lane FETCHES.
+    const int prow = lane >> 2;                                                  // row inside the piece
+    const _Float16* src_lane[8];
+    int dst_piece[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int pc = wave * 8 + j;
+        const int operand = pc >> 5, plane = (pc >> 4) & 1, rb = pc & 15;
+        const int r = rb * 16 + prow;
+        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+        src_lane[j] = planes + ((operand ? b_row0 : a_row0) + r) * grow + plane * 32 + chunk * 8;
+        dst_piece[j] = (operand * 2 + plane) * kPlane + rb * 16 * HBK;           // halves, wave-uniform
+    }
+    auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_lane[j] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(lds_big + buf * kBuffer + dst_piece[j]), 16, 0, 0);
+    };
+    // fragment of lane (lr, lh): 8 halves k = 16 ks + 8 lh .. +7 of plane row `row` -> chunk 2 ks + lh, swizzled by the row
+    auto frag = [&](const _Float16* plane_ptr, int row, int ks) -> halfx8 {
+        return *reinterpret_cast<const halfx8*>(plane_ptr + row * HBK + (((2 * ks + lh) ^ ((row >> 2) & 3)) << 3));
+    };
+
+    const int nk = FS / HBK;
+    GSTAMP(0)
+    issue_tile(0, 0);
+    __syncthreads();                                    // (waits vmcnt(0): the tile has landed)
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
+        const _Float16* base = lds_big + (kt & 1) * kBuffer;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            halfx8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int row = wr * 128 + m * 32 + lr;
+                ah[m] = frag(base, row, ks);
+                al[m] = frag(base + kPlane, row, ks);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int row = wc * 64 + n * 32 + lr;
+                bh[n] = frag(base + 2 * kPlane, row, ks);
+                bl[n] = frag(base + 3 * kPlane, row, ks);
+            }
+            // the order of gram_f16.hip: lo hi', hi lo', hi hi' -- the same sums, bit for bit
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();                                // every wave is done with buffer kt & 1; tile kt+1 has landed
+    }
+
+    GSTAMP(1)
+    // ---- epilogue. acc[m][n][r]: i = wr*128 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr.
+    // Both copies of the block leave through the wave's LDS patch (64 rows x 68 floats) so that every global store is
+    // 16 bytes per lane, four 256-byte rows per instruction (the 4-byte stores of the fragment layout were 256 store
+    // instructions per lane -- the epilogue was store-issue-bound): first the 64 x 64 half as it is, then transposed.
+    // The patches alias the tile buffers, which every wave left at the loop's last barrier.
+    const int64_t gi0 = a_row0 + wr * 128;
+    const int64_t gj0 = b_row0 + wc * 64;
+    constexpr float unscale = 1.0f / (128.0f * 128.0f);          // the 2^7 scale of both operands, exact
+    const bool diag = bi == bj;
+    float* patch = reinterpret_cast<float*>(lds_big) + wave * (64 * kPatchPitch);
+    const int srow = lane >> 4, scol = (lane & 15) * 4;          // store role: row srow + 4 k of the patch, floats scol .. scol+3
+    auto store_rows = [&](int64_t row0, int64_t col0, bool transposed) {
+        // patch row p, float q is S[row0 + p][col0 + q]; on diagonal tiles the natural copy keeps i <= j, the mirror i < j
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int p = srow + 4 * k;
+            const float4 v = *reinterpret_cast<const float4*>(patch + p * kPatchPitch + scol);
+            const int64_t gr = row0 + p, gc = col0 + scol;
+            if (gr >= T) continue;
+            float* dst = out + gr * pitch + gc;
+            const float vals[4] = {v.x, v.y, v.z, v.w};
+            bool all = gc + 3 < T;
+            if (diag) all = all && (transposed ? gr > gc + 3 : gr <= gc);
+            if (all) *reinterpret_cast<float4*>(dst) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool keep = gc + e < T && (!diag || (transposed ? gr > gc + e : gr <= gc + e));
+                    if (keep) dst[e] = vals[e];
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        // natural: patch[i][j]
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    patch[i * kPatchPitch + n * 32 + lr] = acc[2 * mh + mm][n][r] * unscale;
+                }
+        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the patch is wave-private
+        __builtin_amdgcn_wave_barrier();
+        store_rows(gi0 + mh * 64, gj0, false);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        // mirror: patch[j][i]
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    patch[(n * 32 + lr) * kPatchPitch + i] = acc[2 * mh + mm][n][r] * unscale;
+                }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        store_rows(gj0, gi0 + mh * 64, true);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+    GSTAMP(2)
+    GSTAMP(3)
+}
+
+}  // namespace
+
+#ifdef REPET_GRAM_STAMPS
+extern "C" int repet_debug_gram_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gram_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
+
+int gram_big_tile() { return BT; }
+
+hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
+                                    const int2* tiles, int32_t n_tiles, hipStream_t s) {
+    if (T <= 0 || n_tiles <= 0) return hipSuccess;
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_big_kernel), kBigLds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(gram_f16_big_kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
+                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles);
+    return hipGetLastError();
+}
+
+}  // namespace repet

@@ -443,6 +443,34 @@ def test_gram_paths_agree():
     assert rms_err(outs[0]["y"], outs[1]["y"]) < 5e-6
 
 
+def test_gram_tile_sizes_give_the_same_matrix():
+    """The full similarity matrix on 256 x 256 tiles with LDS-DMA staging (gram_f16_big.hip, default from 2 048 frames on)
+    against the 128 x 128-tile kernel (REPET_GRAM_TILE=128): the same three f16 products per term in the same order, so
+    the MATRIX is bit-identical -- checked on the stage export (exact symmetry, NaN row and column of a silent frame
+    included) and end to end."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "rs = np.random.RandomState(5); v = np.abs(rs.standard_normal((513, 2300))); v[:, 700] = 0.0; "
+            "s = repet._selfsimilaritymatrix(v); x = synth(60, 44100, 2, 21); y = repet.sim(x, 44100); "
+            "np.savez(sys.argv[1], s=s, y=y)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for tile in ("256", "128"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile}_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_GRAM_TILE=tile))
+        with np.load(out) as z:
+            outs.append({k: z[k] for k in z.files})
+        os.remove(out)
+    s = outs[0]["s"]
+    assert np.array_equal(s, outs[1]["s"], equal_nan=True)
+    assert np.array_equal(s, s.T, equal_nan=True)
+    assert np.all(np.isnan(s[700])) and np.all(np.isnan(s[:, 700])) and np.isnan(s).sum() == 2 * 2300 - 1
+    assert np.array_equal(outs[0]["y"], outs[1]["y"])
+
+
 @pytest.mark.parametrize("seconds,fs,channels,number,distance", [(50, 44100, 2, 100, 1.0), (110, 22050, 1, 100, 0.3),
                                                                   (70, 16000, 3, 64, 0.2), (30, 44100, 2, 31, 0.1)])
 def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance):

@@ -21,3 +21,11 @@ if hasattr(lib, "repet_debug_wave_stamps"):
     for row in a:
         print("load+transpose %6d  doubling %6d  sweep %6d  decide %6d  rivals+refine %6d  rank %6d | total %6d" % (
             row[0], row[1], row[2], row[3], row[4], row[5], row[:6].sum()))
+
+if hasattr(lib, "repet_debug_gram_stamps"):
+    print("256 x 256 Gram kernel (gram_f16_big.hip), cycles of one workgroup:")
+    g = (ctypes.c_ulonglong * 32)()
+    print("rc", lib.repet_debug_gram_stamps(g))
+    a = np.array(g[:], dtype=np.int64).reshape(8, 4)
+    for row in a:
+        print("K loop %7d  natural stores %6d  mirror %6d | total %7d" % (row[1] - row[0], row[2] - row[1], row[3] - row[2], row[3] - row[0]))
