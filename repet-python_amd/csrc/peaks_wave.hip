@@ -211,23 +211,43 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
     WSTAMP_DECL
     for (;;) {
         n_peak = 0; n_amb = 0; n_cand = 0;
+        // Chunk c + 1 is fetched (into registers) while chunk c is worked on -- the row walk is a chain of dependent steps
+        // per wave, and a global load at its head would otherwise be waited for nine times per row. Only chunks that
+        // lie wholly inside the row (plain 16-byte loads, no boundary cases: few registers) are fetched ahead.
+        auto interior = [&](int c) { return vec_ok && c * step - halo >= 0 && c * step - halo + kChunkElems <= n; };
+        float4 ahead[4];
+        bool have_ahead = false;
         for (int c = 0; c < n_chunks; ++c) {
             const int s0 = c * step - halo;                  // first element of the chunk (a multiple of 4; may be negative)
             const int t_lo = c * step, t_hi = (t_lo + step < n) ? t_lo + step : n;     // elements tested: [t_lo, t_hi)
             wave_sync();                                     // the previous chunk's reads of the buffer are done
             // coalesced 16-byte loads -> padded LDS
+            if (have_ahead) {                                // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = 64 * q + lane;
-                const int i0 = s0 + 4 * g;
-                float4 v;
-                if (vec_ok && i0 >= 0 && i0 + 3 < n) {
-                    v = *reinterpret_cast<const float4*>(src + i0);
-                    v = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
-                } else {
-                    v = make_float4(fetch(i0), fetch(i0 + 1), fetch(i0 + 2), fetch(i0 + 3));
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = ahead[q];
+                    L.buf[phys4(64 * q + lane)] = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
                 }
-                L.buf[phys4(g)] = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = 64 * q + lane;
+                    const int i0 = s0 + 4 * g;
+                    float4 v;
+                    if (vec_ok && i0 >= 0 && i0 + 3 < n) {
+                        v = *reinterpret_cast<const float4*>(src + i0);
+                        v = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
+                    } else {
+                        v = make_float4(fetch(i0), fetch(i0 + 1), fetch(i0 + 2), fetch(i0 + 3));
+                    }
+                    L.buf[phys4(g)] = v;
+                }
+            }
+            have_ahead = c + 1 < n_chunks && interior(c + 1);
+            if (have_ahead) {
+                const float* nx = src + (c + 1) * step - halo + 4 * lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ahead[q] = *reinterpret_cast<const float4*>(nx + 256 * q);
             }
             wave_sync();
             WSTAMP(0)
