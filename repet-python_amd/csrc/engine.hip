@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -62,15 +63,18 @@ int fail(int code, const std::string& msg) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;        // points into another context's buffer: never freed or grown here
+    void borrow(void* ptr, size_t bytes) { p = ptr; cap = bytes; borrowed = true; }
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        if (borrowed) return hipErrorInvalidValue;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         const size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -98,6 +102,11 @@ struct repet_ctx {
     int64_t win_total = 0, win_offset = 0;
     bool win_skip_clear = false;  // exec_extended cleared `out` itself (window mode)
     int32_t last_fs = 0;          // sampling frequency of the resident clip when it came from a WAVE file (for repet_ctx_result_wav)
+    // `extended`: the longer last segment cannot join the batch of equal segments; its analysis (STFT .. mask) runs on
+    // this auxiliary context's stream beside the batch and only its inverse STFT waits for the batch's
+    repet_ctx* aux = nullptr;
+    hipEvent_t aux_start = nullptr, aux_main_done = nullptr, aux_done = nullptr;
+    std::function<int()> pre_synthesis;      // run_original calls it (once) right before its inverse STFT
     bool clip_loop = false;       // true while run_algo works through the clips one by one
     int32_t n_channels = 0;
     // workspaces
@@ -423,6 +432,11 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     m.n_batch = B;
     HIP_TRY(launch_mask_period(m, period_slots, 0, p->period_lo + 1, c->stream));
     mark(c, "mask_period", B * (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
+    if (c->pre_synthesis) {
+        std::function<int()> hook;
+        hook.swap(c->pre_synthesis);
+        RP_TRY(hook());
+    }
     if (!weighted && B == 1) {
         RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, false, 0, 0));
     } else if (!weighted) {
@@ -526,22 +540,61 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
     // the equal-length segments go through every stage as ONE batch -- in bounded batches, so that the workspaces of an
     // hours-long recording stay at a few GB (a segment's spectra are about 15 MB at 44.1 kHz stereo)
     constexpr int64_t kMaxSegmentBatch = 256;
-    for (int64_t done = 0; done < uniform; done += kMaxSegmentBatch) {
-        const int64_t nb = std::min(kMaxSegmentBatch, uniform - done);
-        repet_timing* timing = c->timing;
-        if (done > 0) c->timing = nullptr;                          // stages are listed once, for the first batch
-        const int rc = run_original(c, p, (first + done) * Hs, L, (int)nb, Hs, c->periods.as<int32_t>() + done, true,
-                                    (int)(first + done), (int)count, O);
-        c->timing = timing;
-        if (rc != REPET_OK) return rc;
-    }
-    if (first + n_seg == count) {                                   // the longer last segment, repet.py:320-322
-        repet_timing* timing = c->timing;                           // its stages are not listed separately
-        if (uniform > 0) c->timing = nullptr;
-        int rc = run_original(c, p, last * Hs, N - last * Hs, 1, 0, c->periods.as<int32_t>() + uniform, true, (int)last, (int)count, O);
-        c->timing = timing;
-        if (rc != REPET_OK) return rc;
-        if (uniform > 0) mark(c, "last_segment", 0, 0);
+    auto run_uniform = [&]() -> int {
+        for (int64_t done = 0; done < uniform; done += kMaxSegmentBatch) {
+            const int64_t nb = std::min(kMaxSegmentBatch, uniform - done);
+            repet_timing* timing = c->timing;
+            if (done > 0) c->timing = nullptr;                          // stages are listed once, for the first batch
+            const int rc = run_original(c, p, (first + done) * Hs, L, (int)nb, Hs, c->periods.as<int32_t>() + done, true,
+                                        (int)(first + done), (int)count, O);
+            c->timing = timing;
+            if (rc != REPET_OK) return rc;
+        }
+        return REPET_OK;
+    };
+    const bool with_last = first + n_seg == count;                  // the longer last segment, repet.py:320-322
+    static const bool overlap_last = [] { const char* e = getenv("REPET_EXTENDED_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (with_last && uniform > 0 && overlap_last) {
+        // One small clip through eight kernels is a chain of launch latencies (0.22 ms at cfg 3) -- beside the batch it
+        // is free: its analysis is enqueued on the auxiliary stream FIRST, the batch follows on the main stream, and
+        // only the last segment's inverse STFT (it accumulates into samples the batch also writes) waits for the batch.
+        if (!c->aux) {
+            RP_TRY(repet_ctx_create(c->device, &c->aux));
+            HIP_TRY(hipEventCreateWithFlags(&c->aux_start, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->aux_main_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming));
+        }
+        repet_ctx* x = c->aux;
+        x->audio.borrow(c->audio.p, c->audio.cap);
+        x->out.borrow(c->out.p, c->out.cap);
+        x->n_samples = c->n_samples; x->n_channels = c->n_channels; x->n_clips = 1; x->clip_base = c->clip_base;
+        x->timing = nullptr;
+        HIP_TRY(hipEventRecord(c->aux_start, c->stream));              // the clip is resident, `out` is cleared
+        HIP_TRY(hipStreamWaitEvent(x->stream, c->aux_start, 0));
+        int batch_rc = REPET_OK;
+        x->pre_synthesis = [&]() -> int {
+            batch_rc = run_uniform();
+            if (batch_rc != REPET_OK) return batch_rc;
+            if (hipEventRecord(c->aux_main_done, c->stream) != hipSuccess || hipStreamWaitEvent(x->stream, c->aux_main_done, 0) != hipSuccess)
+                return fail(REPET_ERR_HIP, "extended: stream ordering of the last segment");
+            return REPET_OK;
+        };
+        const int rc = run_original(x, p, last * Hs, N - last * Hs, 1, 0, c->periods.as<int32_t>() + uniform, true, (int)last, (int)count, O);
+        x->pre_synthesis = nullptr;
+        if (rc != REPET_OK) { (void)hipStreamSynchronize(x->stream); return rc; }
+        HIP_TRY(hipEventRecord(c->aux_done, x->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_done, 0));
+        mark(c, "last_segment", 0, 0);
+    } else {
+        if (uniform > 0) RP_TRY(run_uniform());
+        if (with_last) {
+            repet_timing* timing = c->timing;                           // its stages are not listed separately
+            if (uniform > 0) c->timing = nullptr;
+            int rc = run_original(c, p, last * Hs, N - last * Hs, 1, 0, c->periods.as<int32_t>() + uniform, true, (int)last, (int)count, O);
+            c->timing = timing;
+            if (rc != REPET_OK) return rc;
+            if (uniform > 0) mark(c, "last_segment", 0, 0);
+        }
     }
     c->last_n_periods = (int32_t)n_seg;
     return REPET_OK;
@@ -878,6 +931,12 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (!c) return REPET_OK;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux) {
+        c->aux->audio.release(); c->aux->out.release();           // borrowed: just forgotten
+        repet_ctx_destroy(c->aux);
+        c->aux = nullptr;
+        for (hipEvent_t e : {c->aux_start, c->aux_main_done, c->aux_done}) if (e) (void)hipEventDestroy(e);
+    }
     c->ring.release();
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
                       &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
