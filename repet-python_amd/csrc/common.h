@@ -32,6 +32,9 @@ struct StftArgs {
     int32_t W, H; int64_t T; int32_t FS; int32_t centred;
     float2* X; float* V; int64_t chan_stride;     // elements between channels in X and V
     float* Vm; float* Vn; float* P;
+    // (nullable) the f16 hi / lo planes of Vn for the f16-split Gram kernels (gram_f16.hip: [row][FS/32][hi 32 | lo 32],
+    // scale 2^7), written beside Vn so that no separate split pass reads Vn again; clips batch_mean_stride * 2 halves apart
+    void* Vh;
     // batch of equal-length clips (segments of `extended`): blockIdx.y = b
     int32_t n_batch; int64_t batch_sample_stride; // samples between the starts of consecutive clips
     int64_t batch_spec_stride;                    // elements between clips in X and V (= C*chan_stride)
@@ -55,6 +58,15 @@ __host__ __device__ inline float segment_weight(int64_t n, int64_t fade_in, int6
         }
     }
     return w;
+}
+
+// one component of a unit row into the two f16 planes (the arithmetic of split_f16_kernel, gram_f16.hip)
+__device__ __forceinline__ void store_split_f16(void* planes, int64_t e, float x) {
+    _Float16* p = static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31);
+    const float v = x * 128.0f;
+    const _Float16 h = (_Float16)v;
+    p[0] = h;
+    p[32] = (_Float16)(v - (float)h);
 }
 
 // K9: masked spectrum -> inverse real FFT -> time frames yf[c][t][W] (scaled by 1/W like np.fft.ifft).

@@ -224,7 +224,8 @@ bool gram_big_enabled() {
     return on;
 }
 
-int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS, bool unit_rows = false) {
+int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS, bool unit_rows = false,
+                  bool planes_ready = false) {
     if (unit_rows && gram_f16_enabled() && gram_big_enabled() && T >= 8 * gram_big_tile()) {
         const int bt = gram_big_tile();
         const int nb = (int)ceil_div(T, bt);
@@ -240,8 +241,10 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
         // the planes of rows [round_up(T, 128), round_up(T, 256)) are read by the last tile row and never used: the
         // buffer only has to be that long
         const int64_t count = round_up(T, kTile) * FS;
-        HIP_TRY(c->Vh.ensure((size_t)round_up(T, bt) * FS * 4));
-        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        if (!planes_ready) {
+            HIP_TRY(c->Vh.ensure((size_t)round_up(T, bt) * FS * 4));
+            HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        }
         HIP_TRY(launch_gram_full_f16_big(c->Vh.p, T, FS, S, TS, c->tiles_big.as<int2>(), c->tiles_big_count, c->stream));
         return REPET_OK;
     }
@@ -249,8 +252,10 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
     RP_TRY(get_tiles(c, T, 1 << 30, &tiles, &n));
     if (unit_rows && gram_f16_enabled()) {      // rows are unit vectors (components in [0, 1]): safe for the f16 split
         const int64_t count = round_up(T, kTile) * FS;
-        HIP_TRY(c->Vh.ensure((size_t)count * 4));
-        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        if (!planes_ready) {
+            HIP_TRY(c->Vh.ensure((size_t)count * 4));
+            HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        }
         HIP_TRY(launch_gram_full_f16(c->Vh.p, T, FS, S, TS, tiles, n, c->stream));
         return REPET_OK;
     }
@@ -260,7 +265,7 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
 // unit_rows: A holds unit vectors (the similarity band of simonline), safe for the f16-split kernel; the beat-spectrum
 // bands (power spectra, wide dynamic range) stay on the exact-fp32 one. B clips: a_stride / band_stride in elements.
 int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP, bool unit_rows = false,
-                  int B = 1, int64_t a_stride = 0, int64_t band_stride = 0) {
+                  int B = 1, int64_t a_stride = 0, int64_t band_stride = 0, bool planes_ready = false) {
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
     static const bool scaled = [] { const char* e = getenv("REPET_GRAM_BAND"); return !(e && e[0] == 'f' && e[1] == '3'); }();
@@ -285,8 +290,10 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
         const int64_t per_clip = round_up(T, kTile) * FS;
         if (B > 1 && a_stride != per_clip) return fail(REPET_ERR_BAD_ARG, "internal: batch stride of the unit rows");
         const int64_t count = per_clip * B;
-        HIP_TRY(c->Vh.ensure((size_t)count * 4));
-        HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        if (!planes_ready) {
+            HIP_TRY(c->Vh.ensure((size_t)count * 4));
+            HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
+        }
         HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream));
         return REPET_OK;
     }
@@ -346,6 +353,14 @@ Geo make_geo(int W, int H, int64_t T, int C) {
 }
 
 // B: number of equal-geometry clips handled together (segments of `extended`); buffers are [B][C][rows][FS]
+// REPET_SPLIT_IN_STFT=1: the STFT epilogue writes the f16 planes of the unit rows itself instead of a separate pass over
+// Vn. Measured at cfg 2: the split pass disappears (-0.011 ms) and the STFT grows by as much (+0.012 ms: two 2-byte
+// stores per component from a thread that owns every 256th bin) -- no gain, so the separate pass stays the default.
+bool split_in_stft() {
+    static const bool on = [] { const char* e = getenv("REPET_SPLIT_IN_STFT"); return e && e[0] == '1'; }();
+    return on && gram_f16_enabled();
+}
+
 int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B = 1) {
     HIP_TRY(c->X.ensure((size_t)B * g.C * g.chan_stride * sizeof(float2)));
     HIP_TRY(c->V.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
@@ -358,6 +373,14 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
         if (g.Tpad > g.T)
             HIP_TRY(hipMemset2DAsync(c->Vn.as<float>() + g.T * g.FS, mean_elems * sizeof(float), 0,
                                      (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), (size_t)B, c->stream));
+        if (split_in_stft()) {
+            // the f16 planes of the unit rows, written by the STFT beside Vn (same bytes per row: 2 planes x 2 bytes);
+            // the big-tile Gram kernel reads (and ignores) up to round_up(T, 256) rows of a single clip
+            HIP_TRY(c->Vh.ensure((B == 1 ? (size_t)round_up(g.T, 256) * g.FS : B * mean_elems) * sizeof(float)));
+            if (g.Tpad > g.T)
+                HIP_TRY(hipMemset2DAsync(c->Vh.as<float>() + g.T * g.FS, mean_elems * sizeof(float), 0,
+                                         (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), (size_t)B, c->stream));
+        }
     }
     if (want_p) {
         HIP_TRY(c->P.ensure(B * mean_elems * sizeof(float)));
@@ -375,6 +398,7 @@ int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64
     a.W = g.W; a.H = g.H; a.T = g.T; a.FS = g.FS; a.centred = centred;
     a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
     a.Vm = nullptr; a.Vn = vn ? c->Vn.as<float>() : nullptr; a.P = p ? c->P.as<float>() : nullptr;
+    a.Vh = (vn && split_in_stft()) ? c->Vh.p : nullptr;
     a.n_batch = B; a.batch_sample_stride = batch_sample_stride; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
     a.batch_mean_stride = g.Tpad * g.FS;
     HIP_TRY(launch_stft(a, c->stream));
@@ -718,7 +742,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true));
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft()));
     {
         // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
         // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
@@ -808,7 +832,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int LP = (int)round_up(B, 64);
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP, spec_stride = (int64_t)g.C * g.chan_stride;
     HIP_TRY(c->band.ensure((size_t)nb * band_stride * sizeof(float)));
-    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride));
+    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride, split_in_stft()));
     mark(c, c->band_on_f16 ? "similarity_band_f16x3" : "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;

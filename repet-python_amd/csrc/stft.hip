@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
     a.V += b * a.batch_spec_stride;
     if (a.Vm) a.Vm += b * a.batch_mean_stride;
     if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.Vh) a.Vh = static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride;
     if (a.P) a.P += b * a.batch_mean_stride;
     {
         float2 wreg[LOADS], treg[kTwLoads];
@@ -445,12 +446,14 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
             if (k <= N) {
                 if (a.Vm) a.Vm[row + k] = acc[i];
                 if (a.Vn) a.Vn[row + k] = acc[i] / norm;
+                if (a.Vh) store_split_f16(a.Vh, row + k, acc[i] / norm);
                 if (a.P) a.P[row + k] = acc[i] * acc[i];
             }
         }
         if (tid < a.FS - (N + 1)) {
             if (a.Vm) a.Vm[row + N + 1 + tid] = 0.f;
             if (a.Vn) a.Vn[row + N + 1 + tid] = 0.f;
+            if (a.Vh) store_split_f16(a.Vh, row + N + 1 + tid, 0.f);
             if (a.P) a.P[row + N + 1 + tid] = 0.f;
         }
         __syncthreads();
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     a.V += b * a.batch_spec_stride;
     if (a.Vm) a.Vm += b * a.batch_mean_stride;
     if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.Vh) a.Vh = static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride;
     if (a.P) a.P += b * a.batch_mean_stride;
 
     FftTwiddles<kTables ? 4 : N> ft;                // register twiddles only where the tables do not fit in LDS
@@ -622,12 +626,14 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
             if (k <= N) {
                 if (a.Vm) a.Vm[row + k] = acc[i];
                 if (a.Vn) a.Vn[row + k] = acc[i] / norm;
+                if (a.Vh) store_split_f16(a.Vh, row + k, acc[i] / norm);
                 if (a.P) a.P[row + k] = acc[i] * acc[i];
             }
         }
         if (tid < a.FS - (N + 1)) {
             if (a.Vm) a.Vm[row + N + 1 + tid] = 0.f;
             if (a.Vn) a.Vn[row + N + 1 + tid] = 0.f;
+            if (a.Vh) store_split_f16(a.Vh, row + N + 1 + tid, 0.f);
             if (a.P) a.P[row + N + 1 + tid] = 0.f;
         }
         __syncthreads();                     // red[] is reused by the next frame
@@ -915,6 +921,7 @@ __global__ __launch_bounds__(256) void stft_wave_kernel(StftArgs a, int frames_p
     a.V += b * a.batch_spec_stride;
     if (a.Vm) a.Vm += b * a.batch_mean_stride;
     if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.Vh) a.Vh = static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride;
     if (a.P) a.P += b * a.batch_mean_stride;
 
     for (int i = tid; i < W; i += 256) tw[i] = a.twiddle[i];
@@ -990,6 +997,7 @@ __global__ __launch_bounds__(256) void stft_wave_kernel(StftArgs a, int frames_p
                 const float m = (k <= N) ? vst[(df * C) * a.FS + k] : 0.f;
                 if (a.Vm) a.Vm[row + k] = m;
                 if (a.Vn) a.Vn[row + k] = (k <= N) ? m / norm : 0.f;
+                if (a.Vh) store_split_f16(a.Vh, row + k, (k <= N) ? m / norm : 0.f);
                 if (a.P) a.P[row + k] = m * m;
             }
             __syncthreads();                  // red[] and vst are reused

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     a.V += b * a.batch_spec_stride;
     if (a.Vm) a.Vm += b * a.batch_mean_stride;
     if (a.Vn) a.Vn += b * a.batch_mean_stride;
+    if (a.Vh) a.Vh = static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride;
     if (a.P) a.P += b * a.batch_mean_stride;
 
     const RegTwiddles tw = load_reg_twiddles<false>(tw_lds, a.twiddle, tid);
@@ -242,16 +243,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             const int k = lane + 64 * s;
             if (a.Vm) a.Vm[row + k] = acc[s];
             if (a.Vn) a.Vn[row + k] = acc[s] / norm;
+            if (a.Vh) store_split_f16(a.Vh, row + k, acc[s] / norm);
             if (a.P) a.P[row + k] = acc[s] * acc[s];
         }
         if (lane == 0) {
             if (a.Vm) a.Vm[row + N] = acc[16];
             if (a.Vn) a.Vn[row + N] = acc[16] / norm;
+            if (a.Vh) store_split_f16(a.Vh, row + N, acc[16] / norm);
             if (a.P) a.P[row + N] = acc[16] * acc[16];
         }
         if (lane < a.FS - (N + 1)) {
             if (a.Vm) a.Vm[row + N + 1 + lane] = 0.f;
             if (a.Vn) a.Vn[row + N + 1 + lane] = 0.f;
+            if (a.Vh) store_split_f16(a.Vh, row + N + 1 + lane, 0.f);
             if (a.P) a.P[row + N + 1 + lane] = 0.f;
         }
     }
