@@ -458,9 +458,10 @@ def test_gram_tile_sizes_give_the_same_matrix():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "repet-python_amd"), root)
     outs = []
-    for tile in ("256", "128"):
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile}_{os.getpid()}.npz")
-        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_GRAM_TILE=tile))
+    for tile in ("256", "128", "256+split-in-stft"):            # the third: f16 planes written by the STFT epilogue itself
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile[:3]}_{len(tile)}_{os.getpid()}.npz")
+        env = dict(os.environ, REPET_GRAM_TILE=tile[:3], REPET_SPLIT_IN_STFT="1" if "split" in tile else "0")
+        subprocess.check_call([sys.executable, "-c", code, out], env=env)
         with np.load(out) as z:
             outs.append({k: z[k] for k in z.files})
         os.remove(out)
@@ -468,7 +469,7 @@ def test_gram_tile_sizes_give_the_same_matrix():
     assert np.array_equal(s, outs[1]["s"], equal_nan=True)
     assert np.array_equal(s, s.T, equal_nan=True)
     assert np.all(np.isnan(s[700])) and np.all(np.isnan(s[:, 700])) and np.isnan(s).sum() == 2 * 2300 - 1
-    assert np.array_equal(outs[0]["y"], outs[1]["y"])
+    assert np.array_equal(outs[0]["y"], outs[1]["y"]) and np.array_equal(outs[0]["y"], outs[2]["y"])
 
 
 @pytest.mark.parametrize("seconds,fs,channels,number,distance", [(50, 44100, 2, 100, 1.0), (110, 22050, 1, 100, 0.3),
@@ -496,7 +497,7 @@ def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance)
             outs.append({k: z[k] for k in z.files})
         os.remove(out)
     assert "rank_columns" in outs[0]["stages"].tolist() and "rank_columns" not in outs[1]["stages"].tolist()
-    assert np.array_equal(outs[0]["y"], outs[1]["y"])
+    assert np.array_equal(outs[0]["y"], outs[1]["y"]) and np.array_equal(outs[0]["y"], outs[2]["y"])
 
 
 def test_long_similarity_number_uses_bisection_path():
