@@ -17,7 +17,8 @@ root, out = sys.argv[1], sys.argv[2]
 # kernel name fragment -> (stage, fetch correction k, note)
 KERNELS = [
     ("stft_pair_kernel", "stft", 1, "4-8 B/lane"), ("stft_kernel", "stft", 1, "4-8 B/lane"), ("stft_reg_kernel", "stft", 1, "4-8 B/lane"),
-    ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
+    ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("split_f16_rows_kernel", "similarity_gemm", 2, "16 B/lane"),
+    ("gram_f16_big_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("local_maxima_wave_kernel", "local_maxima", 2, "16 B/lane"), ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
     ("columns_from_rows_kernel", "rank_columns", 1, "4 B/lane"), ("rank_columns_kernel", "rank_columns", 2, "16 B/lane"),
