@@ -101,6 +101,7 @@ struct repet_ctx {
     // (multi-GPU `extended`: a rank holds only the samples of its own segment range); 0 = the resident clip is whole
     int64_t win_total = 0, win_offset = 0;
     bool win_skip_clear = false;  // exec_extended cleared `out` itself (window mode)
+    bool ola_first_batch = false; // run_original: the first batch of equal segments of an `extended` run (class 0 may store)
     int32_t last_fs = 0;          // sampling frequency of the resident clip when it came from a WAVE file (for repet_ctx_result_wav)
     // `extended`: the longer last segment cannot join the batch of equal segments; its analysis (STFT .. mask) runs on
     // this auxiliary context's stream beside the batch and only its inverse STFT waits for the batch's
@@ -483,7 +484,10 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
             IstftOlaArgs a{};
             a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
             a.twiddle = tb->twiddle.as<float2>(); a.trim = g.W - g.H; a.out = c->out.as<float>(); a.n_out = n;
-            a.out_offset = c->clip_base; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 1;
+            a.out_offset = c->clip_base; a.scale = (float)(1.0 / tb->cola);
+            // class 0 of the first batch tiles its span of the cleared output exactly when the segment length is a whole
+            // number of steps, and nothing has been added there yet: it stores, the other classes add
+            a.accumulate_weighted = (k == 0 && c->ola_first_batch && hop > 0 && n == (int64_t)classes * hop) ? 2 : 1;
             a.n_batch = (B - k + classes - 1) / classes; a.batch_first = seg_first + k; a.batch_step = classes;
             a.batch_total = seg_total; a.batch_local0 = k; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
             a.batch_out_stride = hop > 0 ? hop : 0; a.overlap = overlap;
@@ -569,8 +573,10 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
             const int64_t nb = std::min(kMaxSegmentBatch, uniform - done);
             repet_timing* timing = c->timing;
             if (done > 0) c->timing = nullptr;                          // stages are listed once, for the first batch
+            c->ola_first_batch = done == 0;
             const int rc = run_original(c, p, (first + done) * Hs, L, (int)nb, Hs, c->periods.as<int32_t>() + done, true,
                                         (int)(first + done), (int)count, O);
+            c->ola_first_batch = false;
             c->timing = timing;
             if (rc != REPET_OK) return rc;
         }

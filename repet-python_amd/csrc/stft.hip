@@ -8,7 +8,10 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace repet {
 
@@ -67,6 +70,16 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const float2* _
 }
 
 constexpr int kFftThreads = 256;
+
+// s_memtime stamps of one workgroup in 61 (diagnostic build only: make stamps, tools/peak_stamps.py)
+#ifdef REPET_FFT_STAMPS
+__device__ unsigned long long g_fft_stamps[2 * 8 * 8];      // [kernel][sampled workgroup][phase] summed cycles
+#define FSTAMP_DECL unsigned long long fst_prev = __builtin_amdgcn_s_memtime(); const bool fst_on = threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x % 61) == 7 && blockIdx.x / 61 < 8;
+#define FSTAMP(kern, k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (fst_on) g_fft_stamps[(kern) * 64 + (blockIdx.x / 61) * 8 + (k)] += now_ - fst_prev; fst_prev = now_; }
+#else
+#define FSTAMP_DECL
+#define FSTAMP(kern, k)
+#endif
 
 // Same Stockham FFT with the per-thread stage twiddles held in registers. Thread `tid` always owns the
 // butterflies i = tid + 256*q (q < BPT), whose twiddle exponent k = i & (p-1) depends only on the stage, so
@@ -221,7 +234,7 @@ __device__ __forceinline__ float2* fft_lds_tab(float2* a, float2* b, const float
     return a;
 }
 
-constexpr int kStftFrameRun = 4;     // frames per workgroup: the register tables are loaded once per run
+constexpr int kStftFrameRun = 4;     // least frames per workgroup: the tables are loaded once per run (launch_stft picks the run)
 
 // Two transforms at once by the same 256 threads (the two channels of a stereo frame): every stage does the
 // butterflies of both before the ONE barrier they share and reads its twiddles once, so each thread has two
@@ -291,7 +304,7 @@ __device__ __forceinline__ void fft_lds_tab2(float2*& a0, float2*& b0, float2*& 
 // transformed together (fft_lds_tab2), their interleaved samples arrive as one float2 per sample and are fetched
 // one frame ahead; window and twiddles live in LDS (see stft_kernel for why).
 template <int W>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void stft_pair_kernel(StftArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void stft_pair_kernel(StftArgs a, int run) {
     constexpr int N = W / 2;
     constexpr int SLOTS = N / kFftThreads + 1;
     constexpr int LOADS = (N + kFftThreads - 1) / kFftThreads;
@@ -304,6 +317,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.y;
     const int C = a.n_channels;
+    FSTAMP_DECL
     a.sample_offset += b * a.batch_sample_stride;
     a.X += b * a.batch_spec_stride;
     a.V += b * a.batch_spec_stride;
@@ -334,8 +348,8 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
             if (m <= 3 * W / 4) tw_lds[m] = treg[i];
         }
     }
-    const int64_t t_begin = (int64_t)blockIdx.x * kStftFrameRun;
-    const int64_t t_end = (t_begin + kStftFrameRun < a.T) ? t_begin + kStftFrameRun : a.T;
+    const int64_t t_begin = (int64_t)blockIdx.x * run;
+    const int64_t t_end = (t_begin + run < a.T) ? t_begin + run : a.T;
 
     float2 raw0[LOADS], raw1[LOADS];               // (channel c, channel c+1) of samples 2n and 2n+1
     auto fetch = [&](int64_t t, int c) {
@@ -367,6 +381,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
     };
     if (t_begin < t_end) fetch(t_begin, 0);
     __syncthreads();
+    FSTAMP(0, 0)                                   // prologue: tables into LDS, first fetch issued
 
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int64_t row = t * a.FS;
@@ -385,13 +400,16 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
                     a1[n] = make_float2(raw0[i].y * w.x, raw1[i].y * w.y);
                 }
             }
+            FSTAMP(0, 1)                           // wait for the fetched samples, window, LDS
             {
                 const bool same_frame = c + 2 < C;
                 const int64_t tn = same_frame ? t : t + 1;
                 if (tn < t_end) fetch(tn, same_frame ? c + 2 : 0);
             }
             __syncthreads();
+            FSTAMP(0, 2)                           // next fetch issued, barrier
             fft_lds_tab2<N, false>(a0, b0, a1, b1, tw_lds, W);
+            FSTAMP(0, 3)                           // the FFT stages
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
                 const int k = tid + kFftThreads * i;
@@ -421,6 +439,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
                 }
             }
             __syncthreads();
+            FSTAMP(0, 4)                           // split, magnitudes, X / V stores, barrier
         }
 
         if (a.Vm == nullptr && a.Vn == nullptr && a.P == nullptr) continue;
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll
         for (int w = 0; w < kFftThreads / kWave; ++w) total += red[w];
         const float norm = sqrtf(total);
+        FSTAMP(0, 5)                               // channel mean, norm reduction
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int k = tid + kFftThreads * i;
@@ -457,6 +477,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
             if (a.P) a.P[row + N + 1 + tid] = 0.f;
         }
         __syncthreads();
+        FSTAMP(0, 6)                               // mean / unit / squared rows stored, barrier
     }
 }
 
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
 #define REPET_ISTFT_MIN_WAVES 1
 #endif
 template <int W>
-__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_STFT_MIN_WAVES : 1, 8))) void stft_kernel(StftArgs a) {
+__global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_STFT_MIN_WAVES : 1, 8))) void stft_kernel(StftArgs a, int run) {
     constexpr int N = W / 2;                       // complex FFT length; also the Nyquist bin index
     constexpr int SLOTS = N / kFftThreads + 1;     // bins k = tid + 256*i, k <= N
     constexpr int LOADS = (N + kFftThreads - 1) / kFftThreads;
@@ -521,8 +542,8 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     } else {
         fft_twiddles<kTables ? 4 : N, false>(ft, a.twiddle, W);
     }
-    const int64_t t_begin = (int64_t)blockIdx.x * kStftFrameRun;
-    const int64_t t_end = (t_begin + kStftFrameRun < a.T) ? t_begin + kStftFrameRun : a.T;
+    const int64_t t_begin = (int64_t)blockIdx.x * run;
+    const int64_t t_end = (t_begin + run < a.T) ? t_begin + run : a.T;
 
     float2 raw[LOADS];                             // samples (2n, 2n+1) of the transform about to be windowed
     auto fetch = [&](int64_t t, int c) {
@@ -694,7 +715,7 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(OlaArgs a) {
 // half of frame h, so it inverts frames h0-1 .. h0+RUN-1 and carries each channel's tail in LDS. The
 // time-domain frames never touch HBM and every output sample is written exactly once, coalesced over
 // the interleaved channels.
-constexpr int kOlaRun = 8;          // hops per workgroup (16 for big batches: the frame before the run is redone per workgroup)
+constexpr int kOlaRun = 8;          // hops per workgroup, about: launch_istft_ola fits the run to the launch (frames_per_workgroup)
 template <int W>
 struct InverseTables {
     FftTwiddles<W / 2> ft;
@@ -725,11 +746,10 @@ __device__ __forceinline__ void fetch_spectrum(SpectrumRegs<W>& r, const float2*
     }
 }
 
-// Hermitian repack of a fetched (masked) spectrum + inverse W/2-point FFT; returns the LDS buffer holding
-// the W time samples (unscaled).
+// Hermitian repack of a fetched (masked) spectrum into the packed W/2-point transform (LDS); the registers are free
+// for the next fetch afterwards.
 template <int W>
-__device__ __forceinline__ const float2* inverse_frame(const SpectrumRegs<W>& r, const InverseTables<W>& t,
-                                                       float2* buf0, float2* buf1) {
+__device__ __forceinline__ void repack_spectrum(const SpectrumRegs<W>& r, const InverseTables<W>& t, float2* buf0) {
     constexpr int N = W / 2;
 #pragma unroll
     for (int i = 0; i < (N + kFftThreads - 1) / kFftThreads; ++i) {
@@ -743,10 +763,26 @@ __device__ __forceinline__ const float2* inverse_frame(const SpectrumRegs<W>& r,
             buf0[k] = make_float2(e.x - o.y, e.y + o.x);
         }
     }
-    __syncthreads();
-    return fft_lds_regs<N, true>(buf0, buf1, t.ft);
 }
 
+// w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; den_in / den_ov
+// are (float)(2 fade_in) and (float)(2 overlap). Same values as segment_weight: the conversions are of the same integers.
+__device__ __forceinline__ float segment_weight32(int n, int fade_in, int overlap, int step, int later, float den_in, float den_ov) {
+    float w = 1.f;
+    if (n < fade_in) w = (float)(2 * n + 1) / den_in;
+    if (overlap > 0 && step > 0) {
+        for (int q = 1, base = step; q <= later && base <= n; ++q, base += step) {
+            const int r = n - base;
+            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) / den_ov;
+        }
+    }
+    return w;
+}
+
+struct __attribute__((packed, aligned(4))) Float4U { float x, y, z, w; };    // a float4 at any dword address (segment offsets)
+
+// accumulate_weighted: 0 = store, 1 = out += w y, 2 = out = w y (a class of segments that tiles its span and is the first
+// to write there: no read of the cleared buffer)
 template <int W>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_ISTFT_MIN_WAVES : 1, 8))) void istft_ola_kernel(IstftOlaArgs a, int run) {
     constexpr int N = W / 2;          // complex points per frame = samples per hop (H = W/2)
@@ -757,9 +793,12 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     const int C = a.n_channels;
     float2* tails = reinterpret_cast<float2*>(dyn);            // [C][HP] second half of the previous frame
     float* stage = dyn + (size_t)C * N;                        // [N samples][C] one hop, interleaved
+    float* wts = stage + (size_t)C * N;                        // [N] cross-fade weights of the hop's samples (modes 1, 2)
     const int tid = threadIdx.x;
     const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * run;
+    const int64_t h_last = (h0 + run - 1 < a.last_hop) ? h0 + run - 1 : a.last_hop;
     const float inv_n = 1.0f / (float)N;
+    FSTAMP_DECL
     InverseTables<W> tables;
     inverse_tables<W>(tables, a.twiddle);
     if (a.n_batch > 0) {
@@ -771,57 +810,95 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
         a.seg_step = a.batch_out_stride;
         a.later = a.batch_total - 1 - j;
     }
+    const int mode = a.accumulate_weighted;
+    const bool narrow = a.n_out < (1 << 30) && a.seg_step < (1 << 30) && a.fade_in < (1 << 30) && a.fade_out < (1 << 30);
+    const int fade_in = (int)a.fade_in, overlap = (int)a.fade_out, step = (int)a.seg_step;
+    const float den_in = (float)(2 * a.fade_in), den_ov = (float)(2 * a.fade_out);
+    // whole float4 groups of the interleaved hop (positions inside a segment in 32 bits; otherwise element by element)
+    const int cshift = (mode != 0 && !narrow) ? -1 : C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : -1;
+    const int n_groups = N * C / 4;
 
+    // Measured and dropped (cfg 2 / 3 / 5): fetching the next spectrum while the current one is inverted, and fetching
+    // the old output values of an accumulating hop ahead -- the 16 + 8 registers cost a resident workgroup per CU and
+    // more than the latency they hide (0.076 / 0.512 / 0.679 ms against 0.071 / 0.488 / 0.600 without).
     SpectrumRegs<W> spec;
-    for (int c = 0; c < C; ++c) {                              // tails of frame h0-1
-        const int64_t t = h0 - 1;
-        if (t >= 0 && t < a.T) {
-            fetch_spectrum<W>(spec, a.Y + c * a.chan_stride + t * a.FS);
-            const float2* z = inverse_frame<W>(spec, tables, buf0, buf1);
-            for (int m = tid; m < HP; m += kFftThreads) tails[c * HP + m] = z[HP + m];
-        } else {
-            for (int m = tid; m < HP; m += kFftThreads) tails[c * HP + m] = make_float2(0.f, 0.f);
+    FSTAMP(1, 0)                                               // prologue: twiddle registers
+    for (int64_t t = h0 - 1; t <= h_last; ++t) {
+        const bool have = t >= 0 && t < a.T;                   // hop T holds only the last frame's tail
+        const bool emit = t >= h0;
+        const int64_t n_base = t * N - a.trim;                 // output sample of stage[0]; hop t = [t N, (t+1) N) padded
+        float* const dst0 = a.out + (a.out_offset + n_base) * C;
+        if (emit && mode != 0 && cshift >= 0) {                // read after the barriers of the channel loop
+            for (int i = tid; i < N; i += kFftThreads) {
+                const int64_t n = n_base + i;
+                wts[i] = (n >= 0 && n < a.n_out) ? segment_weight32((int)n, fade_in, overlap, step, a.later, den_in, den_ov) : 0.f;
+            }
         }
-        __syncthreads();
-    }
-    for (int r = 0; r < run; ++r) {
-        const int64_t h = h0 + r;
-        if (h > a.last_hop) break;
         for (int c = 0; c < C; ++c) {
-            if (h < a.T) {
-                fetch_spectrum<W>(spec, a.Y + c * a.chan_stride + h * a.FS);
-                const float2* z = inverse_frame<W>(spec, tables, buf0, buf1);
-                for (int m = tid; m < HP; m += kFftThreads) {
-                    const float2 head = z[m], tail = tails[c * HP + m];
+            const float2* z = buf0;
+            if (have) {
+                fetch_spectrum<W>(spec, a.Y + c * a.chan_stride + t * a.FS);
+                repack_spectrum<W>(spec, tables, buf0);
+                __syncthreads();
+                z = fft_lds_regs<N, true>(buf0, buf1, tables.ft);
+            }
+            FSTAMP(1, 2)                                       // fetch + repack + inverse FFT
+            for (int m = tid; m < HP; m += kFftThreads) {
+                const float2 head = have ? z[m] : make_float2(0.f, 0.f);
+                if (emit) {
+                    const float2 tail = tails[c * HP + m];
                     stage[(2 * m) * C + c] = (head.x + tail.x) * inv_n;
                     stage[(2 * m + 1) * C + c] = (head.y + tail.y) * inv_n;
-                    tails[c * HP + m] = z[HP + m];
                 }
-            } else {                                           // past the last frame: only the tail remains
-                for (int m = tid; m < HP; m += kFftThreads) {
-                    const float2 tail = tails[c * HP + m];
-                    stage[(2 * m) * C + c] = tail.x * inv_n;
-                    stage[(2 * m + 1) * C + c] = tail.y * inv_n;
-                    tails[c * HP + m] = make_float2(0.f, 0.f);
-                }
+                tails[c * HP + m] = have ? z[HP + m] : make_float2(0.f, 0.f);
             }
             __syncthreads();
+            FSTAMP(1, 3)                                       // heads + tails into the hop image, barrier
         }
-        // hop h covers padded samples [h*N, (h+1)*N); output sample n = padded - trim
-        const int64_t n_base = h * N - a.trim;
-        for (int i = tid; i < N * C; i += kFftThreads) {
-            const int64_t n = n_base + i / C;
-            if (n < 0 || n >= a.n_out) continue;
-            float v = stage[i] * a.scale;
-            float* dst = a.out + (a.out_offset + n) * C + (i % C);
-            if (a.accumulate_weighted) {
-                const float w = segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later);
-                *dst += w * v;
-            } else {
-                *dst = v;
+        if (!emit) continue;
+        if (cshift >= 0) {
+            for (int g = tid; g < n_groups; g += kFftThreads) {
+                const int64_t n0 = n_base + ((4 * g) >> cshift), n1 = n0 + (4 >> cshift) - 1;
+                const float4 raw = *reinterpret_cast<const float4*>(stage + 4 * g);
+                float v[4] = {raw.x * a.scale, raw.y * a.scale, raw.z * a.scale, raw.w * a.scale};
+                if (n0 >= 0 && n1 < a.n_out) {
+                    Float4U* dst = reinterpret_cast<Float4U*>(dst0 + 4 * g);
+                    if (mode != 0) {
+                        const float* wg = wts + ((4 * g) >> cshift);
+                        const float w[4] = {wg[0], wg[1 >> cshift], wg[2 >> cshift], wg[3 >> cshift]};
+                        if (mode == 1) {
+                            const Float4U o = *dst;
+                            v[0] = o.x + w[0] * v[0]; v[1] = o.y + w[1] * v[1]; v[2] = o.z + w[2] * v[2]; v[3] = o.w + w[3] * v[3];
+                        } else {
+                            v[0] = w[0] * v[0]; v[1] = w[1] * v[1]; v[2] = w[2] * v[2]; v[3] = w[3] * v[3];
+                        }
+                    }
+                    *dst = Float4U{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {              // the first and the last hop of a clip or segment
+                        const int64_t n = n_base + ((4 * g + e) >> cshift);
+                        if (n < 0 || n >= a.n_out) continue;
+                        float* dst = dst0 + 4 * g + e;
+                        const float w = mode != 0 ? wts[(4 * g + e) >> cshift] : 1.f;
+                        if (mode == 1) *dst += w * v[e];
+                        else *dst = w * v[e];
+                    }
+                }
+            }
+        } else {
+            for (int i = tid; i < N * C; i += kFftThreads) {
+                const int64_t n = n_base + i / C;
+                if (n < 0 || n >= a.n_out) continue;
+                const float v = stage[i] * a.scale;
+                float* dst = dst0 + i;
+                const float w = mode != 0 ? segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later) : 1.f;
+                if (mode == 1) *dst += w * v;
+                else *dst = mode == 2 ? w * v : v;
             }
         }
         __syncthreads();
+        FSTAMP(1, 4)                                           // the hop written (or accumulated), barrier
     }
 }
 
@@ -1099,6 +1176,45 @@ static hipError_t dispatch_window(int W, Fn&& fn) {
     return hipGetLastError();
 }
 
+// Frames (or hops) per workgroup. A launch runs in rounds of the device's resident workgroup slots and a workgroup's time
+// is its run plus a fixed part (tables, the frame before an overlap-add run), so the run is chosen to minimise
+// rounds x (run + fixed): cfg 2's forward STFT was 1 939 workgroups of 4 frames on 768 slots -- three rounds, the last
+// half empty; 705 workgroups of 11 frames are one. REPET_FFT_RUN=n fixes the run (diagnostics).
+static int frames_per_workgroup(const void* kernel, size_t dynamic_lds, int64_t units, int64_t batches, int least, double fixed) {
+    static const int forced = [] { const char* e = getenv("REPET_FFT_RUN"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> slots_of;
+    int slots;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = slots_of.find({kernel, dynamic_lds});
+        if (it == slots_of.end()) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop{};
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFftThreads, dynamic_lds) != hipSuccess || per_cu < 1) per_cu = 2;
+            // the occupancy query divides 160 KB by the bytes asked for; the hardware hands LDS out in 1 280-byte granules
+            // (32 768 bytes take 26 of the 128: four workgroups per CU, not five -- measured on the inverse kernel)
+            hipFuncAttributes fa{};
+            if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) {
+                const size_t lds = round_up((int64_t)(fa.sharedSizeBytes + dynamic_lds), 1280);
+                if (lds > 0 && (int)(163840 / lds) < per_cu) per_cu = (int)(163840 / lds) > 0 ? (int)(163840 / lds) : 1;
+            }
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
+            it = slots_of.emplace(std::make_pair(kernel, dynamic_lds), per_cu * prop.multiProcessorCount).first;
+        }
+        slots = it->second;
+    }
+    int best = least;
+    double best_cost = 0;
+    for (int run = least; run <= 8 * least; ++run) {
+        const int64_t wgs = ceil_div(units, run) * batches;
+        const double cost = (double)ceil_div(wgs, slots) * (run + fixed);
+        if (run == least || cost < best_cost * 0.98) { best = run; best_cost = cost; }     // longer runs only for a real gain
+    }
+    return best;
+}
+
 static bool use_wave_kernels() {
     static const bool on = [] { const char* e = getenv("REPET_FFT_PATH"); return e && e[0] == 'w'; }();   // "wave" selects the wave-synchronous kernels (slower today: see DESIGN.md)
     return on;
@@ -1108,6 +1224,7 @@ constexpr int kOlaWaveRun = 15;      // + the frame before = 16 frames per workg
 
 hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
     if (a.T <= 0) return hipSuccess;
+    // (also for the handful of frames of a streaming push: the stream's output must equal the offline result bit for bit)
     if (reg_fft_supported(a.W, a.n_channels, false)) return launch_stft_reg(a, s);
     if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 8) {
         const int C = a.n_channels, N = a.W / 2;
@@ -1124,19 +1241,20 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
         });
     }
     static const bool pair = [] { const char* e = getenv("REPET_FFT_PAIR"); return e ? atoi(e) != 0 : true; }();   // REPET_FFT_PAIR=0: one transform per pass
+    const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
     if (pair && (a.n_channels % 2) == 0 && a.W <= 2048) {
         return dispatch_window(a.W, [&](auto w) {
             constexpr int Wc = decltype(w)::value;
-            if constexpr (Wc <= 2048)
-                hipLaunchKernelGGL(stft_pair_kernel<Wc>,
-                                   dim3((unsigned)ceil_div(a.T, kStftFrameRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
-                                   dim3(kFftThreads), 0, s, a);
+            if constexpr (Wc <= 2048) {
+                const int run = frames_per_workgroup(reinterpret_cast<const void*>(&stft_pair_kernel<Wc>), 0, a.T, batches, kStftFrameRun, 0.35);
+                hipLaunchKernelGGL(stft_pair_kernel<Wc>, dim3((unsigned)ceil_div(a.T, run), (unsigned)batches), dim3(kFftThreads), 0, s, a, run);
+            }
         });
     }
     return dispatch_window(a.W, [&](auto w) {
-        hipLaunchKernelGGL(stft_kernel<decltype(w)::value>,
-                           dim3((unsigned)ceil_div(a.T, kStftFrameRun), (unsigned)(a.n_batch > 0 ? a.n_batch : 1)),
-                           dim3(kFftThreads), 0, s, a);
+        constexpr int Wc = decltype(w)::value;
+        const int run = frames_per_workgroup(reinterpret_cast<const void*>(&stft_kernel<Wc>), 0, a.T, batches, kStftFrameRun, 0.35);
+        hipLaunchKernelGGL(stft_kernel<Wc>, dim3((unsigned)ceil_div(a.T, run), (unsigned)batches), dim3(kFftThreads), 0, s, a, run);
     });
 }
 
@@ -1173,15 +1291,16 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
             }
         });
     }
-    const size_t dyn = (size_t)a.n_channels * N * sizeof(float) * 2;   // tails [C][N/2] float2 + stage [N][C]
+    // tails [C][N/2] float2 + stage [N][C] (+ weights [N] for the cross-faded segments of `extended`)
+    const size_t dyn = (size_t)a.n_channels * N * sizeof(float) * 2 + (a.accumulate_weighted ? (size_t)N * sizeof(float) : 0);
     if (dyn > 96 * 1024) return hipErrorInvalidValue;
     return dispatch_window(a.W, [&](auto w) {
         constexpr int Wc = decltype(w)::value;
-        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), (int)dyn);
         const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
-        const int run = hops * batches >= 8192 ? 2 * kOlaRun : kOlaRun;      // enough workgroups either way
-        hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, run), (unsigned)batches),
-                           dim3(kFftThreads), dyn, s, a, run);
+        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), (int)dyn);
+        // a run of r hops costs r + 1 inversions (the frame before it) and the twiddle prologue
+        const int run = frames_per_workgroup(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), dyn, hops, batches, kOlaRun - 2, 1.5);
+        hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, run), (unsigned)batches), dim3(kFftThreads), dyn, s, a, run);
     });
 }
 
@@ -1296,3 +1415,13 @@ hipError_t launch_unit_rows(const float* src, float* dst, int64_t T, int32_t F, 
 }
 
 }  // namespace repet
+
+#ifdef REPET_FFT_STAMPS
+extern "C" int repet_debug_fft_stamps(unsigned long long* out, int clear) {
+    if (clear) {
+        static unsigned long long zeros[2 * 8 * 8];
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(repet::g_fft_stamps), zeros, sizeof(zeros));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(repet::g_fft_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+}
+#endif

@@ -14,6 +14,7 @@
 // one ds_bpermute per component. Same arithmetic contract as stft.hip (repet.py:1001-1105, :158, :1220).
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace repet {
@@ -64,6 +65,15 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) dft4<INV>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);   // v[s + 4r] = X[r + 4s]
 }
+
+#ifdef REPET_FFT_STAMPS
+__device__ unsigned long long g_reg_stamps[8 * 8];         // [sampled wave][phase] summed cycles
+#define RSTAMP_DECL unsigned long long rst_prev = __builtin_amdgcn_s_memtime(); const bool rst_on = (threadIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x % 61) == 7 && blockIdx.x / 61 < 8 && threadIdx.x < 64;
+#define RSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (rst_on) g_reg_stamps[(blockIdx.x / 61) * 8 + (k)] += now_ - rst_prev; rst_prev = now_; }
+#else
+#define RSTAMP_DECL
+#define RSTAMP(k)
+#endif
 
 constexpr int kRegN = 1024;          // complex FFT length
 constexpr int kExPitch = 1280;       // float2 per wave: max(16 * 68, 16 * 80)
@@ -131,66 +141,154 @@ __device__ __forceinline__ float lane_fetch(float x, int src_lane) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void stft_reg_kernel(StftArgs a, int frames_per_wave) {
+// Twelve wavefronts per workgroup, ONE workgroup per CU (147 KB of LDS: twelve private exchange regions and the tables
+// every wave reads -- stage twiddles, window, split twiddles). A wave takes whole frames (every channel of frame u,
+// u = wave id + k x waves of the launch, frames of a batch numbered through): no workgroup barrier after the prologue,
+// twelve independent load -> FFT -> store chains per CU instead of three barrier-coupled ones.
+// Stereo clips arrive as [n][2] floats: samples 2n and 2n+1 of both channels are ONE float4 per lane, fetched once per
+// frame (the block kernels and the first version of this one read 4-byte elements 16 bytes apart).
+constexpr int kFwdWaves = 12;
+constexpr int kFwdLdsFloat2 = kFwdWaves * kExPitch + kTwFloat2 + 2 * kRegN;      // + window [N] + split twiddles [N]
+
+struct __attribute__((packed, aligned(4))) Float4A { float x, y, z, w; };         // any dword address (segment offsets)
+struct __attribute__((packed, aligned(4))) Float2A { float x, y; };
+
+template <int CMODE>      // 2: stereo float4 path, 1: mono float2 path, 0: any channel count, element loads
+__global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, int64_t units) {
     constexpr int N = kRegN, W = 2 * kRegN;
-    __shared__ float2 ex_all[4 * kExPitch];
-    __shared__ float2 tw_lds[kTwFloat2];
-    const int tid = threadIdx.x, lane_id = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float2 fwd_lds[];
+    float2* ex_all = fwd_lds;
+    float2* tw_lds = ex_all + kFwdWaves * kExPitch;
+    float2* win_lds = tw_lds + kTwFloat2;               // (window[2n], window[2n+1])
+    float2* split_lds = win_lds + N;                    // exp(-2 pi i k / W), k < N
+    const int tid = threadIdx.x, lane_id = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: frame numbers, rows and pointers stay in SGPRs
     float2* ex = ex_all + wave * kExPitch;
-    const int C = a.n_channels;
-    const int64_t b = blockIdx.y;
-    a.sample_offset += b * a.batch_sample_stride;
-    a.X += b * a.batch_spec_stride;
-    a.V += b * a.batch_spec_stride;
-    if (a.Vm) a.Vm += b * a.batch_mean_stride;
-    if (a.Vn) a.Vn += b * a.batch_mean_stride;
-    if (a.Vh) a.Vh = static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride;
-    if (a.P) a.P += b * a.batch_mean_stride;
+    const int C = CMODE ? CMODE : a.n_channels;
+    RSTAMP_DECL
 
-    const RegTwiddles tw = load_reg_twiddles<false>(tw_lds, a.twiddle, tid);
+    for (int i = tid; i < 16 * 64; i += 64 * kFwdWaves) {
+        const int k1 = i >> 6, l = i & 63;
+        tw_lds[i] = a.twiddle[2 * l * k1];                    // exp(-2 pi i l k1 / 1024)
+    }
+    if (tid < 64) tw_lds[16 * 64 + tid] = a.twiddle[32 * (tid >> 4) * (tid & 15)];    // exp(-2 pi i m2 j1 / 64)
+    for (int i = tid; i < N; i += 64 * kFwdWaves) {
+        win_lds[i] = *reinterpret_cast<const float2*>(a.window + 2 * i);
+        split_lds[i] = a.twiddle[i];
+    }
+    const RegTwiddles tw{tw_lds, tw_lds + 16 * 64};
     __syncthreads();
+    RSTAMP(0)
     const bool want_mean = a.Vm || a.Vn || a.P;
-    const int64_t t_first = ((int64_t)blockIdx.x * 4 + wave) * frames_per_wave;
+    // round k of the launch: workgroup b's twelve waves take the twelve CONSECUTIVE frames (k gridDim + b) 12 + wave, so
+    // the half frame two neighbours share is asked for by the same CU at about the same time
+    const int64_t stride = (int64_t)gridDim.x * kFwdWaves;
 
-    for (int64_t t = t_first; t < t_first + frames_per_wave && t < a.T; ++t) {
+    for (int64_t u = (int64_t)blockIdx.x * kFwdWaves + wave; u < units; u += stride) {
+        const int64_t b = a.n_batch > 1 ? (int64_t)((uint32_t)u / (uint32_t)a.T) : 0;     // launch_stft_reg: units < 2^31
+        const int64_t t = u - b * a.T;
         const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
         const int64_t row = t * a.FS;
+        float2* Xb = a.X + b * a.batch_spec_stride;
+        float* Vb = a.V + b * a.batch_spec_stride;
         float acc[17];
 #pragma unroll
         for (int s = 0; s < 17; ++s) acc[s] = 0.f;
+        // the lane number, made opaque once per frame: otherwise the compiler hoists the per-slot addresses out of the
+        // loops and spills them
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const int partner = (64 - lane) & 63;
+        const bool inside = start >= 0 && start + W <= a.n_samples;       // wave-uniform
+        // a frame over an edge of the clip: positions [lo, hi) of it exist (32-bit, relative to the frame's first sample;
+        // `frame` may point before the clip then and is only dereferenced at existing positions -- `safe` is one)
+        const float* frame = a.audio + (a.sample_offset + b * a.batch_sample_stride + start) * C;
+        const int lo = start < 0 ? (int)std::min<int64_t>(-start, W) : 0;
+        const int hi = (int)std::max<int64_t>(std::min<int64_t>(a.n_samples - start, W), 0);
+        const int safe = lo;
+        const bool none = lo >= hi;                                        // nothing of the frame exists (an empty clip): all zeros, no load
 
-        for (int c = 0; c < C; ++c) {
-            // the lane number, made opaque once per transform: otherwise the compiler hoists the ~50 per-slot
-            // addresses out of both loops and spills them
-            int lane = lane_id;
-            asm volatile("" : "+v"(lane));
-            const int partner = (64 - lane) & 63;
-            float2 v[16];
-            // may point before the clip for the leading frames: then only the guarded path dereferences it
-            const float* base = a.audio + ((a.sample_offset + start) * C + c);
-            if (start >= 0 && start + W <= a.n_samples) {          // wave-uniform: the frame lies inside the clip
+        // Measured and dropped: fetching the next transform's samples (two dwords per point and channel, 32 registers)
+        // while the current one is transformed -- cfg 2 / 3 / 5: 0.094 / 0.647 / 0.838 ms against 0.084 / 0.537 / 0.755
+        // with the plain float4 fetch below; the strided dword loads cost the memory pipeline more than the wait they hide.
+        float2 v[16];
+        float2 v1[CMODE == 2 ? 16 : 1];                // stereo: channel 1, windowed, parked while channel 0 is transformed
+        if constexpr (CMODE == 2) {
+            float4 raw4[16];
+            if (inside) {
+                const Float4A* src = reinterpret_cast<const Float4A*>(frame) + lane;
 #pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) {
-                    const int n = 64 * n1 + lane;
-                    const float x0 = base[2 * n * C], x1 = base[(2 * n + 1) * C];
-                    const float2 w = *reinterpret_cast<const float2*>(a.window + 2 * n);
-                    v[n1] = make_float2(x0 * w.x, x1 * w.y);
-                }
+                for (int n1 = 0; n1 < 16; ++n1) { const Float4A q = src[64 * n1]; raw4[n1] = make_float4(q.x, q.y, q.z, q.w); }
+            } else if (none) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) raw4[n1] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
-                    const int n = 64 * n1 + lane;
-                    const int64_t s0 = start + 2 * n, s1 = s0 + 1;
-                    const float x0 = (s0 >= 0 && s0 < a.n_samples) ? base[2 * n * C] : 0.f;
-                    const float x1 = (s1 >= 0 && s1 < a.n_samples) ? base[(2 * n + 1) * C] : 0.f;
-                    const float2 w = *reinterpret_cast<const float2*>(a.window + 2 * n);
-                    v[n1] = make_float2(x0 * w.x, x1 * w.y);
+                    const int p0 = 2 * (64 * n1 + lane), p1 = p0 + 1;
+                    const bool in0 = p0 >= lo && p0 < hi, in1 = p1 >= lo && p1 < hi;
+                    const Float2A q0 = *reinterpret_cast<const Float2A*>(frame + (in0 ? p0 : safe) * 2);
+                    const Float2A q1 = *reinterpret_cast<const Float2A*>(frame + (in1 ? p1 : safe) * 2);
+                    raw4[n1] = make_float4(in0 ? q0.x : 0.f, in0 ? q0.y : 0.f, in1 ? q1.x : 0.f, in1 ? q1.y : 0.f);
                 }
             }
-            wave_fft1024<false>(v, ex, tw, lane);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float2 w = win_lds[64 * n1 + lane];
+                v[n1] = make_float2(raw4[n1].x * w.x, raw4[n1].z * w.y);
+                v1[n1] = make_float2(raw4[n1].y * w.x, raw4[n1].w * w.y);
+            }
+        }
 
-            float2* Xrow = a.X + c * a.chan_stride + row;
-            float* Vrow = a.V + c * a.chan_stride + row;
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            if constexpr (CMODE == 2) {
+                if (c == 1) {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) v[n1] = v1[n1];
+                }
+            } else if constexpr (CMODE == 1) {
+                if (inside) {
+                    const Float2A* src = reinterpret_cast<const Float2A*>(frame) + lane;
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const Float2A q = src[64 * n1];
+                        const float2 w = win_lds[64 * n1 + lane];
+                        v[n1] = make_float2(q.x * w.x, q.y * w.y);
+                    }
+                } else if (none) {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(0.f, 0.f);
+                } else {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const int p0 = 2 * (64 * n1 + lane), p1 = p0 + 1;
+                        const bool in0 = p0 >= lo && p0 < hi, in1 = p1 >= lo && p1 < hi;
+                        const float q0 = frame[in0 ? p0 : safe], q1 = frame[in1 ? p1 : safe];
+                        const float2 w = win_lds[64 * n1 + lane];
+                        v[n1] = make_float2(in0 ? q0 * w.x : 0.f, in1 ? q1 * w.y : 0.f);
+                    }
+                }
+            } else {
+                int lane = lane_id;                    // opaque per channel: see above
+                asm volatile("" : "+v"(lane));
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const int p0 = 2 * (64 * n1 + lane), p1 = p0 + 1;
+                    const bool in0 = !none && p0 >= lo && p0 < hi, in1 = !none && p1 >= lo && p1 < hi;
+                    const float q0 = none ? 0.f : frame[(in0 ? p0 : safe) * C + c], q1 = none ? 0.f : frame[(in1 ? p1 : safe) * C + c];
+                    const float2 w = win_lds[64 * n1 + lane];
+                    v[n1] = make_float2(in0 ? q0 * w.x : 0.f, in1 ? q1 * w.y : 0.f);
+                }
+            }
+            RSTAMP(1)                                  // samples fetched, windowed
+            __builtin_amdgcn_sched_barrier(0);
+            wave_fft1024<false>(v, ex, tw, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            RSTAMP(2)                                  // FFT
+
+            float2* Xrow = Xb + c * a.chan_stride + row;
+            float* Vrow = Vb + c * a.chan_stride + row;
             // Hermitian split: X[k] = E + W_2048^k O with E = (Z[k] + conj Z[N-k]) / 2, O = (Z[k] - conj Z[N-k]) / 2i.
             // Z[N-k] for k = lane + 64 s is slot 15 - s of lane 64 - lane (lane 0: its own slot (16 - s) & 15).
 #pragma unroll
@@ -204,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
                 const float2 d = csub(zk, zc);
                 const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
-                const float2 x = cadd(e, cmul(a.twiddle[k], o));
+                const float2 x = cadd(e, cmul(split_lds[k], o));
                 const float mag = sqrtf(x.x * x.x + x.y * x.y);
                 Xrow[k] = x;
                 Vrow[k] = mag;
@@ -222,10 +320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 Xrow[N + 1 + lane] = make_float2(0.f, 0.f);
                 Vrow[N + 1 + lane] = 0.f;
             }
+            RSTAMP(3)                                  // split + X / V stores issued
         }
         if (!want_mean) continue;
-        int lane = lane_id;
-        asm volatile("" : "+v"(lane));
 
         // channel mean (repet.py:162,:667) and its L2 norm over frequency (repet.py:1220), all inside the wave
         const float inv_c = 1.0f / (float)C;
@@ -238,26 +335,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
         const float norm = sqrtf(ss);        // 0 for a silent frame: 0/0 = NaN like repet.py:1220
+        const int64_t mrow = b * a.batch_mean_stride + row;
+        float* Vm = a.Vm ? a.Vm + mrow : nullptr;
+        float* Vn = a.Vn ? a.Vn + mrow : nullptr;
+        float* P = a.P ? a.P + mrow : nullptr;
+        void* Vh = a.Vh ? static_cast<void*>(static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride) : nullptr;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k = lane + 64 * s;
-            if (a.Vm) a.Vm[row + k] = acc[s];
-            if (a.Vn) a.Vn[row + k] = acc[s] / norm;
-            if (a.Vh) store_split_f16(a.Vh, row + k, acc[s] / norm);
-            if (a.P) a.P[row + k] = acc[s] * acc[s];
+            if (Vm) Vm[k] = acc[s];
+            if (Vn) Vn[k] = acc[s] / norm;
+            if (Vh) store_split_f16(Vh, row + k, acc[s] / norm);
+            if (P) P[k] = acc[s] * acc[s];
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (lane == 0) {
-            if (a.Vm) a.Vm[row + N] = acc[16];
-            if (a.Vn) a.Vn[row + N] = acc[16] / norm;
-            if (a.Vh) store_split_f16(a.Vh, row + N, acc[16] / norm);
-            if (a.P) a.P[row + N] = acc[16] * acc[16];
+            if (Vm) Vm[N] = acc[16];
+            if (Vn) Vn[N] = acc[16] / norm;
+            if (Vh) store_split_f16(Vh, row + N, acc[16] / norm);
+            if (P) P[N] = acc[16] * acc[16];
         }
         if (lane < a.FS - (N + 1)) {
-            if (a.Vm) a.Vm[row + N + 1 + lane] = 0.f;
-            if (a.Vn) a.Vn[row + N + 1 + lane] = 0.f;
-            if (a.Vh) store_split_f16(a.Vh, row + N + 1 + lane, 0.f);
-            if (a.P) a.P[row + N + 1 + lane] = 0.f;
+            if (Vm) Vm[N + 1 + lane] = 0.f;
+            if (Vn) Vn[N + 1 + lane] = 0.f;
+            if (Vh) store_split_f16(Vh, row + N + 1 + lane, 0.f);
+            if (P) P[N + 1 + lane] = 0.f;
         }
+        RSTAMP(4)                                      // mean rows
     }
 }
 
@@ -351,13 +455,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }  // namespace
 
 bool reg_fft_supported(int W, int n_channels, bool inverse) {
-    static const int mode = [] {            // REPET_FFT_PATH=reg selects these kernels (default: the block Stockham ones)
+    // forward: the wave kernel is the default for mono and stereo clips (cfg 2 / 3 / 4 / 5: 0.095 / 0.62 / 0.099 / 0.795 ms
+    // with the block kernels -> 0.084 / 0.54 / 0.074 / 0.755); inverse: the block kernel stays the default.
+    // REPET_FFT_PATH=block | wave: the LDS Stockham kernels of stft.hip for everything; =reg: both kernels of this file,
+    // any channel count they take; =fwd: the forward one only.
+    static const int mode = [] {
         const char* e = getenv("REPET_FFT_PATH");
-        return (e && e[0] == 'r') ? 1 : 0;
+        if (!e || !e[0]) return 4;
+        return e[0] == 'r' ? 3 : e[0] == 'f' ? 1 : 0;
     }();
-    if (!mode || W != 2 * kRegN) return false;
-    if (inverse) return n_channels == 1 || n_channels == 2 || n_channels == 4;
-    return n_channels >= 1;
+    if (W != 2 * kRegN) return false;
+    if (inverse) return (mode & 2) && (n_channels == 1 || n_channels == 2 || n_channels == 4);
+    if (mode & 4) return n_channels == 1 || n_channels == 2;
+    return (mode & 1) && n_channels >= 1;
 }
 
 // Both kernels keep 3 workgroups (12 wavefronts) per CU; the work per wave / per workgroup is sized so that the
@@ -366,10 +476,22 @@ constexpr int64_t kRegSlots = 256 * 3;
 
 hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s) {
     const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
-    int64_t fpw = ceil_div(a.T * batches, 4 * kRegSlots);
-    fpw = fpw < 1 ? 1 : (fpw > 16 ? 16 : fpw);
-    const unsigned blocks = (unsigned)ceil_div(a.T, 4 * fpw);
-    hipLaunchKernelGGL(stft_reg_kernel, dim3(blocks, (unsigned)batches), dim3(256), 0, s, a, (int)fpw);
+    const int64_t units = a.T * batches;
+    if (units >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop{};
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(units, kFwdWaves), cus);
+    const size_t dyn = (size_t)kFwdLdsFloat2 * sizeof(float2);
+    auto go = [&](auto kernel) {
+        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)dyn);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * kFwdWaves), dyn, s, a, units);
+    };
+    if (a.n_channels == 2) go(&stft_reg_kernel<2>);
+    else if (a.n_channels == 1) go(&stft_reg_kernel<1>);
+    else go(&stft_reg_kernel<0>);
     return hipGetLastError();
 }
 
@@ -386,3 +508,13 @@ hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t
 }
 
 }  // namespace repet
+
+#ifdef REPET_FFT_STAMPS
+extern "C" int repet_debug_reg_stamps(unsigned long long* out, int clear) {
+    if (clear) {
+        static unsigned long long zeros[64];
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(repet::g_reg_stamps), zeros, sizeof(zeros));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(repet::g_reg_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
