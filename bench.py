@@ -214,7 +214,7 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)                   # stage figures are per clip
         T, F, C = int(ctx.last_frame_count()), params.window_length // 2 + 1, channels
-        rank_path = "rank_columns" in stage_ms
+        rank_path = any("rank_columns" in name for name in stage_ms)
         sim_like = args.algo in ("sim", "simonline")
         k_mean = net_size = net_instr = None
         if sim_like:
@@ -267,6 +267,10 @@ def main():
                               "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic": meta["bytes"]})
                 if name == "rank_columns":
                     entry["note"] = "three kernels (transpose, per-column sort + rank search in LDS, transpose back); the sort is LDS/VALU-bound"
+                if name == "peaks+rank_columns":
+                    entry["note"] = ("two independent launches side by side on two streams: peak picking (one wavefront per row of S, instruction- and "
+                                     "latency-bound) and the column sort of V (transpose, per-column sort + rank search in LDS, transpose back); "
+                                     "bytes = S read once + the sort's passes, time = both (REPET_RANK_OVERLAP=0 lists them apart)")
             stages.append(entry)
         dom = max(stages, key=lambda s: s["ms"])
         roof = {"kernel": dom["name"]}

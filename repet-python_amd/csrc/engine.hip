@@ -715,7 +715,7 @@ bool rank_median_enabled() {
 constexpr int kRankMinList = 24;     // shortest list bound for which the column sort is worth its time
 
 // Sort every column of V and fill m's rank fields (bins [0, F-1); the lone Nyquist bin stays on the float kernel).
-int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m) {
+int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark) {
     const int n_cols = g.F - 1;
     const int64_t vs_pitch = round_up(g.T, 32);
     HIP_TRY(c->R.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned short)));
@@ -723,17 +723,17 @@ int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m) {
     HIP_TRY(c->rank_codes.ensure((size_t)g.C * n_cols * vs_pitch * sizeof(unsigned short)));
     if (c->r_pads_ptr != c->R.p || c->r_pads_stride != g.chan_stride || c->r_pads_row != g.Tpad || c->r_pads_channels != g.C ||
         c->r_pads_fs != g.FS) {
-        HIP_TRY(launch_fill_rank_pad_rows(c->R.as<unsigned short>(), g.chan_stride, g.C, g.Tpad, g.FS, c->stream));
+        HIP_TRY(launch_fill_rank_pad_rows(c->R.as<unsigned short>(), g.chan_stride, g.C, g.Tpad, g.FS, stream));
         c->r_pads_ptr = c->R.p; c->r_pads_stride = g.chan_stride; c->r_pads_row = g.Tpad; c->r_pads_channels = g.C; c->r_pads_fs = g.FS;
     }
     RankArgs a{};
     a.V = c->V.as<float>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.n_cols = n_cols;
     a.R = c->R.as<unsigned short>(); a.r_chan_stride = g.chan_stride; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
     a.codes = c->rank_codes.as<unsigned short>();
-    HIP_TRY(launch_rank_columns(a, c->stream));
+    HIP_TRY(launch_rank_columns(a, stream));
     m->R = a.R; m->r_chan_stride = a.r_chan_stride; m->Vs = a.Vs; m->vs_pitch = vs_pitch; m->n_rank_cols = n_cols;
     // V read, columns written / read twice / written sorted, codes written column-major, read, written frame-major
-    mark(c, "rank_columns", (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * n_cols * (double)g.T * g.C, 0);
+    if (with_mark) mark(c, "rank_columns", (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * n_cols * (double)g.T * g.C, 0);
     return REPET_OK;
 }
 
@@ -768,6 +768,21 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     PeakRefine rf{};
     RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf));
     if (n_chunks <= 1) {
+        MaskArgs m = mask_args(c, g, p->cutoff_bins);
+        const bool use_rank = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
+                              max_peaks >= kRankMinList && max_peaks <= 128;
+        // The column sort needs nothing of the similarity matrix: it runs on the side stream BESIDE the peak picking, whose
+        // rows take 30 .. 140 us each -- the second half of that launch is a tail of fewer and fewer waves (spans of every
+        // row: tools/peak_stamps.py), which the sort's workgroups fill. (Beside the Gram kernel it does not pay: a sort
+        // workgroup on a CU keeps the Gram's 139 KB workgroup off it.) REPET_RANK_OVERLAP=0: one after the other.
+        static const bool rank_overlap = [] { const char* e = getenv("REPET_RANK_OVERLAP"); return !(e && e[0] == '0'); }();
+        const bool beside = use_rank && rank_overlap;
+        if (beside) {
+            HIP_TRY(hipEventRecord(c->fork_event, c->stream));          // V is complete (so is S)
+            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
+            RP_TRY(run_rank_columns(c, g, &m, c->side_stream, false));
+            HIP_TRY(hipEventRecord(c->join_event, c->side_stream));
+        }
         const size_t scratch = local_maxima_scratch_bytes(T, (int)T, p->sim_distance_frames);
         if (scratch > 0) HIP_TRY(c->peak_scratch.ensure(scratch));
         hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
@@ -775,11 +790,14 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
                                            nullptr, scratch > 0 ? c->peak_scratch.p : nullptr);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
-        mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
-        MaskArgs m = mask_args(c, g, p->cutoff_bins);
-        const bool use_rank = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
-                              max_peaks >= kRankMinList && max_peaks <= 128;
-        if (use_rank) RP_TRY(run_rank_columns(c, g, &m));
+        if (beside) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->join_event, 0));
+            // one figure for the two concurrent launches: their bytes added up (S read once + the sort's passes over V)
+            mark(c, "peaks+rank_columns", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * (g.F - 1) * (double)g.T * g.C, 0);
+        } else {
+            mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
+            if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true));
+        }
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
                                 c->fork_event, c->join_event));
         mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);

@@ -12,7 +12,10 @@
 // SIMD. The staging itself goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write);
 // the XOR-swizzled LDS image of gram_f16.hip is kept by permuting the per-lane SOURCE addresses (the LDS side of an
 // LDS-DMA is lane-linear). Two LDS buffers, one barrier per K-tile: the DMA of tile k+1 flies during the 3 072-cycle
-// compute of tile k. Upper-triangle tiles only, mirrored through per-wave LDS patches; diagonal tiles store the values
+// compute of tile k (moving that barrier to the middle of the K-tile, with the next tile's first fragments fetched behind it
+// while the second half is multiplied, was measured and is slower: K loop 141 k -> 155 k cycles -- the loop is held by
+// the LDS, 192 KB of fragment reads + 64 KB of DMA per 3 072 MFMA cycles, not by the wait after the barrier).
+// Upper-triangle tiles only, mirrored through per-wave LDS patches; diagonal tiles store the values
 // computed for i <= j on both sides, so S is exactly symmetric.
 #include "common.h"
 

@@ -19,6 +19,41 @@ struct PeakArgs {
 constexpr int kAmbCap = 96;    // near-tied elements refined per row; a row with more keeps its fp32 decisions
 constexpr int kRivalCap = 96;  // (near-tied element, rival) pairs per row, same fallback
 
+// Sum of a double over the wave, the same value in every lane, without the LDS: four DPP steps inside the rows of 16
+// lanes, then gfx950's v_permlane16_swap / v_permlane32_swap across them. (Five quantities reduced by __shfl_xor were
+// 60 ds_bpermute round trips per pair of similarities -- the refinement of a row with forty near-ties took 100 us.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_mov_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);      // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);      // row_mirror: every lane of a row holds the row's sum
+    {
+        const long long b = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);     // {rows 0 0 2 2, rows 1 1 3 3}
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __builtin_bit_cast(double, ((long long)(unsigned)h[0] << 32) | (unsigned)l[0]) +
+            __builtin_bit_cast(double, ((long long)(unsigned)h[1] << 32) | (unsigned)l[1]);
+    }
+    {
+        const long long b = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);     // {low half twice, high half twice}
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __builtin_bit_cast(double, ((long long)(unsigned)h[0] << 32) | (unsigned)l[0]) +
+            __builtin_bit_cast(double, ((long long)(unsigned)h[1] << 32) | (unsigned)l[1]);
+    }
+    return v;
+}
+
 // float64 cosine similarity of two fp32 rows (one wave, result in every lane). The rows are unit vectors up
 // to fp32 rounding, so their float64 norms are divided out again: the value then depends on the fp32
 // spectra alone, not on how the fp32 Gram kernel accumulated them.
@@ -50,16 +85,86 @@ __device__ __forceinline__ void exact_similarity2(const float* __restrict__ x, c
             yy1 += live * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        xx += __shfl_xor(xx, o);
-        xy0 += __shfl_xor(xy0, o);
-        yy0 += __shfl_xor(yy0, o);
-        xy1 += __shfl_xor(xy1, o);
-        yy1 += __shfl_xor(yy1, o);
-    }
+    xx = wave_sum_f64(xx);
+    xy0 = wave_sum_f64(xy0);
+    yy0 = wave_sum_f64(yy0);
+    xy1 = wave_sum_f64(xy1);
+    yy1 = wave_sum_f64(yy1);
     *e0 = xy0 / sqrt(xx * yy0);
     *e1 = xy1 / sqrt(xx * yy1);
+}
+
+// The same similarities for a LIST of rows against one row x (rows of up to 1 280 bins: x stays in registers, the next
+// item's row is fetched while the current one is reduced). Values equal exact_similarity2's bit for bit: same per-lane
+// sums in the same order, same wave reduction. row_of(i) gives item i's row, store(i, e) takes its similarity (every lane
+// calls it with the same e).
+template <class RowOf, class Store>
+__device__ __forceinline__ void exact_similarity_list(const float* __restrict__ x, int len4, int lane, int n_items, RowOf row_of, Store store) {
+    if (len4 > 320) {                                   // longer rows: pairwise, re-reading x
+        for (int it = 0; it < n_items; it += 2) {
+            const bool two = it + 1 < n_items;
+            double e0, e1;
+            exact_similarity2(x, row_of(it), row_of(two ? it + 1 : it), len4, lane, &e0, &e1);
+            store(it, e0);
+            if (two) store(it + 1, e1);
+        }
+        return;
+    }
+    // lanes past the row end read a clamped index and are zeroed (x * 0 and y * 0 are what exact_similarity2 adds there)
+    auto fetch_row = [&](const float* row, float4 (&dst)[5]) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) dst[u] = r4[min(64 * u + lane, len4 - 1)];
+    };
+    auto zero_tail = [&](float4 (&v)[5]) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            if (64 * u + lane >= len4) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // The item rows sit in the Infinity Cache or HBM (a different row of the unit spectra each): one dword per 128-byte
+    // line of eight rows at a time pulls them into this XCD's L2 behind ONE round trip, so the row fetches below hit L2
+    // instead of costing a far round trip per item (3 000 cycles each, the whole of the slow rows' refinement time).
+    {
+        float sink = 0.f;
+        const int at = min(32 * lane, 4 * len4 - 1);
+        for (int it0 = 0; it0 < n_items; it0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) t[b] = row_of(min(it0 + b, n_items - 1))[at];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sink += t[b];
+        }
+        asm volatile("" ::"v"(sink));
+    }
+    float4 p[5], q[5];
+    fetch_row(x, p);
+    if (n_items > 0) fetch_row(row_of(0), q);
+    zero_tail(p);
+    double xx = 0.0;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const double p0 = p[u].x, p1 = p[u].y, p2 = p[u].z, p3 = p[u].w;
+        xx += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+    }
+    xx = wave_sum_f64(xx);
+    for (int it = 0; it < n_items; ++it) {
+        float4 r[5];
+        fetch_row(row_of(it + 1 < n_items ? it + 1 : it), r);      // in flight during the sums below
+        zero_tail(q);
+        double xy = 0.0, yy = 0.0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const double p0 = p[u].x, p1 = p[u].y, p2 = p[u].z, p3 = p[u].w;
+            const double q0 = q[u].x, q1 = q[u].y, q2 = q[u].z, q3 = q[u].w;
+            xy += p0 * q0 + p1 * q1 + p2 * q2 + p3 * q3;
+            yy += q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+        }
+        xy = wave_sum_f64(xy);
+        yy = wave_sum_f64(yy);
+        store(it, xy / sqrt(xx * yy));
+#pragma unroll
+        for (int u = 0; u < 5; ++u) q[u] = r[u];
+    }
 }
 
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {

@@ -22,11 +22,23 @@
 
 namespace repet {
 
-#ifdef REPET_PEAK_STAMPS
+// Diagnostics (make stamps, tools/peak_stamps.py). REPET_PEAK_SPANS: (start, end) of every row's wave on the chip-wide 100 MHz
+// clock -- two scalar reads and one store per row, the same registers as the shipped kernel. REPET_PEAK_STAMPS: cycles per
+// phase of a few rows (costs registers: the stamped kernel holds three waves per SIMD where the shipped one holds four).
+#if defined(REPET_PEAK_STAMPS) || defined(REPET_PEAK_SPANS)
 __device__ unsigned long long g_wave_stamps[8 * 8];
+__device__ unsigned long long g_wave_span[2 * 16384];
+__device__ unsigned int g_wave_phase[10 * 16384];           // REPET_PEAK_STAMPS: cycles per phase of EVERY row
+#endif
+#ifdef REPET_PEAK_STAMPS
 #define WSTAMP_DECL unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #define WSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] += now_ - last_; last_ = now_; }
-#define WSTAMP_OUT if (lane == 0 && (r % 997) == 5 && r / 997 < 8) { for (int k_ = 0; k_ < 8; ++k_) g_wave_stamps[(r / 997) * 8 + k_] = acc_[k_]; }
+#define WSTAMP_OUT if (lane == 0 && (r % 997) == 5 && r / 997 < 8) { for (int k_ = 0; k_ < 8; ++k_) g_wave_stamps[(r / 997) * 8 + k_] = acc_[k_]; } \
+    if (lane == 0 && r < 16384) { for (int k_ = 0; k_ < 8; ++k_) g_wave_phase[10 * r + k_] = (unsigned)acc_[k_]; g_wave_phase[10 * r + 8] = (unsigned)n_amb; g_wave_phase[10 * r + 9] = (unsigned)n_peak; }
+#elif defined(REPET_PEAK_SPANS)
+#define WSTAMP_DECL const unsigned long long span0_ = __builtin_amdgcn_s_memrealtime();
+#define WSTAMP(k)
+#define WSTAMP_OUT if (lane == 0 && r < 16384) { g_wave_span[2 * r] = span0_; g_wave_span[2 * r + 1] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define WSTAMP_DECL
 #define WSTAMP(k)
@@ -111,10 +123,12 @@ __device__ __forceinline__ void wave_sync() {
 
 // RD = d & 3: the two window reads at run-time offsets (-d and d-w+1) then have compile-time float4 remainders
 template <int RD>
-__global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int64_t n_rows, int lds_per_wave) {
+// One wavefront per WORKGROUP: rows take 30 .. 140 us (the refinement of near-ties varies), and a workgroup's LDS and
+// registers are only handed back when its last wave is done (s_memrealtime spans of every row: tools/peak_stamps.py).
+__global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64_t n_rows, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wave_smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;        // row within this launch
+    const int lane = threadIdx.x & 63, wave = 0;
+    const int64_t r = (int64_t)blockIdx.x;                   // row within this launch
     if (r >= n_rows) return;
     const WaveLds L = carve(wave_smem + (size_t)wave * lds_per_wave, a.peak_cap);
     const int n = a.n, d = a.d;
@@ -131,6 +145,14 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
         int l = (int)(j - i) % n;                            // circular-buffer order of the online variant
         if (l < 0) l += n;
         return nan_to_inf(a.M[(j - l - a.shift) * a.pitch + l]);
+    };
+    // the same for an index known to lie in [0, n), without a branch: loads of a batch must not each sit behind their own
+    // control-flow join (the value is needed AT the join, so every load was waited for before the next was issued)
+    auto fetch_inside = [&](int i) -> float {
+        int l = (int)(j - i) % n;
+        l += l < 0 ? n : 0;
+        const int64_t at = a.mode == 0 ? j * a.pitch + i : (j - l - a.shift) * a.pitch + l;
+        return a.M[at];
     };
     auto elem_row = [&](int i) -> const float* {             // unit row of the frame behind element i
         int64_t fr = i;
@@ -349,33 +371,60 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
                 // "no"). The row is read again where it lies (it went through this CU's caches a moment ago).
                 const int n_near = n_amb;
                 for (int k = lane; k < n_near; k += 64) L.amb_lose[k] = 0;
-                for (int s = 0; s < n_near && n_riv <= kRivalCap; ++s) {
-                    const int i = L.amb_idx[s];
-                    const float lim = L.amb_val[s] - dlt;
-                    for (int k0 = i - d; k0 <= i + d; k0 += 64) {
-                        const int k = k0 + lane;
-                        const bool rival = k != i && k <= i + d && k >= 0 && k < n && fetch(k) >= lim;
+                // All (near-tied element, window position) pairs are walked lane-parallel, 256 at a time with their
+                // loads in flight together: one near-tie after the other, each behind its own global round trip, was
+                // 7 000 cycles per near-tie and the whole of the slow rows' time. Entries come out in the same order
+                // (element, then position).
+                const int win = 2 * d + 1, total = n_near * win;
+                const float inv_win = 1.0f / (float)win;
+                for (int e0 = 0; e0 < total && n_riv <= kRivalCap; e0 += 256) {
+                    float val[4], lim[4];
+                    int pos[4], own[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int e = e0 + 64 * b + lane;
+                        const int ec = e < total ? e : 0;
+                        const int s_ = (int)(((float)ec + 0.5f) * inv_win);         // ec / win: ec < 2^14, never near a boundary
+                        const int i = L.amb_idx[s_];
+                        const int k = i - d + (ec - s_ * win);
+                        own[b] = s_; pos[b] = (e < total && k != i && k >= 0 && k < n) ? k : -1;
+                        lim[b] = L.amb_val[s_] - dlt;
+                        val[b] = fetch_inside(pos[b] >= 0 ? pos[b] : i);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) val[b] = nan_to_inf(val[b]);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int k = pos[b];
+                        const bool rival = k >= 0 && val[b] >= lim[b];
                         if (__any(rival)) {
-                            int next, next_u;
+                            int next;
                             const int entry = ballot_slot(rival, n_riv, lane, &next);
-                            int ref = -1;
-                            const bool stored = rival && entry < kRivalCap;
-                            if (stored) {
-                                for (int t = 0; t < n_near; ++t) if (L.amb_idx[t] == k) ref = t;
-                                L.riv_owner[entry] = (short)s; L.riv_ref[entry] = (short)ref; L.riv_idx[entry] = k;
-                            }
-                            // a rival that is not a near-tied element itself gets a float64 value of its own
-                            const bool unlisted = stored && ref < 0;
-                            const int us = ballot_slot(unlisted, n_unl, lane, &next_u);
-                            if (unlisted) L.unl_list[us] = (short)entry;
-                            n_unl = next_u;
+                            if (rival && entry < kRivalCap) { L.riv_owner[entry] = (short)own[b]; L.riv_idx[entry] = k; }
                             n_riv = next;
                         }
                     }
                 }
+                wave_sync();
+                // which rivals are near-tied elements themselves (they have a float64 value already), which get one of
+                // their own: one pass over the entries, the near-tie list read as LDS broadcasts
+                const int n_kept = n_riv < kRivalCap ? n_riv : kRivalCap;
+                for (int e0 = 0; e0 < n_kept; e0 += 64) {
+                    const int e = e0 + lane;
+                    const int k = e < n_kept ? L.riv_idx[e] : -1;
+                    int ref = -1;
+                    for (int t = 0; t < n_near; ++t) if (L.amb_idx[t] == k) ref = t;
+                    if (e < n_kept) L.riv_ref[e] = (short)ref;
+                    int next_u;
+                    const bool unlisted = e < n_kept && ref < 0;
+                    const int us = ballot_slot(unlisted, n_unl, lane, &next_u);
+                    if (unlisted) L.unl_list[us] = (short)e;
+                    n_unl = next_u;
+                }
                 if (n_riv > kRivalCap) redo = true;
             }
         }
+        WSTAMP(6)                                             // rivals of the near-tied elements
         if (!redo) break;
         if (a.stats && lane == 0) atomicAdd(&a.stats[3], 1u);      // redo the test with the plain fp32 decisions
         dlt = 0.0f;
@@ -390,16 +439,13 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
         auto item_row = [&](int it) -> const float* {
             return elem_row(it < n_near ? L.amb_idx[it] : L.riv_idx[L.unl_list[it - n_near]]);
         };
-        for (int it = 0; it < n_items; it += 2) {
-            const bool two = it + 1 < n_items;
-            double e0, e1;
-            exact_similarity2(self_row, item_row(it), item_row(two ? it + 1 : it), len4, lane, &e0, &e1);
+        exact_similarity_list(self_row, len4, lane, n_items, item_row, [&](int it, double e) {
             if (lane == 0) {
-                if (it < n_near) L.amb_exact[it] = e0; else L.riv_exact[L.unl_list[it - n_near]] = e0;
-                if (two) { if (it + 1 < n_near) L.amb_exact[it + 1] = e1; else L.riv_exact[L.unl_list[it + 1 - n_near]] = e1; }
+                if (it < n_near) L.amb_exact[it] = e; else L.riv_exact[L.unl_list[it - n_near]] = e;
             }
-        }
+        });
         wave_sync();
+        WSTAMP(7)                                             // float64 similarities
         for (int e = lane; e < n_rival; e += 64) {
             const int s = L.riv_owner[e], ref = L.riv_ref[e];
             const double er = ref >= 0 ? L.amb_exact[ref] : L.riv_exact[e];
@@ -438,21 +484,33 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
     const float4* pv4 = reinterpret_cast<const float4*>(L.pval);
     const bool cut_check = dlt > 0.0f && np_ > a.number;
     int* prank = reinterpret_cast<int*>(L.buf);               // the window maxima are no longer needed (cap <= 640 ints fit)
-    for (int p = lane; p < np_; p += 64) {
-        const float v = L.pval[p];
-        const int i = L.pidx[p];
-        int rank = 0;
+    // Two candidates per lane and pass over the list; equal VALUES are only counted here -- every candidate meets itself
+    // in the list, so a tie branch inside the loop was taken by some lane in nearly every iteration (26 000 of a row's
+    // 125 000 cycles). A candidate with a real tie (count > 1: rare) settles it by index afterwards.
+    for (int pb = 0; pb < np_; pb += 128) {
+        const int pa = pb + lane, pc = pb + 64 + lane;
+        const bool has_a = pa < np_, has_c = pc < np_;
+        const float va = has_a ? L.pval[pa] : INFINITY, vc = has_c ? L.pval[pc] : INFINITY;
+        int gt_a = 0, eq_a = 0, gt_c = 0, eq_c = 0;
 #pragma unroll 4
         for (int q4 = 0; 4 * q4 < np_; ++q4) {
             const float4 u = pv4[q4];
-            rank += (u.x > v) + (u.y > v) + (u.z > v) + (u.w > v);
-            if (u.x == v || u.y == v || u.z == v || u.w == v) {     // exact ties: rare
-                rank += (u.x == v && L.pidx[4 * q4] > i) + (u.y == v && L.pidx[4 * q4 + 1] > i) +
-                        (u.z == v && L.pidx[4 * q4 + 2] > i) + (u.w == v && L.pidx[4 * q4 + 3] > i);
-            }
+            gt_a += (u.x > va) + (u.y > va) + (u.z > va) + (u.w > va);
+            eq_a += (u.x == va) + (u.y == va) + (u.z == va) + (u.w == va);
+            gt_c += (u.x > vc) + (u.y > vc) + (u.z > vc) + (u.w > vc);
+            eq_c += (u.x == vc) + (u.y == vc) + (u.z == vc) + (u.w == vc);
         }
-        if (rank < a.number) out[rank] = out_index(i);
-        if (cut_check) prank[p] = rank;
+        auto settle = [&](bool has, int p, float v, int gt, int eq) {
+            if (!has) return;
+            const int i = L.pidx[p];
+            int rank = gt;
+            if (eq > 1)                                       // higher index first on ties
+                for (int q = 0; q < np_; ++q) rank += (L.pval[q] == v && L.pidx[q] > i);
+            if (rank < a.number) out[rank] = out_index(i);
+            if (cut_check) prank[p] = rank;
+        };
+        settle(has_a, pa, va, gt_a, eq_a);
+        settle(has_c, pc, vc, gt_c, eq_c);
     }
     if (cut_check) {
         // Top-`number` cut with more candidates than slots (see peaks.hip): candidates within delta of the boundary
@@ -481,12 +539,8 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
             if (n_band <= kAmbCap) {
                 const int len4 = a.unit_pitch >> 2;
                 const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
-                for (int it = 0; it < n_band; it += 2) {
-                    const bool two = it + 1 < n_band;
-                    double e0, e1;
-                    exact_similarity2(self_row, elem_row(L.amb_idx[it]), elem_row(L.amb_idx[two ? it + 1 : it]), len4, lane, &e0, &e1);
-                    if (lane == 0) { L.amb_exact[it] = e0; if (two) L.amb_exact[it + 1] = e1; }
-                }
+                exact_similarity_list(self_row, len4, lane, n_band, [&](int it) { return elem_row(L.amb_idx[it]); },
+                                      [&](int it, double e) { if (lane == 0) L.amb_exact[it] = e; });
                 wave_sync();
                 int changed = 0;
                 for (int k = lane; k < n_band; k += 64) {
@@ -511,9 +565,15 @@ __global__ __launch_bounds__(256) void local_maxima_wave_kernel(PeakArgs a, int6
     WSTAMP_OUT
 }
 
-#ifdef REPET_PEAK_STAMPS
+#if defined(REPET_PEAK_STAMPS) || defined(REPET_PEAK_SPANS)
 extern "C" int repet_debug_wave_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 64);
+}
+extern "C" int repet_debug_wave_phases(unsigned int* out, int rows) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_phase), sizeof(unsigned int) * 10 * rows);
+}
+extern "C" int repet_debug_wave_spans(unsigned long long* out, int rows) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_span), sizeof(unsigned long long) * 2 * rows);
 }
 #endif
 
@@ -521,7 +581,7 @@ template <int RD>
 static hipError_t launch_wave_rd(const PeakArgs& a, int64_t n_rows, int n_batch, int bytes, int per_wave, hipStream_t s) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_wave_kernel<RD>), bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(local_maxima_wave_kernel<RD>, dim3((unsigned)ceil_div(n_rows, 4), (unsigned)n_batch), dim3(256), bytes, s, a, n_rows, per_wave);
+    hipLaunchKernelGGL(local_maxima_wave_kernel<RD>, dim3((unsigned)n_rows, (unsigned)n_batch), dim3(64), bytes, s, a, n_rows, per_wave);
     return hipGetLastError();
 }
 
@@ -536,7 +596,7 @@ hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_ba
     if (cap > kMaxWaveCap) return hipErrorNotSupported;
     a.peak_cap = cap;
     const int per_wave = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
-    const int bytes = 4 * per_wave;
+    const int bytes = per_wave;
     switch (a.d & 3) {
         case 0: return launch_wave_rd<0>(a, n_rows, n_batch, bytes, per_wave, s);
         case 1: return launch_wave_rd<1>(a, n_rows, n_batch, bytes, per_wave, s);

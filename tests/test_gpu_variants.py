@@ -143,7 +143,8 @@ def test_integer_intermediates_through_the_context():
 
     timing = ctx.execute("sim", p, timing=True)
     names = [s["name"] for s in timing["stages"]]
-    assert [n.replace("_f16x3", "") for n in names if n != "rank_columns"] in (
+    # (the column sort of the rank-domain median runs beside the peak picking: one stage entry for the two)
+    assert [n.replace("_f16x3", "").replace("peaks+rank_columns", "local_maxima") for n in names if n != "rank_columns"] in (
         ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"], ["stft", "similarity_gemm", "peaks+mask", "istft_ola"])
     assert timing["total_ms"] > 0
     ctx.close()
@@ -496,7 +497,7 @@ def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance)
         with np.load(out) as z:
             outs.append({k: z[k] for k in z.files})
         os.remove(out)
-    assert "rank_columns" in outs[0]["stages"].tolist() and "rank_columns" not in outs[1]["stages"].tolist()
+    assert any("rank_columns" in n for n in outs[0]["stages"].tolist()) and not any("rank_columns" in n for n in outs[1]["stages"].tolist())
     assert np.array_equal(outs[0]["y"], outs[1]["y"])
 
 
