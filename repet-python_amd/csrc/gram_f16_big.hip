@@ -30,9 +30,12 @@ typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
 #ifdef REPET_GRAM_STAMPS
 __device__ unsigned long long g_gram_stamps[4 * 8];
+__device__ unsigned long long g_gram_span[2 * 4096];        // (start, end) of every workgroup, s_memrealtime (100 MHz, chip-wide)
+#define GSPAN(k) if (tid == 0 && blockIdx.x < 4096) g_gram_span[2 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime();
 #define GSTAMP(k) if (tid == 0 && (blockIdx.x % 61) == 7 && blockIdx.x / 61 < 8) g_gram_stamps[(blockIdx.x / 61) * 4 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define GSTAMP(k)
+#define GSPAN(k)
 #endif
 
 namespace {
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __res
 
     const int nk = FS / HBK;
     GSTAMP(0)
+    GSPAN(0)
     issue_tile(0, 0);
     __syncthreads();                                    // (waits vmcnt(0): the tile has landed)
     for (int kt = 0; kt < nk; ++kt) {
@@ -205,11 +209,15 @@ __global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __res
     }
     GSTAMP(2)
     GSTAMP(3)
+    GSPAN(1)
 }
 
 }  // namespace
 
 #ifdef REPET_GRAM_STAMPS
+extern "C" int repet_debug_gram_spans(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(repet::g_gram_span), sizeof(unsigned long long) * 2 * n);
+}
 extern "C" int repet_debug_gram_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gram_stamps), sizeof(unsigned long long) * 32);
 }

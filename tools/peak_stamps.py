@@ -10,7 +10,7 @@ lib = ctypes.CDLL(os.environ["REPET_HIP_LIB"])
 buf = (ctypes.c_ulonglong * 64)()
 print("rc", lib.repet_debug_peak_stamps(buf))
 a = np.array(buf[:], dtype=np.int64).reshape(8, 8)
-for row in a:
+for row in (a if a.any() else []):
     print("load %6d  passes %6d  test %6d  refine %6d  rank %6d  | total %6d cycles" % (
         row[1] - row[0], row[2] - row[1], row[5] - row[2], row[3] - row[5], row[4] - row[3], row[4] - row[0]))
 
@@ -18,7 +18,7 @@ if hasattr(lib, "repet_debug_wave_stamps"):
     print("wave kernel (peaks_wave.hip), cycles summed over the chunks of one row:")
     print("rc", lib.repet_debug_wave_stamps(buf))
     a = np.array(buf[:], dtype=np.int64).reshape(8, 8)
-    for row in a:
+    for row in (a if a.any() else []):
         print("load+transpose %6d  doubling %6d  sweep %6d  decide %6d  rivals+refine %6d  rank %6d | total %6d" % (
             row[0], row[1], row[2], row[3], row[4], row[5], row[:6].sum()))
 
@@ -61,3 +61,21 @@ if hasattr(lib, "repet_debug_gram_stamps"):
     a = np.array(g[:], dtype=np.int64).reshape(8, 4)
     for row in a:
         print("K loop %7d  natural stores %6d  mirror %6d | total %7d" % (row[1] - row[0], row[2] - row[1], row[3] - row[2], row[3] - row[0]))
+
+if hasattr(lib, "repet_debug_gram_spans"):
+    T = ctx.last_frame_count()
+    nt = -(-T // 256)
+    n = nt * (nt + 1) // 2
+    sp = (ctypes.c_ulonglong * (2 * n))()
+    print("rc", lib.repet_debug_gram_spans(sp, n))
+    sp = np.array(sp[:], dtype=np.int64).reshape(n, 2) * 10e-3
+    sp = sp[sp[:, 1] > 0]
+    t0 = sp[:, 0].min()
+    dur = sp[:, 1] - sp[:, 0]
+    span = sp[:, 1].max() - t0
+    print("Gram workgroups %d  kernel span %.1f us  workgroup time: mean %.1f  min %.1f  max %.1f us | mean concurrency %.0f" % (
+        len(sp), span, dur.mean(), dur.min(), dur.max(), dur.sum() / span))
+    for lo in range(0, int(span) + 1, 20):
+        alive = np.sum((sp[:, 0] - t0 <= lo) & (sp[:, 1] - t0 > lo))
+        started = np.sum((sp[:, 0] - t0 >= lo) & (sp[:, 0] - t0 < lo + 20))
+        print("  t = %3d us: %4d workgroups alive, %4d start in the next 20 us" % (lo, alive, started))
