@@ -774,7 +774,9 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         // The column sort needs nothing of the similarity matrix: it runs on the side stream BESIDE the peak picking, whose
         // rows take 30 .. 140 us each -- the second half of that launch is a tail of fewer and fewer waves (spans of every
         // row: tools/peak_stamps.py), which the sort's workgroups fill. (Beside the Gram kernel it does not pay: a sort
-        // workgroup on a CU keeps the Gram's 139 KB workgroup off it.) REPET_RANK_OVERLAP=0: one after the other.
+        // workgroup on a CU keeps the Gram's 139 KB workgroup off it -- and so does the memory-bound transpose that opens
+        // the sort, although its 17 KB of LDS fit beside a Gram workgroup: Gram 0.209 -> 0.244 ms for 0.015 ms saved
+        // afterwards.) REPET_RANK_OVERLAP=0: one after the other.
         static const bool rank_overlap = [] { const char* e = getenv("REPET_RANK_OVERLAP"); return !(e && e[0] == '0'); }();
         const bool beside = use_rank && rank_overlap;
         if (beside) {
