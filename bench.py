@@ -247,6 +247,15 @@ def main():
                 b8d = 4.0 * F * rows * C * (1.0 + k_mean + 1.0) * (args.clips if batched else 1)
                 entry["survey_8d_bytes"] = {"algorithmic": b8d, "GB/s": round(b8d / sec / 1e9, 1), "frac_of_hbm_peak": round(b8d / sec / 1e9 / HBM_PEAK_GBS, 4),
                                             "k_mean": round(k_mean, 2), "note": "gathers are served by L2 / Infinity Cache" + ("; the rank path moves 2 bytes per gathered value, not 4" if rank_path else "")}
+                # short lists (simonline: about ten similar frames): the network is a few dozen instructions and the stage is
+                # bound by what MUST cross HBM -- V read once (the gathers re-read it from cache), X read and written
+                compulsory = (4.0 + 16.0) * F * rows * C * (args.clips if batched else 1)
+                if compulsory / (HBM_PEAK_GBS * 1e9) > net_instr * waves / (VALU_QUARTER_RATE_GINSTR * 1e9):
+                    entry["valu_view"] = {k: entry[k] for k in ("achieved", "peak", "unit", "frac")}
+                    ach = compulsory / sec / 1e9
+                    entry.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic": compulsory,
+                                  "note": "compulsory bytes 4FTC (V) + 16FTC (X in place); the network is too short to bind"})
             elif meta["flops"] > 0 and "f16x3" in name:
                 # f16-split matrix-core kernel: three f16 MFMA products per fp32 term, fp32 accumulate. Priced on EXECUTED
                 # f16 flops against the dense f16 MFMA peak; the fp32-equivalent algorithmic rate is stated beside it.

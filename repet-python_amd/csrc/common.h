@@ -60,6 +60,14 @@ __host__ __device__ inline float segment_weight(int64_t n, int64_t fade_in, int6
     return w;
 }
 
+// a * b rounded to fp32 and never contracted into a following add (HIP's __fmul_rn is a plain product): the inverse STFT
+// kernels multiply the spectrum by the mask plane with it, so that the products equal the ones a mask kernel stores
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // one component of a unit row into the two f16 planes (the arithmetic of split_f16_kernel, gram_f16.hip)
 __device__ __forceinline__ void store_split_f16(void* planes, int64_t e, float x) {
     _Float16* p = static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31);
@@ -87,6 +95,9 @@ struct IstftOlaArgs {
     // spectra at j_local*batch_spec_stride, writes at out_offset + j*batch_out_stride, and fades in unless
     // j == 0 / out unless j == batch_total-1 over `overlap` samples (fade_in/fade_out are ignored then)
     int32_t n_batch, batch_first, batch_step, batch_total, batch_local0; int64_t batch_spec_stride, batch_out_stride, overlap;
+    // (nullable) the soft mask as a plane of its own, laid out like V (element strides of Y): the spectrum is multiplied
+    // by it as it is fetched, so the mask kernels write 4 bytes per cell instead of reading and rewriting 8 + 8
+    const float* M;
 };
 hipError_t launch_istft_ola(const IstftOlaArgs& a, hipStream_t s);
 // register-resident variants for W = 2048 (stft_reg.hip); launch_stft / launch_istft_ola pick them themselves

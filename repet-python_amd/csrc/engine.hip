@@ -101,6 +101,8 @@ struct repet_ctx {
     // (multi-GPU `extended`: a rank holds only the samples of its own segment range); 0 = the resident clip is whole
     int64_t win_total = 0, win_offset = 0;
     bool win_skip_clear = false;  // exec_extended cleared `out` itself (window mode)
+    DevBuf Mk;                    // the soft mask as a plane of its own (laid out like V), when the inverse STFT applies it
+    bool mask_plane = false;      // the pipeline being enqueued keeps the mask apart instead of multiplying X in place
     bool ola_first_batch = false; // run_original: the first batch of equal segments of an `extended` run (class 0 may store)
     int32_t last_fs = 0;          // sampling frequency of the resident clip when it came from a WAVE file (for repet_ctx_result_wav)
     // `extended`: the longer last segment cannot join the batch of equal segments; its analysis (STFT .. mask) runs on
@@ -362,9 +364,30 @@ bool split_in_stft() {
     return on && gram_f16_enabled();
 }
 
+// The period mask of `original` / `extended` reads V, reads X and writes X: 20 bytes per cell, and the inverse STFT reads
+// X again. With the mask as a plane of its own the mask kernel writes 4 bytes and the inverse STFT multiplies while it
+// fetches (8 + 4): 20 instead of 28 bytes per cell over the two stages, the same products bit for bit (mul_rounded).
+// Measured (mask + inverse, ms): extended cfg 3 0.414 + 0.491 -> 0.243 + 0.571; adaptive cfg 4 0.075 + 0.061 -> 0.059 +
+// 0.082; simonline cfg 5 0.776 + 0.608 -> 0.600 + 0.765; sim cfg 2 (selection-bound mask) 0.50 + 0.072 -> 0.50 + 0.091 --
+// the inverse kernel pays for its extra loads what the byte count says, so only the period mask gains: that is the
+// default. REPET_MASK_PLANE=0 / 1: never / in every variant.
+enum class MaskKind { period, adaptive, sim_float, sim_ranks };
+bool mask_plane_wanted(MaskKind kind) {
+    static const int forced = [] { const char* e = getenv("REPET_MASK_PLANE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return forced >= 0 ? forced != 0 : kind == MaskKind::period;
+}
+
+struct MaskPlaneScope {            // the choice holds for one pipeline; stage exports and the streaming handle never see it
+    repet_ctx* c;
+    MaskPlaneScope(repet_ctx* ctx, bool on) : c(ctx) { c->mask_plane = on; }
+    ~MaskPlaneScope() { c->mask_plane = false; }
+};
+
 int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B = 1) {
+    if (g.W > 4096) c->mask_plane = false;       // the 8192-sample inverse kernel has no registers to spare for the mask
     HIP_TRY(c->X.ensure((size_t)B * g.C * g.chan_stride * sizeof(float2)));
     HIP_TRY(c->V.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
+    if (c->mask_plane) HIP_TRY(c->Mk.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
     if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
     HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream));
     const size_t mean_elems = (size_t)g.Tpad * g.FS;
@@ -411,7 +434,8 @@ int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64
 MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
     MaskArgs m{};
     m.V = c->V.as<float>(); m.chan_stride = g.chan_stride; m.n_channels = g.C; m.T = g.T; m.F = g.F; m.FS = g.FS;
-    m.X = c->X.as<float2>(); m.mask = nullptr; m.cutoff = cutoff; m.pad_row = g.Tpad;
+    m.X = c->mask_plane ? nullptr : c->X.as<float2>(); m.mask = c->mask_plane ? c->Mk.as<float>() : nullptr;
+    m.cutoff = cutoff; m.pad_row = g.Tpad;
     m.n_batch = 1; m.batch_stride = (int64_t)g.C * g.chan_stride;
     return m;
 }
@@ -420,14 +444,14 @@ MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
 int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_t n_out, int64_t out_offset,
               bool weighted, int64_t fade_in, int64_t fade_out) {
     IstftOlaArgs a{};
-    a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+    a.Y = c->X.as<float2>(); a.M = c->mask_plane ? c->Mk.as<float>() : nullptr; a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
     a.twiddle = tb->twiddle.as<float2>(); a.trim = trim; a.out = c->out.as<float>(); a.n_out = n_out;
     a.out_offset = c->clip_base + out_offset; a.scale = (float)(1.0 / tb->cola);
     a.accumulate_weighted = weighted ? 1 : 0; a.fade_in = fade_in; a.fade_out = fade_out;
     hipError_t e = launch_istft_ola(a, c->stream);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
     HIP_TRY(e);
-    mark(c, "istft_ola", 8.0 * g.F * g.T * g.C + 4.0 * n_out * g.C, 0);
+    mark(c, "istft_ola", (c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n_out * g.C, 0);
     return REPET_OK;
 }
 
@@ -456,7 +480,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     MaskArgs m = mask_args(c, g, p->cutoff_bins);
     m.n_batch = B;
     HIP_TRY(launch_mask_period(m, period_slots, 0, p->period_lo + 1, c->stream));
-    mark(c, "mask_period", B * (4.0 + 4.0 + 16.0) * g.F * T * g.C, 0);
+    mark(c, "mask_period", B * (4.0 + 4.0 + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);     // V, the gathers, the mask plane or X in place
     if (c->pre_synthesis) {
         std::function<int()> hook;
         hook.swap(c->pre_synthesis);
@@ -467,7 +491,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     } else if (!weighted) {
         // independent clips of a batch context: clip b is written at offset + b*hop, no cross-fade
         IstftOlaArgs a{};
-        a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+        a.Y = c->X.as<float2>(); a.M = c->mask_plane ? c->Mk.as<float>() : nullptr; a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
         a.twiddle = tb->twiddle.as<float2>(); a.trim = g.W - g.H; a.out = c->out.as<float>(); a.n_out = n;
         a.out_offset = c->clip_base + offset; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 0;
         a.n_batch = B; a.batch_first = 0; a.batch_step = 1; a.batch_total = B; a.batch_local0 = 0;
@@ -475,14 +499,14 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
         hipError_t e = launch_istft_ola(a, c->stream);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
         HIP_TRY(e);
-        mark(c, "istft_ola", B * (8.0 * g.F * g.T * g.C + 4.0 * n * g.C), 0);
+        mark(c, "istft_ola", B * ((c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n * g.C), 0);
     } else {
         // segments that overlap in the output must not be accumulated concurrently: one launch per residue
         // class modulo ceil(n / hop) (2 for the default 10 s / 5 s), each class writes disjoint samples
         const int classes = hop > 0 ? (int)ceil_div(n, hop) : 1;
         for (int k = 0; k < classes && k < B; ++k) {
             IstftOlaArgs a{};
-            a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+            a.Y = c->X.as<float2>(); a.M = c->mask_plane ? c->Mk.as<float>() : nullptr; a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
             a.twiddle = tb->twiddle.as<float2>(); a.trim = g.W - g.H; a.out = c->out.as<float>(); a.n_out = n;
             a.out_offset = c->clip_base; a.scale = (float)(1.0 / tb->cola);
             // class 0 of the first batch tiles its span of the cleared output exactly when the segment length is a whole
@@ -496,13 +520,14 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
             HIP_TRY(e);
         }
-        mark(c, "istft_ola", B * (8.0 * g.F * g.T * g.C + 4.0 * n * g.C), 0);
+        mark(c, "istft_ola", B * ((c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n * g.C), 0);
     }
     c->last_T = T;
     return REPET_OK;
 }
 
 int exec_original(repet_ctx* c, const repet_params* p) {
+    MaskPlaneScope plane(c, mask_plane_wanted(MaskKind::period));
     // a batch context at its base runs all clips together (one launch per stage); otherwise the current clip
     const int nb = c->clip_loop ? 1 : c->n_clips;
     HIP_TRY(c->periods.ensure((size_t)nb * sizeof(int32_t)));
@@ -548,6 +573,7 @@ int exec_extended(repet_ctx* c, const repet_params* p, int64_t first = 0, int64_
 }
 
 int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64_t n_seg, int64_t N) {
+    MaskPlaneScope plane(c, mask_plane_wanted(MaskKind::period));
     const int64_t L = p->seg_len_samples, Hs = p->seg_step_samples;
     const int64_t count = extended_segment_count(N, p);
     if (count < 0) return fail(REPET_ERR_BAD_ARG, "extended: bad segment length/step (Window length M must be a non-negative integer)");
@@ -599,6 +625,7 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         x->out.borrow(c->out.p, c->out.cap);
         x->n_samples = c->n_samples; x->n_channels = c->n_channels; x->n_clips = 1; x->clip_base = c->clip_base;
         x->timing = nullptr;
+        MaskPlaneScope aux_plane(x, c->mask_plane);
         HIP_TRY(hipEventRecord(c->aux_start, c->stream));              // the clip is resident, `out` is cleared
         HIP_TRY(hipStreamWaitEvent(x->stream, c->aux_start, 0));
         int batch_rc = REPET_OK;
@@ -631,6 +658,7 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
 }
 
 int exec_adaptive(repet_ctx* c, const repet_params* p) {
+    MaskPlaneScope plane(c, mask_plane_wanted(MaskKind::adaptive));
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, p->window_length, &tb));
     const int64_t N = c->n_samples;
@@ -744,6 +772,11 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int64_t T = repet_frame_count(N, p->window_length, p->step_length, 1);
     const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
     if (p->sim_number < 1) return fail(REPET_ERR_BAD_ARG, "similarity_number must be >= 1");
+    // (the same test as below: the median on rank codes multiplies X in place, the float path keeps the mask apart)
+    const bool ranks_ahead = sim_chunks(T) <= 1 && rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
+                             std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1)) >= kRankMinList &&
+                             std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1)) <= 128;
+    MaskPlaneScope plane(c, mask_plane_wanted(ranks_ahead ? MaskKind::sim_ranks : MaskKind::sim_float));
     RP_TRY(ensure_spectra(c, g, true, false));
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);
@@ -841,6 +874,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
 }
 
 int exec_simonline(repet_ctx* c, const repet_params* p) {
+    MaskPlaneScope plane(c, mask_plane_wanted(MaskKind::sim_float));
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, p->window_length, &tb));
     const int64_t N = c->n_samples;
@@ -884,7 +918,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
         RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
     } else {
         IstftOlaArgs a{};
-        a.Y = c->X.as<float2>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
+        a.Y = c->X.as<float2>(); a.M = c->mask_plane ? c->Mk.as<float>() : nullptr; a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
         a.twiddle = tb->twiddle.as<float2>(); a.trim = 0; a.out = c->out.as<float>(); a.n_out = N;
         a.out_offset = 0; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 0;
         a.n_batch = nb; a.batch_first = 0; a.batch_step = 1; a.batch_total = nb; a.batch_local0 = 0;
@@ -892,7 +926,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
         hipError_t e2 = launch_istft_ola(a, c->stream);
         if (e2 == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
         HIP_TRY(e2);
-        mark(c, "istft_ola", nb * (8.0 * g.F * g.T * g.C + 4.0 * N * g.C), 0);
+        mark(c, "istft_ola", nb * ((c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * N * g.C), 0);
     }
     c->last_T = T; c->last_idx_rows = rows; c->last_idx_pitch = KP; c->last_idx_number = K;
     c->last_idx_batch = rows >= 1 ? nb : 1;       // rows_alloc == rows then: the clips' lists are contiguous
@@ -988,7 +1022,7 @@ int repet_ctx_destroy(repet_ctx* c) {
         for (hipEvent_t e : {c->aux_start, c->aux_main_done, c->aux_done}) if (e) (void)hipEventDestroy(e);
     }
     c->ring.release();
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Mk, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
                       &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();

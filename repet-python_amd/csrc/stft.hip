@@ -112,7 +112,11 @@ __device__ __forceinline__ void fft_twiddles(FftTwiddles<N>& t, const float2* __
             const int k = i & (p - 1);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                float2 w = (i < N / 4) ? tw[(r + 1) * k * tstep] : make_float2(1.f, 0.f);
+                // the load is unconditional (index 0 for an idle thread) and the choice made afterwards: a load inside a
+                // branch is waited for at the join, so the sixteen table loads of the prologue came back one after the
+                // other (12 000 cycles per workgroup of the inverse kernel)
+                const float2 l = tw[(i < N / 4) ? (r + 1) * k * tstep : 0];
+                const float2 w = (i < N / 4) ? l : make_float2(1.f, 0.f);
                 t.w4[s][q][r] = INVERSE ? cconj(w) : w;
             }
         }
@@ -123,7 +127,8 @@ __device__ __forceinline__ void fft_twiddles(FftTwiddles<N>& t, const float2* __
 #pragma unroll
         for (int q = 0; q < P::kBpt2; ++q) {
             const int i = tid + kFftThreads * q;
-            float2 w = (i < N / 2) ? tw[(i & (p - 1)) * tstep] : make_float2(1.f, 0.f);
+            const float2 l = tw[(i < N / 2) ? (i & (p - 1)) * tstep : 0];
+            const float2 w = (i < N / 2) ? l : make_float2(1.f, 0.f);
             t.w2[q] = INVERSE ? cconj(w) : w;
         }
     }
@@ -729,20 +734,31 @@ __device__ __forceinline__ void inverse_tables(InverseTables<W>& t, const float2
 #pragma unroll
     for (int i = 0; i < (N + kFftThreads - 1) / kFftThreads; ++i) {
         const int k = threadIdx.x + kFftThreads * i;
-        t.wk[i] = (k < N) ? cconj(tw[k]) : make_float2(0.f, 0.f);
+        const float2 l = tw[k < N ? k : 0];
+        t.wk[i] = (k < N) ? cconj(l) : make_float2(0.f, 0.f);
     }
 }
 
 template <int W>
 struct SpectrumRegs { float2 xk[(W / 2 + kFftThreads - 1) / kFftThreads], xc[(W / 2 + kFftThreads - 1) / kFftThreads]; };
 
-template <int W>
-__device__ __forceinline__ void fetch_spectrum(SpectrumRegs<W>& r, const float2* __restrict__ Y) {
+template <int W, bool MASKED>
+__device__ __forceinline__ void fetch_spectrum(SpectrumRegs<W>& r, const float2* __restrict__ Y, const float* __restrict__ M) {
     constexpr int N = W / 2;
 #pragma unroll
     for (int i = 0; i < (N + kFftThreads - 1) / kFftThreads; ++i) {
         const int k = threadIdx.x + kFftThreads * i;
-        if (k < N) { r.xk[i] = Y[k]; r.xc[i] = Y[N - k]; }
+        if (k < N) {
+            float2 xk = Y[k], xc = Y[N - k];
+            if constexpr (MASKED) {          // the products the mask kernels would have stored: same bits
+                const float mk = M[k], mc = M[N - k];
+                // rounded products, never contracted into the sums of the repack (then they would differ from the stored
+                // ones in the last bit, and the stream from the offline result)
+                xk = make_float2(mul_rounded(xk.x, mk), mul_rounded(xk.y, mk));
+                xc = make_float2(mul_rounded(xc.x, mc), mul_rounded(xc.y, mc));
+            }
+            r.xk[i] = xk; r.xc[i] = xc;
+        }
     }
 }
 
@@ -759,8 +775,12 @@ __device__ __forceinline__ void repack_spectrum(const SpectrumRegs<W>& r, const 
             const float2 xc = cconj(r.xc[i]);
             const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
             const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
-            const float2 o = cmul(d, t.wk[i]);
-            buf0[k] = make_float2(e.x - o.y, e.y + o.x);
+            // the complex product spelled out, one fused multiply-add per component: left to the compiler, the masked and
+            // the plain instantiation of the kernel contract these sums differently and their outputs differ in the last bit
+            const float2 w = t.wk[i];
+            const float ox = fmaf(d.x, w.x, -mul_rounded(d.y, w.y));
+            const float oy = fmaf(d.x, w.y, mul_rounded(d.y, w.x));
+            buf0[k] = make_float2(e.x - oy, e.y + ox);
         }
     }
 }
@@ -783,7 +803,7 @@ struct __attribute__((packed, aligned(4))) Float4U { float x, y, z, w; };    // 
 
 // accumulate_weighted: 0 = store, 1 = out += w y, 2 = out = w y (a class of segments that tiles its span and is the first
 // to write there: no read of the cleared buffer)
-template <int W>
+template <int W, bool MASKED>
 __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <= 2048 ? REPET_ISTFT_MIN_WAVES : 1, 8))) void istft_ola_kernel(IstftOlaArgs a, int run) {
     constexpr int N = W / 2;          // complex points per frame = samples per hop (H = W/2)
     constexpr int HP = N / 2;         // float2 per half frame
@@ -804,6 +824,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     if (a.n_batch > 0) {
         const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        if (MASKED) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
         a.fade_out = a.overlap;
@@ -837,7 +858,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
         for (int c = 0; c < C; ++c) {
             const float2* z = buf0;
             if (have) {
-                fetch_spectrum<W>(spec, a.Y + c * a.chan_stride + t * a.FS);
+                fetch_spectrum<W, MASKED>(spec, a.Y + c * a.chan_stride + t * a.FS, MASKED ? a.M + c * a.chan_stride + t * a.FS : nullptr);
                 repack_spectrum<W>(spec, tables, buf0);
                 __syncthreads();
                 z = fft_lds_regs<N, true>(buf0, buf1, tables.ft);
@@ -1096,6 +1117,7 @@ __global__ __launch_bounds__(256) void istft_ola_wave_kernel(IstftOlaArgs a, int
     if (a.n_batch > 0) {
         const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        if (a.M) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
         a.fade_out = a.overlap;
@@ -1119,9 +1141,15 @@ __global__ __launch_bounds__(256) void istft_ola_wave_kernel(IstftOlaArgs a, int
             const int64_t t = t0 + df;
             if (t >= 0 && t < a.T && t <= h1) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
+                const float* Mr = a.M ? a.M + c * a.chan_stride + t * a.FS : nullptr;
                 for (int k = lane; k < N; k += 64) {
-                    const float2 xk = Y[k];
-                    const float2 xc = cconj(Y[N - k]);
+                    float2 xk = Y[k];
+                    float2 xc = cconj(Y[N - k]);
+                    if (Mr) {
+                        const float mk = Mr[k], mc = Mr[N - k];
+                        xk = make_float2(mul_rounded(xk.x, mk), mul_rounded(xk.y, mk));
+                        xc = make_float2(mul_rounded(xc.x, mc), mul_rounded(xc.y, mc));
+                    }
                     const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
                     const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
                     const float2 o = cmul(d, cconj(tw[k]));
@@ -1297,10 +1325,17 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     return dispatch_window(a.W, [&](auto w) {
         constexpr int Wc = decltype(w)::value;
         const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
-        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), (int)dyn);
-        // a run of r hops costs r + 1 inversions (the frame before it) and the twiddle prologue
-        const int run = frames_per_workgroup(reinterpret_cast<const void*>(&istft_ola_kernel<Wc>), dyn, hops, batches, kOlaRun - 2, 1.5);
-        hipLaunchKernelGGL(istft_ola_kernel<Wc>, dim3((unsigned)ceil_div(hops, run), (unsigned)batches), dim3(kFftThreads), dyn, s, a, run);
+        auto go = [&](auto kernel) {
+            (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)dyn);
+            // a run of r hops costs r + 1 inversions (the frame before it) and the twiddle prologue
+            const int run = frames_per_workgroup(reinterpret_cast<const void*>(kernel), dyn, hops, batches, kOlaRun - 2, 1.5);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(hops, run), (unsigned)batches), dim3(kFftThreads), dyn, s, a, run);
+        };
+        if constexpr (Wc <= 4096) {
+            if (a.M) go(&istft_ola_kernel<Wc, true>); else go(&istft_ola_kernel<Wc, false>);
+        } else {
+            go(&istft_ola_kernel<Wc, false>);       // the engine keeps the mask in X for the longest window (registers)
+        }
     });
 }
 

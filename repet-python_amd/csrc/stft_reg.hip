@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     if (a.n_batch > 0) {
         const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        if (a.M) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
         a.fade_out = a.overlap;
@@ -406,12 +407,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             float2 v[16];
             if (t >= 0 && t < a.T && t <= h1) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
+                const float* Mr = a.M ? a.M + c * a.chan_stride + t * a.FS : nullptr;
                 // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
                     const int k = 64 * n1 + lane;
-                    const float2 xk = Y[k];
-                    const float2 xc = cconj(Y[N - k]);
+                    float2 xk = Y[k];
+                    float2 xc = cconj(Y[N - k]);
+                    if (Mr) {
+                        const float mk = Mr[k], mc = Mr[N - k];
+                        xk = make_float2(mul_rounded(xk.x, mk), mul_rounded(xk.y, mk));
+                        xc = make_float2(mul_rounded(xc.x, mc), mul_rounded(xc.y, mc));
+                    }
                     const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
                     const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
                     const float2 o = cmul(d, cconj(a.twiddle[k]));

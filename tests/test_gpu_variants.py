@@ -420,6 +420,30 @@ def test_fft_paths_agree():
     assert rms_err(outs[0], outs[2]) < 2e-6
 
 
+def test_mask_plane_gives_the_same_bits():
+    """The soft mask kept as a plane of its own and applied by the inverse STFT while it fetches the spectrum
+    (REPET_MASK_PLANE=1; default for original / extended) against the mask multiplied into the spectrum in place (=0):
+    the same rounded products either way, so every variant's output must be IDENTICAL -- batched extended segments,
+    a batch context of simonline clips and the 4-channel block-kernel path included."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "x = synth(31, 44100, 2, 3); outs = [getattr(repet, a)(x, 44100) for a in ('original', 'extended', 'adaptive', 'sim', 'simonline')]; "
+            "q = synth(12, 22050, 4, 5); outs += [repet.extended(q, 22050), repet.simonline(q, 22050)]; "
+            "c = repet.Context(0); c.upload_batch(np.stack([synth(13, 16000, 2, s) for s in range(3)])); c.execute('simonline', repet.derive_params(16000)); "
+            "outs.append(c.download()); np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for plane in ("0", "1"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_plane_{plane}_{os.getpid()}.npy")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MASK_PLANE=plane))
+        outs.append(np.load(out))
+        os.remove(out)
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
 def test_gram_paths_agree():
     """sim's similarity matrix: the f16-split matrix-core kernel (default) against the exact-fp32 one (REPET_GRAM=f32).
     Same similar-frame lists (the float64 refinement settles every near-tie either way), outputs equal to fp32 noise."""
