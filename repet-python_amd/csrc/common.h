@@ -68,6 +68,20 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
     return p;
 }
 
+// w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; den_in / den_ov
+// are (float)(2 fade_in) and (float)(2 overlap). Same values as segment_weight: the conversions are of the same integers.
+__device__ __forceinline__ float segment_weight32(int n, int fade_in, int overlap, int step, int later, float den_in, float den_ov) {
+    float w = 1.f;
+    if (n < fade_in) w = (float)(2 * n + 1) / den_in;
+    if (overlap > 0 && step > 0) {
+        for (int q = 1, base = step; q <= later && base <= n; ++q, base += step) {
+            const int r = n - base;
+            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) / den_ov;
+        }
+    }
+    return w;
+}
+
 // one component of a unit row into the two f16 planes (the arithmetic of split_f16_kernel, gram_f16.hip)
 __device__ __forceinline__ void store_split_f16(void* planes, int64_t e, float x) {
     _Float16* p = static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31);

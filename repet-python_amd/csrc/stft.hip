@@ -785,20 +785,6 @@ __device__ __forceinline__ void repack_spectrum(const SpectrumRegs<W>& r, const 
     }
 }
 
-// w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; den_in / den_ov
-// are (float)(2 fade_in) and (float)(2 overlap). Same values as segment_weight: the conversions are of the same integers.
-__device__ __forceinline__ float segment_weight32(int n, int fade_in, int overlap, int step, int later, float den_in, float den_ov) {
-    float w = 1.f;
-    if (n < fade_in) w = (float)(2 * n + 1) / den_in;
-    if (overlap > 0 && step > 0) {
-        for (int q = 1, base = step; q <= later && base <= n; ++q, base += step) {
-            const int r = n - base;
-            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) / den_ov;
-        }
-    }
-    return w;
-}
-
 struct __attribute__((packed, aligned(4))) Float4U { float x, y, z, w; };    // a float4 at any dword address (segment offsets)
 
 // accumulate_weighted: 0 = store, 1 = out += w y, 2 = out = w y (a class of segments that tiles its span and is the first
@@ -1304,7 +1290,10 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     if (a.last_hop > a.T) a.last_hop = a.T;                  // hop T holds the last frame's tail, later hops are empty
     const int64_t hops = a.last_hop - a.first_hop + 1;
     if (hops <= 0) return hipSuccess;
-    if (reg_fft_supported(a.W, a.n_channels, true)) return launch_istft_ola_reg(a, hops, s);
+    if (reg_fft_supported(a.W, a.n_channels, true)) {
+        const hipError_t e = launch_istft_ola_reg(a, hops, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 4 && a.n_channels != 3) {
         const int C = a.n_channels;
         const int FI = 4 / C;

@@ -366,96 +366,165 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
 }
 
 // ---- inverse + overlap-add ---------------------------------------------------------------------------
-// `run` hops per workgroup; each round the four waves invert FI = 4 / C consecutive frames x C channels into
-// their LDS regions (natural order, as W real samples), then all threads add heads and tails and write whole
-// hops interleaved over the channels. tails[c][n] carries the second half of the previous frame.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void istft_ola_reg_kernel(IstftOlaArgs a, int run) {
+// Twelve wavefronts per workgroup, one workgroup per CU, a wave inverts a whole frame (every channel) per round and the
+// twelve frames of a round are CONSECUTIVE: hop t = first half of frame t + second half of frame t - 1, so a wave
+// leaves its frame's second half in its (now idle) exchange region, one barrier, and reads its left neighbour's; the
+// last wave's goes through a carry region to the first wave of the next round. The workgroup's first wave inverts the
+// frame before the run once more (its tail is all that is used). Two barriers per round of 12 x C transforms, none
+// inside a transform; output as one 16-byte store per lane and sample pair of a stereo clip.
+constexpr int kInvWaves = 12;
+constexpr int kInvLdsFloat2 = kInvWaves * kExPitch + kTwFloat2 + kRegN + 2 * 8 * 64;    // + split twiddles [N] + carry [2][8][64]
+
+template <int C, bool MASKED>      // C = 1, 2
+__global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaArgs a, int rounds) {
     constexpr int N = kRegN;          // samples per hop = complex FFT length
-    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
-    float2* ex_all = lds2;                                               // [4][kExPitch]
-    float2* tw_lds = ex_all + 4 * kExPitch;                              // [kTwFloat2]
-    float* tails = reinterpret_cast<float*>(tw_lds + kTwFloat2);         // [C][N]
-    const int tid = threadIdx.x, lane_id = tid & 63, wave = tid >> 6;
-    const int C = a.n_channels;
+    extern __shared__ __attribute__((aligned(16))) float2 inv_lds[];
+    float2* ex_all = inv_lds;
+    float2* tw_lds = ex_all + kInvWaves * kExPitch;
+    float2* split_lds = tw_lds + kTwFloat2;                     // conj(exp(-2 pi i k / W)), k < N
+    float2* carry = split_lds + N;                              // [C][8][64]: second half of the frame before the round
+    const int tid = threadIdx.x, lane_id = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* ex = ex_all + wave * kExPitch;
     if (a.n_batch > 0) {
         const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
-        if (a.M) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        if (MASKED) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
         a.fade_out = a.overlap;
         a.seg_step = a.batch_out_stride;
         a.later = a.batch_total - 1 - j;
     }
-    for (int i = tid; i < C * N; i += 256) tails[i] = 0.f;
-    const RegTwiddles tw = load_reg_twiddles<true>(tw_lds, a.twiddle, tid);
+    for (int i = tid; i < 16 * 64; i += 64 * kInvWaves) {
+        const int k1 = i >> 6, l = i & 63;
+        tw_lds[i] = cconj(a.twiddle[2 * l * k1]);                 // exp(+2 pi i l k1 / 1024)
+    }
+    if (tid < 64) tw_lds[16 * 64 + tid] = cconj(a.twiddle[32 * (tid >> 4) * (tid & 15)]);
+    for (int i = tid; i < N; i += 64 * kInvWaves) split_lds[i] = cconj(a.twiddle[i]);
+    for (int i = tid; i < C * 8 * 64; i += 64 * kInvWaves) carry[i] = make_float2(0.f, 0.f);
+    const RegTwiddles tw{tw_lds, tw_lds + 16 * 64};
     __syncthreads();
 
-    const int FI = 4 / C;                       // frames per round (C in {1, 2, 4})
-    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * run;
-    int64_t h1 = h0 + run - 1;
-    if (h1 > a.last_hop) h1 = a.last_hop;
-    float2* ex = ex_all + wave * kExPitch;
-    const float inv_n = a.scale / (float)N;
-    // frames h0-1 .. h1 ; frame t feeds hop t (first half) and hop t+1 (second half)
-    for (int64_t t0 = h0 - 1; t0 <= h1; t0 += FI) {
-        {
-            const int df = wave / C, c = wave - df * C;
-            const int64_t t = t0 + df;
-            int lane = lane_id;
+    const int hops_per_wg = kInvWaves * rounds - 1;
+    const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * hops_per_wg;
+    const int64_t h_last = (h0 + hops_per_wg - 1 < a.last_hop) ? h0 + hops_per_wg - 1 : a.last_hop;
+    const float inv_n = 1.0f / (float)N;
+    const int mode = a.accumulate_weighted;
+    // (positions inside a segment fit 32 bits here: launch_istft_ola_reg leaves longer segments to the block kernel)
+    const int fade_in = (int)a.fade_in, overlap = (int)a.fade_out, step = (int)a.seg_step;
+    const float den_in = (float)(2 * a.fade_in), den_ov = (float)(2 * a.fade_out);
+    auto weight = [&](int64_t n) -> float { return segment_weight32((int)n, fade_in, overlap, step, a.later, den_in, den_ov); };
+
+    for (int r = 0; r < rounds; ++r) {
+        const int64_t t = h0 - 1 + (int64_t)kInvWaves * r + wave;       // this wave's frame; it emits hop t
+        const bool have = t >= 0 && t < a.T && t <= h_last;              // wave-uniform
+        float2 head[C][8], tail[C][8];
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            int lane = lane_id;                                          // opaque per transform (see the forward kernel)
             asm volatile("" : "+v"(lane));
             float2 v[16];
-            if (t >= 0 && t < a.T && t <= h1) {
+            if (have) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
-                const float* Mr = a.M ? a.M + c * a.chan_stride + t * a.FS : nullptr;
+                const float* Mr = MASKED ? a.M + c * a.chan_stride + t * a.FS : nullptr;
                 // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
                     const int k = 64 * n1 + lane;
                     float2 xk = Y[k];
-                    float2 xc = cconj(Y[N - k]);
-                    if (Mr) {
+                    float2 xc = Y[N - k];
+                    if constexpr (MASKED) {
                         const float mk = Mr[k], mc = Mr[N - k];
                         xk = make_float2(mul_rounded(xk.x, mk), mul_rounded(xk.y, mk));
                         xc = make_float2(mul_rounded(xc.x, mc), mul_rounded(xc.y, mc));
                     }
+                    xc = cconj(xc);
                     const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
                     const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
-                    const float2 o = cmul(d, cconj(a.twiddle[k]));
-                    v[n1] = make_float2(e.x - o.y, e.y + o.x);
-                    if ((n1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                    const float2 w = split_lds[k];
+                    const float ox = fmaf(d.x, w.x, -mul_rounded(d.y, w.y));
+                    const float oy = fmaf(d.x, w.y, mul_rounded(d.y, w.x));
+                    v[n1] = make_float2(e.x - oy, e.y + ox);
+                    if ((n1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four points' loads in flight, not sixteen
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 wave_fft1024<true>(v, ex, tw, lane);
+                __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) v[s] = make_float2(0.f, 0.f);
             }
+            // v[s] = samples (2n, 2n + 1), n = lane + 64 s, of the frame (unscaled)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) ex[lane + 64 * s] = v[s];        // samples 2k, 2k+1 of the frame
+            for (int s = 0; s < 8; ++s) {
+                if (c == 0) { head[0][s] = v[s]; tail[0][s] = v[8 + s]; }
+                else { head[C - 1][s] = v[s]; tail[C - 1][s] = v[8 + s]; }
+            }
         }
+        // this frame's second halves -> my exchange region (idle between transforms), [c][s][lane]
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ex[(c * 8 + s) * 64 + lane_id] = tail[c][s];
         __syncthreads();
-        for (int i = tid; i < N * C; i += 256) {
-            const int sidx = i / C, c = i - sidx * C;
-            float prev = tails[c * N + sidx];
-            for (int df = 0; df < FI; ++df) {
-                const int64_t h = t0 + df;                     // hop fed by the first half of frame t0+df
-                const float* fr = reinterpret_cast<const float*>(ex_all + (df * C + c) * kExPitch);
-                const float v = (prev + fr[sidx]) * inv_n;
-                prev = fr[N + sidx];
-                if (h < h0 || h > h1) continue;
-                const int64_t n = h * N - a.trim + sidx;
-                if (n < 0 || n >= a.n_out) continue;
-                float* dst = a.out + (a.out_offset + n) * C + c;
-                if (a.accumulate_weighted) {
-                    const float w = segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later);
-                    *dst += w * v;
+        // hop t = my heads + the second halves of frame t - 1 (my left neighbour's; wave 0: the carry of the last round)
+        const float2* prev = wave > 0 ? ex - kExPitch : carry;
+        const bool emit = t >= h0 && t <= h_last;                       // wave-uniform
+        if (emit) {
+            const int64_t n_base = t * N - a.trim;                       // output sample of the hop's first sample
+            int lane = lane_id;                                          // opaque: no per-slot addresses kept across rounds
+            asm volatile("" : "+v"(lane));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float o[C][2];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float2 p = prev[(c * 8 + s) * 64 + lane];
+                    o[c][0] = (head[c][s].x + p.x) * inv_n * a.scale;
+                    o[c][1] = (head[c][s].y + p.y) * inv_n * a.scale;
+                }
+                const int64_t n0 = n_base + 2 * (lane + 64 * s);          // samples n0, n0 + 1
+                float* dst = a.out + (a.out_offset + n0) * C;
+                if (n0 >= 0 && n0 + 1 < a.n_out) {
+                    float w0 = 1.f, w1 = 1.f;
+                    if (mode != 0) { w0 = weight(n0); w1 = weight(n0 + 1); }
+                    if constexpr (C == 2) {
+                        Float4A* q = reinterpret_cast<Float4A*>(dst);
+                        Float4A r{o[0][0], o[1][0], o[0][1], o[1][1]};
+                        if (mode == 1) { const Float4A old = *q; r = Float4A{old.x + w0 * r.x, old.y + w0 * r.y, old.z + w1 * r.z, old.w + w1 * r.w}; }
+                        else if (mode == 2) r = Float4A{w0 * r.x, w0 * r.y, w1 * r.z, w1 * r.w};
+                        *q = r;
+                    } else {
+                        Float2A* q = reinterpret_cast<Float2A*>(dst);
+                        Float2A r{o[0][0], o[0][1]};
+                        if (mode == 1) { const Float2A old = *q; r = Float2A{old.x + w0 * r.x, old.y + w1 * r.y}; }
+                        else if (mode == 2) r = Float2A{w0 * r.x, w1 * r.y};
+                        *q = r;
+                    }
                 } else {
-                    *dst = v;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {                       // the first and the last hop of a clip or segment
+                        const int64_t n = n0 + e;
+                        if (n < 0 || n >= a.n_out) continue;
+                        const float w = mode != 0 ? weight(n) : 1.f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            float* q = dst + e * C + c;
+                            if (mode == 1) *q += w * o[c][e];
+                            else *q = w * o[c][e];
+                        }
+                    }
                 }
             }
-            tails[c * N + sidx] = prev;
         }
         __syncthreads();
+        if (wave == kInvWaves - 1) {                                    // the next round's first frame follows mine
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) carry[(c * 8 + s) * 64 + lane_id] = tail[c][s];
+        }
     }
 }
 
@@ -463,7 +532,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 
 bool reg_fft_supported(int W, int n_channels, bool inverse) {
     // forward: the wave kernel is the default for mono and stereo clips (cfg 2 / 3 / 4 / 5: 0.095 / 0.62 / 0.099 / 0.795 ms
-    // with the block kernels -> 0.084 / 0.54 / 0.074 / 0.755); inverse: the block kernel stays the default.
+    // with the block kernels -> 0.084 / 0.54 / 0.074 / 0.755); inverse: the block kernel stays the default -- the
+    // wave-per-frame inverse above measures 0.071 / 0.598 / 0.064 / 0.699 ms against 0.072 / 0.620 / 0.060 / 0.608.
     // REPET_FFT_PATH=block | wave: the LDS Stockham kernels of stft.hip for everything; =reg: both kernels of this file,
     // any channel count they take; =fwd: the forward one only.
     static const int mode = [] {
@@ -472,14 +542,10 @@ bool reg_fft_supported(int W, int n_channels, bool inverse) {
         return e[0] == 'r' ? 3 : e[0] == 'f' ? 1 : 0;
     }();
     if (W != 2 * kRegN) return false;
-    if (inverse) return (mode & 2) && (n_channels == 1 || n_channels == 2 || n_channels == 4);
+    if (inverse) return (mode & 2) && (n_channels == 1 || n_channels == 2);
     if (mode & 4) return n_channels == 1 || n_channels == 2;
     return (mode & 1) && n_channels >= 1;
 }
-
-// Both kernels keep 3 workgroups (12 wavefronts) per CU; the work per wave / per workgroup is sized so that the
-// whole launch is one well-filled round of those slots.
-constexpr int64_t kRegSlots = 256 * 3;
 
 hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s) {
     const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
@@ -503,14 +569,32 @@ hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t s) {
-    const int C = a.n_channels, FI = 4 / C;
     const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
-    int64_t want = ceil_div(hops * batches, kRegSlots);
-    want = want < 7 ? 7 : (want > 31 ? 31 : want);
-    const int run = (int)round_up(want + 1, FI) - 1;        // + the frame before = a whole number of rounds
-    const size_t dyn = (size_t)(4 * kExPitch + kTwFloat2) * sizeof(float2) + (size_t)C * kRegN * sizeof(float);
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_reg_kernel), (int)dyn);
-    hipLaunchKernelGGL(istft_ola_reg_kernel, dim3((unsigned)ceil_div(hops, run), (unsigned)batches), dim3(256), dyn, s, a, run);
+    const int64_t lim = (int64_t)1 << 30;
+    if (a.accumulate_weighted && (a.n_out >= lim || a.batch_out_stride >= lim || a.overlap >= lim || a.fade_in >= lim || a.fade_out >= lim))
+        return hipErrorNotSupported;                   // cross-fade positions beyond 32 bits: the block kernel
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop{};
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
+    // a workgroup of R rounds emits 12 R - 1 hops (its first wave repeats the frame before the run): R is chosen for the
+    // fewest rounds of workgroups x rounds inside them
+    int rounds = 1;
+    double best = 0;
+    for (int R = 1; R <= 16; ++R) {
+        const int64_t wgs = ceil_div(hops, kInvWaves * R - 1) * batches;
+        const double cost = (double)ceil_div(wgs, cus) * (R + 0.3);
+        if (R == 1 || cost < best * 0.98) { best = cost; rounds = R; }
+    }
+    const unsigned blocks = (unsigned)ceil_div(hops, kInvWaves * rounds - 1);
+    const size_t dyn = (size_t)kInvLdsFloat2 * sizeof(float2);
+    auto go = [&](auto kernel) {
+        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)dyn);
+        hipLaunchKernelGGL(kernel, dim3(blocks, (unsigned)batches), dim3(64 * kInvWaves), dyn, s, a, rounds);
+    };
+    if (a.n_channels == 2) { if (a.M) go(&istft_ola_reg_kernel<2, true>); else go(&istft_ola_reg_kernel<2, false>); }
+    else { if (a.M) go(&istft_ola_reg_kernel<1, true>); else go(&istft_ola_reg_kernel<1, false>); }
     return hipGetLastError();
 }
 
