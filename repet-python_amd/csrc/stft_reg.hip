@@ -428,25 +428,38 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
             if (have) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
                 const float* Mr = MASKED ? a.M + c * a.chan_stride + t * a.FS : nullptr;
-                // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D
+                // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D. All loads of a
+                // half (of the whole transform without a mask plane) are issued before the first is consumed: in batches
+                // of four the transform waited for memory four times over
+                constexpr int kHalf = MASKED ? 8 : 16;
 #pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) {
-                    const int k = 64 * n1 + lane;
-                    float2 xk = Y[k];
-                    float2 xc = Y[N - k];
-                    if constexpr (MASKED) {
-                        const float mk = Mr[k], mc = Mr[N - k];
-                        xk = make_float2(mul_rounded(xk.x, mk), mul_rounded(xk.y, mk));
-                        xc = make_float2(mul_rounded(xc.x, mc), mul_rounded(xc.y, mc));
+                for (int h0_ = 0; h0_ < 16; h0_ += kHalf) {
+                    float2 xk[kHalf], xc[kHalf];
+                    float mk[MASKED ? kHalf : 1], mc[MASKED ? kHalf : 1];
+#pragma unroll
+                    for (int j = 0; j < kHalf; ++j) {
+                        const int k = 64 * (h0_ + j) + lane;
+                        xk[j] = Y[k];
+                        xc[j] = Y[N - k];
+                        if constexpr (MASKED) { mk[j] = Mr[k]; mc[j] = Mr[N - k]; }
                     }
-                    xc = cconj(xc);
-                    const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
-                    const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
-                    const float2 w = split_lds[k];
-                    const float ox = fmaf(d.x, w.x, -mul_rounded(d.y, w.y));
-                    const float oy = fmaf(d.x, w.y, mul_rounded(d.y, w.x));
-                    v[n1] = make_float2(e.x - oy, e.y + ox);
-                    if ((n1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four points' loads in flight, not sixteen
+#pragma unroll
+                    for (int j = 0; j < kHalf; ++j) {
+                        const int k = 64 * (h0_ + j) + lane;
+                        float2 a_ = xk[j], b_ = xc[j];
+                        if constexpr (MASKED) {
+                            a_ = make_float2(mul_rounded(a_.x, mk[j]), mul_rounded(a_.y, mk[j]));
+                            b_ = make_float2(mul_rounded(b_.x, mc[j]), mul_rounded(b_.y, mc[j]));
+                        }
+                        b_ = cconj(b_);
+                        const float2 e = make_float2(0.5f * (a_.x + b_.x), 0.5f * (a_.y + b_.y));
+                        const float2 d = make_float2(0.5f * (a_.x - b_.x), 0.5f * (a_.y - b_.y));
+                        const float2 w = split_lds[k];
+                        const float ox = fmaf(d.x, w.x, -mul_rounded(d.y, w.y));
+                        const float oy = fmaf(d.x, w.y, mul_rounded(d.y, w.x));
+                        v[h0_ + j] = make_float2(e.x - oy, e.y + ox);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 wave_fft1024<true>(v, ex, tw, lane);
@@ -531,10 +544,11 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
 }  // namespace
 
 bool reg_fft_supported(int W, int n_channels, bool inverse) {
-    // forward: the wave kernel is the default for mono and stereo clips (cfg 2 / 3 / 4 / 5: 0.095 / 0.62 / 0.099 / 0.795 ms
-    // with the block kernels -> 0.084 / 0.54 / 0.074 / 0.755); inverse: the block kernel stays the default -- the
-    // wave-per-frame inverse above measures 0.071 / 0.598 / 0.064 / 0.699 ms against 0.072 / 0.620 / 0.060 / 0.608.
-    // REPET_FFT_PATH=block | wave: the LDS Stockham kernels of stft.hip for everything; =reg: both kernels of this file,
+    // Both wave kernels are the default for mono and stereo clips at W = 2048 (cfg 2 / 3 / 4 / 5, block kernels -> these:
+    // forward 0.095 / 0.62 / 0.099 / 0.795 ms -> 0.084 / 0.54 / 0.074 / 0.755; inverse 0.071 / 0.603 / 0.059 / 0.604 ->
+    // 0.058 / 0.481 / 0.054 / 0.537 -- the inverse only once ALL loads of a transform were issued before the first is
+    // consumed: in batches of four it was no faster than the block kernel).
+    // REPET_FFT_PATH=block | wave: the LDS Stockham kernels of stft.hip for everything; =reg: both kernels of this file for
     // any channel count they take; =fwd: the forward one only.
     static const int mode = [] {
         const char* e = getenv("REPET_FFT_PATH");
@@ -542,7 +556,7 @@ bool reg_fft_supported(int W, int n_channels, bool inverse) {
         return e[0] == 'r' ? 3 : e[0] == 'f' ? 1 : 0;
     }();
     if (W != 2 * kRegN) return false;
-    if (inverse) return (mode & 2) && (n_channels == 1 || n_channels == 2);
+    if (inverse) return (mode & 6) && (n_channels == 1 || n_channels == 2);
     if (mode & 4) return n_channels == 1 || n_channels == 2;
     return (mode & 1) && n_channels >= 1;
 }
