@@ -249,13 +249,14 @@ def main():
                                             "k_mean": round(k_mean, 2), "note": "gathers are served by L2 / Infinity Cache" + ("; the rank path moves 2 bytes per gathered value, not 4" if rank_path else "")}
                 # short lists (simonline: about ten similar frames): the network is a few dozen instructions and the stage is
                 # bound by what MUST cross HBM -- V read once (the gathers re-read it from cache), X read and written
-                compulsory = (4.0 + 16.0) * F * rows * C * (args.clips if batched else 1)
+                # (the engine's figure = V + gathers + what it writes: 16 bytes with X masked in place, 4 with the mask as a plane)
+                compulsory = meta["bytes"] - 4.0 * params.sim_number * F * rows * C * (args.clips if batched else 1)
                 if compulsory / (HBM_PEAK_GBS * 1e9) > net_instr * waves / (VALU_QUARTER_RATE_GINSTR * 1e9):
                     entry["valu_view"] = {k: entry[k] for k in ("achieved", "peak", "unit", "frac")}
                     ach = compulsory / sec / 1e9
                     entry.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic": compulsory,
-                                  "note": "compulsory bytes 4FTC (V) + 16FTC (X in place); the network is too short to bind"})
+                                  "note": "compulsory bytes: V once + the mask plane (or X in place); the network is too short to bind"})
             elif meta["flops"] > 0 and "f16x3" in name:
                 # f16-split matrix-core kernel: three f16 MFMA products per fp32 term, fp32 accumulate. Priced on EXECUTED
                 # f16 flops against the dense f16 MFMA peak; the fp32-equivalent algorithmic rate is stated beside it.

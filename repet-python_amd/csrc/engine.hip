@@ -364,17 +364,19 @@ bool split_in_stft() {
     return on && gram_f16_enabled();
 }
 
-// The period mask of `original` / `extended` reads V, reads X and writes X: 20 bytes per cell, and the inverse STFT reads
-// X again. With the mask as a plane of its own the mask kernel writes 4 bytes and the inverse STFT multiplies while it
-// fetches (8 + 4): 20 instead of 28 bytes per cell over the two stages, the same products bit for bit (mul_rounded).
-// Measured (mask + inverse, ms): extended cfg 3 0.414 + 0.491 -> 0.243 + 0.571; adaptive cfg 4 0.075 + 0.061 -> 0.059 +
-// 0.082; simonline cfg 5 0.776 + 0.608 -> 0.600 + 0.765; sim cfg 2 (selection-bound mask) 0.50 + 0.072 -> 0.50 + 0.091 --
-// the inverse kernel pays for its extra loads what the byte count says, so only the period mask gains: that is the
-// default. REPET_MASK_PLANE=0 / 1: never / in every variant.
+// The mask kernels read V, read X and write X: 20 bytes per cell, and the inverse STFT reads X again. With the mask as a
+// plane of its own they write 4 bytes and the inverse STFT multiplies while it fetches (8 + 4): 20 instead of 28 bytes per
+// cell over the two stages, the same products bit for bit (mul_rounded). The inverse kernel pays for its extra loads
+// about what the byte count says, so it depends on the mask kernel whether the sum gains (mask + inverse, ms, same box):
+//   extended cfg 3 (period mask, HBM-bound)      0.415 + 0.461 -> 0.249 + 0.498   default: plane
+//   simonline cfg 5 (ten similar frames: HBM)    0.763 + 0.544 -> 0.603 + 0.608   default: plane
+//   adaptive cfg 4                                0.077 + 0.055 -> 0.060 + 0.068   default: in place
+//   sim cfg 2 (selection-bound mask)              0.50 + 0.072 -> 0.50 + 0.091     default: in place
+// REPET_MASK_PLANE=0 / 1: never / in every variant.
 enum class MaskKind { period, adaptive, sim_float, sim_ranks };
 bool mask_plane_wanted(MaskKind kind) {
     static const int forced = [] { const char* e = getenv("REPET_MASK_PLANE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced != 0 : kind == MaskKind::period;
+    return forced >= 0 ? forced != 0 : (kind == MaskKind::period || kind == MaskKind::sim_float);
 }
 
 struct MaskPlaneScope {            // the choice holds for one pipeline; stage exports and the streaming handle never see it
@@ -835,7 +837,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         }
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
                                 c->fork_event, c->join_event));
-        mark(c, "mask_sim", (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
+        mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     } else {
         // Peak picking is LDS/latency-bound, the median mask VALU-bound: run them as a two-stage pipeline over
         // row chunks -- chunk k+1 is picked on the side stream while chunk k is masked on the main stream.
@@ -866,7 +868,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->side_stream, nullptr, nullptr, nullptr, 2));
         HIP_TRY(hipEventRecord(c->join_event, c->side_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->join_event, 0));
-        mark(c, "peaks+mask", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 * K + 16.0) * g.F * T * g.C, 0);
+        mark(c, "peaks+mask", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     }
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = KP; c->last_idx_number = K;
@@ -913,7 +915,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     m.n_batch = nb; m.batch_stride = spec_stride; m.idx_batch_stride = rows_alloc * KP; m.cnt_batch_stride = rows_alloc;
     HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream, c->side_stream,
                             c->fork_event, c->join_event));
-    mark(c, "mask_sim", nb * (4.0 + 4.0 * K + 16.0) * g.F * (double)rows * g.C, 0);
+    mark(c, "mask_sim", nb * (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * (double)rows * g.C, 0);
     if (nb == 1) {
         RP_TRY(run_istft(c, g, tb, 0, N, 0, false, 0, 0));
     } else {

@@ -147,6 +147,9 @@ __device__ __forceinline__ float lane_fetch(float x, int src_lane) {
 // twelve independent load -> FFT -> store chains per CU instead of three barrier-coupled ones.
 // Stereo clips arrive as [n][2] floats: samples 2n and 2n+1 of both channels are ONE float4 per lane, fetched once per
 // frame (the block kernels and the first version of this one read 4-byte elements 16 bytes apart).
+#ifndef REPET_FWD_SPLIT_BATCH
+#define REPET_FWD_SPLIT_BATCH 4
+#endif
 constexpr int kFwdWaves = 12;
 constexpr int kFwdLdsFloat2 = kFwdWaves * kExPitch + kTwFloat2 + 2 * kRegN;      // + window [N] + split twiddles [N]
 
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
                 Xrow[k] = x;
                 Vrow[k] = mag;
                 acc[s] += mag;
-                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four bins in flight, not sixteen
+                if ((s & (REPET_FWD_SPLIT_BATCH - 1)) == REPET_FWD_SPLIT_BATCH - 1) __builtin_amdgcn_sched_barrier(0);    // a few bins in flight, not sixteen
             }
             {   // k = N (Nyquist): Z[N & (N-1)] = Z[0] on both sides, W_2048^N = -1
                 const float z0x = __shfl(v[0].x, 0), z0y = __shfl(v[0].y, 0);
