@@ -35,6 +35,10 @@ struct StftArgs {
     // (nullable) the f16 hi / lo planes of Vn for the f16-split Gram kernels (gram_f16.hip: [row][FS/32][hi 32 | lo 32],
     // scale 2^7), written beside Vn so that no separate split pass reads Vn again; clips batch_mean_stride * 2 halves apart
     void* Vh;
+    // (nullable, stft_reg.hip only) the f16 planes of P = Vm^2 scaled ROW BY ROW for the banded Gram of the beat spectrum
+    // (what split_f16_rows_kernel makes of P) and the inverse scale of every row: the wave that owns a frame has the whole
+    // row in registers, so neither the fp32 P nor a second pass over it is needed
+    void* Ph; float* Ph_inv; int64_t batch_inv_stride;
     // batch of equal-length clips (segments of `extended`): blockIdx.y = b
     int32_t n_batch; int64_t batch_sample_stride; // samples between the starts of consecutive clips
     int64_t batch_spec_stride;                    // elements between clips in X and V (= C*chan_stride)
@@ -80,6 +84,23 @@ __device__ __forceinline__ float segment_weight32(int n, int fade_in, int overla
         }
     }
     return w;
+}
+
+// The power of two that brings a row's largest magnitude m to [2^13, 2^14) (gram_f16.hip: rows of a general matrix are
+// scaled one by one for the f16 split; exact to apply and to remove).
+__device__ __forceinline__ float f16_row_scale(float m) {
+    if (!(m > 0.f) || !(m < INFINITY)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1
+    return ldexpf(1.f, 14 - e);
+}
+// one component x of such a row into the two f16 planes (the arithmetic of split4, gram_f16.hip)
+__device__ __forceinline__ void store_split_f16_scaled(void* planes, int64_t e, float x, float sc) {
+    _Float16* p = static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31);
+    const float v = x * sc;
+    const _Float16 h = (_Float16)v;
+    p[0] = h;
+    p[32] = (_Float16)(v - (float)h);
 }
 
 // one component of a unit row into the two f16 planes (the arithmetic of split_f16_kernel, gram_f16.hip)

@@ -267,23 +267,32 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
 }
 // unit_rows: A holds unit vectors (the similarity band of simonline), safe for the f16-split kernel; the beat-spectrum
 // bands (power spectra, wide dynamic range) stay on the exact-fp32 one. B clips: a_stride / band_stride in elements.
+// does the banded Gram of power spectra (beat spectrum) run on the f16-split kernel with row-scaled planes?
+bool band_rows_on_f16(repet_ctx* c, int64_t T, int FS, int n_lags, int B, int64_t a_stride) {
+    static const bool scaled = [] { const char* e = getenv("REPET_GRAM_BAND"); return !(e && e[0] == 'f' && e[1] == '3'); }();
+    const int2* tiles; int n;
+    if (get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n) != REPET_OK) return false;
+    return scaled && gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS);
+}
+
 int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP, bool unit_rows = false,
                   int B = 1, int64_t a_stride = 0, int64_t band_stride = 0, bool planes_ready = false) {
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
-    static const bool scaled = [] { const char* e = getenv("REPET_GRAM_BAND"); return !(e && e[0] == 'f' && e[1] == '3'); }();
     // power spectra (beat spectrum): any range, so the split is scaled by the matrix's largest magnitude. Two extra
     // passes over the matrix (max, split): worth it from about two rounds of tiles on (the batched segments of
     // `extended`: 0.58 -> 0.43 ms at cfg 3), not for one clip's narrow band (0.16 -> 0.17 ms at cfg 2 / cfg 4 sizes)
     c->band_on_f16 = false;
-    if (!unit_rows && scaled && gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS)) {
+    if (!unit_rows && band_rows_on_f16(c, T, FS, n_lags, B, a_stride)) {
         c->band_on_f16 = true;
         const int64_t per_clip = round_up(T, kTile) * FS;
         const int64_t count = per_clip * B;
-        HIP_TRY(c->Vh.ensure((size_t)count * 4));
         const int64_t rows_per_clip = round_up(T, kTile);
-        HIP_TRY(c->amax.ensure((size_t)rows_per_clip * B * sizeof(float)));          // one inverse scale per row
-        HIP_TRY(launch_split_f16_rows(A, c->Vh.p, rows_per_clip * B, FS, c->amax.as<float>(), c->stream));
+        if (!planes_ready) {                                                         // (else: written by the STFT itself)
+            HIP_TRY(c->Vh.ensure((size_t)count * 4));
+            HIP_TRY(c->amax.ensure((size_t)rows_per_clip * B * sizeof(float)));      // one inverse scale per row
+            HIP_TRY(launch_split_f16_rows(A, c->Vh.p, rows_per_clip * B, FS, c->amax.as<float>(), c->stream));
+        }
         HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream,
                                      c->amax.as<float>(), rows_per_clip));
         return REPET_OK;
@@ -417,13 +426,14 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
 }
 
 int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64_t n, int centred, bool vn, bool p,
-             int B = 1, int64_t batch_sample_stride = 0) {
+             int B = 1, int64_t batch_sample_stride = 0, bool p_as_planes = false) {
     StftArgs a{};
     a.audio = c->audio.as<float>(); a.n_samples = n; a.n_channels = g.C; a.sample_offset = c->clip_base + offset;
     a.window = tb->window.as<float>(); a.twiddle = tb->twiddle.as<float2>();
     a.W = g.W; a.H = g.H; a.T = g.T; a.FS = g.FS; a.centred = centred;
     a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
-    a.Vm = nullptr; a.Vn = vn ? c->Vn.as<float>() : nullptr; a.P = p ? c->P.as<float>() : nullptr;
+    a.Vm = nullptr; a.Vn = vn ? c->Vn.as<float>() : nullptr; a.P = (p && !p_as_planes) ? c->P.as<float>() : nullptr;
+    if (p_as_planes) { a.Ph = c->Vh.p; a.Ph_inv = c->amax.as<float>(); a.batch_inv_stride = g.Tpad; }
     a.Vh = (vn && split_in_stft()) ? c->Vh.p : nullptr;
     a.n_batch = B; a.batch_sample_stride = batch_sample_stride; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
     a.batch_mean_stride = g.Tpad * g.FS;
@@ -468,13 +478,28 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
     const int hi = (int)std::min<int64_t>(p->period_hi, T / 3);
     if (hi <= p->period_lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence (clip too short for the period range)");
-    RP_TRY(ensure_spectra(c, g, false, true, B));
-    RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true, B, hop));
     const int LP = (int)round_up(hi, 64);
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP;
+    // When the beat spectrum's Gram runs on the f16-split kernel (many segments) and the forward STFT is the
+    // wave-per-frame kernel, the wave that owns a frame writes the row-scaled f16 planes of P itself: no fp32 P, no
+    // second pass over it (extended 600 s: 0.34 -> 0.24 ms for the Gram stage). REPET_P_PLANES=0: the separate pass.
+    static const bool p_planes_on = [] { const char* e = getenv("REPET_P_PLANES"); return !(e && e[0] == '0'); }();
+    const bool p_planes = p_planes_on && g.Tpad == round_up(T, kTile) && reg_fft_supported(g.W, g.C, false) &&
+                          band_rows_on_f16(c, T, g.FS, hi, B, mean_stride);
+    RP_TRY(ensure_spectra(c, g, false, !p_planes, B));
+    if (p_planes) {
+        HIP_TRY(c->Vh.ensure((size_t)B * mean_stride * 4));
+        HIP_TRY(c->amax.ensure((size_t)B * g.Tpad * sizeof(float)));
+        if (g.Tpad > T) {           // rows [T, Tpad) of every segment: zero planes, inverse scale 1 (what the pass makes of zero rows)
+            HIP_TRY(hipMemset2DAsync(static_cast<char*>(c->Vh.p) + (size_t)T * g.FS * 4, (size_t)mean_stride * 4, 0,
+                                     (size_t)(g.Tpad - T) * g.FS * 4, (size_t)B, c->stream));
+        }
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->amax.p), 0x3f800000, (size_t)B * g.Tpad, c->stream));
+    }
+    RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true, B, hop, p_planes));
     HIP_TRY(c->band.ensure((size_t)B * band_stride * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)B * LP * sizeof(float)));
-    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, false, B, mean_stride, band_stride));
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, false, B, mean_stride, band_stride, p_planes));
     mark(c, c->band_on_f16 ? "gram_band_f16x3" : "gram_band", B * (4.0 * g.F * T + 4.0 * T * hi), B * 2.0 * g.F * T * hi);
     RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, hi, g.F, 0, 0, T, 1, c->beat.as<float>(), LP, B, band_stride, LP));
     HIP_TRY(launch_periods(c->beat.as<float>(), B, LP, (int)T, p->period_lo, p->period_hi, period_slots, c->stream));

@@ -49,12 +49,7 @@ constexpr float kSplitScale = 128.0f;          // 2^7
 // epilogue multiplies entry (i, j) by inv[i] * inv[j]). One scale for the whole matrix would flush a passage 60-100 dB
 // below the loudest one to f16 zeros -- for a power spectrum that is 30-50 dB of level -- and hand its frames an all-zero
 // beat spectrum. Unit rows (row_inv == null) use the fixed 2^7.
-__device__ __forceinline__ float row_scale(float m) {
-    if (!(m > 0.f) || !(m < INFINITY)) return 1.f;
-    int e;
-    (void)frexpf(m, &e);                       // m = f * 2^e, 0.5 <= f < 1
-    return ldexpf(1.f, 14 - e);
-}
+__device__ __forceinline__ float row_scale(float m) { return f16_row_scale(m); }
 
 __device__ __forceinline__ void split4(const float4 x, float sc, _Float16* __restrict__ planes, int64_t i) {
     const float v[4] = {x.x * sc, x.y * sc, x.z * sc, x.w * sc};

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
     const RegTwiddles tw{tw_lds, tw_lds + 16 * 64};
     __syncthreads();
     RSTAMP(0)
-    const bool want_mean = a.Vm || a.Vn || a.P;
+    const bool want_mean = a.Vm || a.Vn || a.P || a.Ph;
     // round k of the launch: workgroup b's twelve waves take the twelve CONSECUTIVE frames (k gridDim + b) 12 + wave, so
     // the half frame two neighbours share is asked for by the same CU at about the same time
     const int64_t stride = (int64_t)gridDim.x * kFwdWaves;
@@ -363,6 +363,24 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             if (Vn) Vn[N + 1 + lane] = 0.f;
             if (Vh) store_split_f16(Vh, row + N + 1 + lane, 0.f);
             if (P) P[N + 1 + lane] = 0.f;
+        }
+        if (a.Ph) {
+            // the squared row straight into the row-scaled f16 planes (split_f16_rows_kernel's arithmetic on the same values)
+            float mx = 0.f;
+#pragma unroll
+            for (int s = 0; s < 17; ++s) if (s < 16 || lane == 0) mx = fmaxf(mx, acc[s] * acc[s]);      // fmaxf drops NaN
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            const float sc = f16_row_scale(mx);
+            void* Ph = static_cast<void*>(static_cast<_Float16*>(a.Ph) + 2 * b * a.batch_mean_stride);
+            if (lane == 0) a.Ph_inv[b * a.batch_inv_stride + t] = 1.0f / sc;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                store_split_f16_scaled(Ph, row + lane + 64 * s, acc[s] * acc[s], sc);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane == 0) store_split_f16_scaled(Ph, row + N, acc[16] * acc[16], sc);
+            if (lane < a.FS - (N + 1)) store_split_f16_scaled(Ph, row + N + 1 + lane, 0.f, sc);
         }
         RSTAMP(4)                                      // mean rows
     }

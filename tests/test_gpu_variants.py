@@ -444,6 +444,32 @@ def test_mask_plane_gives_the_same_bits():
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
 
 
+@pytest.mark.slow
+def test_power_planes_from_the_stft_give_the_same_bits():
+    """extended with enough segments for the f16-split banded Gram (>= 512 tiles: a 400-s clip): the row-scaled f16 planes
+    of the power spectra written by the forward STFT's own waves (default) against the separate pass over an fp32 P
+    (REPET_P_PLANES=0). The same values are split by the same arithmetic, so periods and output must be identical."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "x = synth(400.0, 44100, 2, 17); p = repet.derive_params(44100); c = repet.Context(0); c.upload(x); "
+            "tm = c.execute('extended', p, timing=True); y = c.download(); per = c.last_periods(256); "
+            "np.savez(sys.argv[1], y=y, per=per, stages=np.array([s['name'] for s in tm['stages']]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for planes in ("1", "0"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_pplanes_{planes}_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_P_PLANES=planes))
+        with np.load(out) as z:
+            outs.append({k: z[k] for k in z.files})
+        os.remove(out)
+    assert "gram_band_f16x3" in outs[0]["stages"].tolist()            # the path under test really ran
+    assert np.array_equal(outs[0]["per"], outs[1]["per"])
+    assert np.array_equal(outs[0]["y"], outs[1]["y"])
+
+
 def test_gram_paths_agree():
     """sim's similarity matrix: the f16-split matrix-core kernel (default) against the exact-fp32 one (REPET_GRAM=f32).
     Same similar-frame lists (the float64 refinement settles every near-tie either way), outputs equal to fp32 noise."""
