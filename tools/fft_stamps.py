@@ -20,18 +20,18 @@ if hasattr(lib, "repet_debug_reg_stamps"): lib.repet_debug_reg_stamps(buf, 1)
 ctx.execute(algo, p)
 print("rc", lib.repet_debug_fft_stamps(buf, 0), algo, ctx.stage_times() if hasattr(ctx, "stage_times") else "")
 a = np.array(buf[:], dtype=np.int64).reshape(2, 8, 8)
-print("stft_pair_kernel (4 stereo frames per workgroup):")
-for row in a[0]:
+if a[0].any(): print("stft_pair_kernel (block kernel, REPET_FFT_PATH=block; a run of stereo frames per workgroup):")
+for row in (a[0] if a[0].any() else []):
     print("  prologue %6d | wait+window %6d  fetch+barrier %6d  fft %6d  split+stores %6d  mean+norm %6d  rows stored %6d | total %7d" % (
         row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[:7].sum()))
-print("istft_ola_kernel (run of 8 or 16 hops x channels per workgroup):")
-for row in a[1]:
+if a[1].any(): print("istft_ola_kernel (block kernel; a run of hops x channels per workgroup):")
+for row in (a[1] if a[1].any() else []):
     print("  prologue %6d  frame before %6d | fetch+repack+fft %7d  combine %6d  hop out %6d | total %7d" % (
         row[0], row[1], row[2], row[3], row[4], row[:5].sum()))
 
-if os.environ.get("REPET_FFT_PATH", "")[:1] in ("r", "f"):
+if hasattr(lib, "repet_debug_reg_stamps"):
     lib.repet_debug_reg_stamps(buf, 0)
     a = np.array(buf[:64], dtype=np.int64).reshape(8, 8)
-    print("stft_reg_kernel (one wave, its frames x channels):")
-    for row in a:
+    if a.any(): print("stft_reg_kernel (wave-per-frame forward kernel, the default at W = 2048; one wave, its frames x channels):")
+    for row in (a if a.any() else []):
         print("  prologue %6d | loads waited %7d  fft %7d  split+stores %7d  mean rows %7d | total %7d" % (row[0], row[1], row[2], row[3], row[4], row[:5].sum()))
