@@ -283,7 +283,7 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
     // passes over the matrix (max, split): worth it from about two rounds of tiles on (the batched segments of
     // `extended`: 0.58 -> 0.43 ms at cfg 3), not for one clip's narrow band (0.16 -> 0.17 ms at cfg 2 / cfg 4 sizes)
     c->band_on_f16 = false;
-    if (!unit_rows && band_rows_on_f16(c, T, FS, n_lags, B, a_stride)) {
+    if (!unit_rows && (planes_ready || band_rows_on_f16(c, T, FS, n_lags, B, a_stride))) {
         c->band_on_f16 = true;
         const int64_t per_clip = round_up(T, kTile) * FS;
         const int64_t count = per_clip * B;
@@ -470,6 +470,23 @@ int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_
 // ---- original on B equal-length clips of the resident signal: clip b covers samples
 // [offset + b*hop, offset + b*hop + n). B = 1, hop = 0 is repet.original itself; B > 1 are segments
 // seg_first .. seg_first+B-1 of `extended` (of seg_total), whose outputs are cross-faded into c->out.
+// The forward STFT's waves write the row-scaled f16 planes of the power spectra themselves (stft_reg.hip): workspace, the
+// pad rows of every clip (zero planes, inverse scale 1: what the separate pass makes of zero rows).
+int prepare_power_planes(repet_ctx* c, const Geo& g, int64_t T, int B) {
+    const int64_t mean_stride = g.Tpad * g.FS;
+    HIP_TRY(c->Vh.ensure((size_t)B * mean_stride * 4));
+    HIP_TRY(c->amax.ensure((size_t)B * g.Tpad * sizeof(float)));
+    if (g.Tpad > T)
+        HIP_TRY(hipMemset2DAsync(static_cast<char*>(c->Vh.p) + (size_t)T * g.FS * 4, (size_t)mean_stride * 4, 0,
+                                 (size_t)(g.Tpad - T) * g.FS * 4, (size_t)B, c->stream));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->amax.p), 0x3f800000, (size_t)B * g.Tpad, c->stream));
+    return REPET_OK;
+}
+bool power_planes_enabled() {
+    static const bool on = [] { const char* e = getenv("REPET_P_PLANES"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n, int B, int64_t hop,
                  int32_t* period_slots, bool weighted, int seg_first, int seg_total, int64_t overlap) {
     Tables* tb = nullptr;
@@ -483,19 +500,10 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     // When the beat spectrum's Gram runs on the f16-split kernel (many segments) and the forward STFT is the
     // wave-per-frame kernel, the wave that owns a frame writes the row-scaled f16 planes of P itself: no fp32 P, no
     // second pass over it (extended 600 s: 0.34 -> 0.24 ms for the Gram stage). REPET_P_PLANES=0: the separate pass.
-    static const bool p_planes_on = [] { const char* e = getenv("REPET_P_PLANES"); return !(e && e[0] == '0'); }();
-    const bool p_planes = p_planes_on && g.Tpad == round_up(T, kTile) && reg_fft_supported(g.W, g.C, false) &&
-                          band_rows_on_f16(c, T, g.FS, hi, B, mean_stride);
+    const bool p_planes = power_planes_enabled() && gram_f16_enabled() && g.Tpad == round_up(T, kTile) && reg_fft_supported(g.W, g.C, false) &&
+                          (band_rows_on_f16(c, T, g.FS, hi, B, mean_stride) || (B == 1 && T >= 2048));   // (a long single clip: as in exec_adaptive)
     RP_TRY(ensure_spectra(c, g, false, !p_planes, B));
-    if (p_planes) {
-        HIP_TRY(c->Vh.ensure((size_t)B * mean_stride * 4));
-        HIP_TRY(c->amax.ensure((size_t)B * g.Tpad * sizeof(float)));
-        if (g.Tpad > T) {           // rows [T, Tpad) of every segment: zero planes, inverse scale 1 (what the pass makes of zero rows)
-            HIP_TRY(hipMemset2DAsync(static_cast<char*>(c->Vh.p) + (size_t)T * g.FS * 4, (size_t)mean_stride * 4, 0,
-                                     (size_t)(g.Tpad - T) * g.FS * 4, (size_t)B, c->stream));
-        }
-        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->amax.p), 0x3f800000, (size_t)B * g.Tpad, c->stream));
-    }
+    if (p_planes) RP_TRY(prepare_power_planes(c, g, T, B));
     RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true, B, hop, p_planes));
     HIP_TRY(c->band.ensure((size_t)B * band_stride * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)B * LP * sizeof(float)));
@@ -696,15 +704,21 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     const int hi = std::min(p->period_hi, Ls / 3);
     if (hi <= p->period_lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence (segment too short for the period range)");
     if (p->filter_order < 1) return fail(REPET_ERR_BAD_ARG, "adaptive: filter_order must be >= 1");
-    RP_TRY(ensure_spectra(c, g, false, true));
-    RP_TRY(run_stft(c, g, tb, 0, N, 1, false, true));
+    // One long clip's narrow band did not pay for the two extra passes of the f16 split (0.16 -> 0.17 ms at cfg 4); with the
+    // planes written by the forward STFT's own waves there are no extra passes. REPET_ADAPTIVE_F16=0: the fp32 MFMA kernel.
+    static const bool adaptive_f16 = [] { const char* e = getenv("REPET_ADAPTIVE_F16"); return !(e && e[0] == '0'); }();
+    const bool p_planes = adaptive_f16 && power_planes_enabled() && gram_f16_enabled() && g.Tpad == round_up(T, kTile) &&
+                          reg_fft_supported(g.W, g.C, false) && T >= 2048;
+    RP_TRY(ensure_spectra(c, g, false, !p_planes));
+    if (p_planes) RP_TRY(prepare_power_planes(c, g, T, 1));
+    RP_TRY(run_stft(c, g, tb, 0, N, 1, false, true, 1, 0, p_planes));
     const int LP = (int)round_up(hi, 64);
     const int n_win = (int)ceil_div(T, Hs);
     HIP_TRY(c->band.ensure((size_t)g.Tpad * LP * sizeof(float)));
     HIP_TRY(c->beat.ensure((size_t)n_win * LP * sizeof(float)));
     HIP_TRY(c->win_periods.ensure((size_t)n_win * sizeof(int32_t)));
     HIP_TRY(c->periods.ensure((size_t)T * sizeof(int32_t)));
-    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP));
+    RP_TRY(run_gram_band(c, c->P.as<float>(), T, g.FS, c->band.as<float>(), hi, LP, false, 1, 0, 0, p_planes));
     mark(c, c->band_on_f16 ? "gram_band_f16x3" : "gram_band", 4.0 * g.F * T + 4.0 * T * hi, 2.0 * g.F * T * hi);
     const int64_t left = (Ls - 1 + 1) / 2;    // ceil((Ls-1)/2), repet.py:1182
     RP_TRY(run_band_window_sum(c, c->band.as<float>(), T, LP, hi, g.F, -left, Hs, Ls, n_win, c->beat.as<float>(), LP, 1, 0, 0));
