@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--algo", default="sim")
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--scatter-limit", type=float, default=240.0, help="seconds the scatter/gather leg may take before it is given up")
     ap.add_argument("--clips", type=int, default=1, help="independent clips per rank and step (config 5: 64 in total)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5],
                     help="BASELINE.json configs[i-1]: 1 original on the reference's 23-s example clip (--wav, only where the "
@@ -205,11 +206,8 @@ def main():
 
     out = ctxs[-1].download()
     assert out.shape[-2:] == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
-    scatter = None
-    if not args.no_scatter and args.config == 2 and example_clip is None:
-        for ctx_ in ctxs[1:]:
-            ctx_.close()
-        scatter = scatter_gather_leg(dist, rank, world, local_rank, args.algo, fs, channels, args.duration, 8)
+    want_scatter = not args.no_scatter and args.config == 2 and example_clip is None
+    line = None
 
     if rank == 0:
         steps = max(args.steps, 1)                   # stage figures are per clip
@@ -330,10 +328,35 @@ def main():
             line["array_in_array_out"] = {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
                                           "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2),
                                           "note": "repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads narrow/widen through a pinned ring, fp32 over PCIe)" % args.algo}
-        if scatter is not None:
-            line["scatter_gather"] = scatter
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
+
+    # The multi-GPU data path (scatter -> separate -> gather over RCCL point-to-point) runs LAST and under a watchdog: the
+    # headline above must reach stdout whatever that leg does on a node it has never run on. A time-out or an exception on
+    # any rank ends every rank at once, rank 0 with the line (and the reason under "scatter_gather").
+    if want_scatter:
+        import threading
+
+        def bail(reason):
+            if rank == 0:
+                line["scatter_gather"] = {"error": reason}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.scatter_limit, bail, args=(f"no result within {args.scatter_limit:g} s",))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            for ctx_ in ctxs[1:]:
+                ctx_.close()
+            scatter = scatter_gather_leg(dist, rank, world, local_rank, args.algo, fs, channels, args.duration, 8)
+            if dist is not None:
+                dist.barrier()
+        except BaseException as exc:                 # noqa: BLE001 -- the other ranks wait in a collective: end them all
+            bail(f"{type(exc).__name__}: {exc}")
+        watchdog.cancel()
+        if rank == 0 and scatter is not None:
+            line["scatter_gather"] = scatter
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
