@@ -289,13 +289,14 @@ __global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const in
         // lower middle value >= own value  =>  median >= own value  =>  mask = (V + eps) / (V + eps) = 1: any model >= V
         // gives the same bits, so V itself stands in for it
         med0 = v_own.x; med1 = v_own.y;
-        if (lo0 < (own & 0xffffu)) {
-            med0 = vs[min(lo0 - kRankCodeBase, t_last)];
-            if (!(n & 1)) med0 = 0.5f * (med0 + vs[min((hi & 0xffffu) - kRankCodeBase, t_last)]);
-        }
-        if (lo1 < (own >> 16)) {
-            med1 = vs[a.vs_pitch + min(lo1 - kRankCodeBase, t_last)];
-            if (!(n & 1)) med1 = 0.5f * (med1 + vs[a.vs_pitch + min((hi >> 16) - kRankCodeBase, t_last)]);
+        // both bins' lookups behind ONE branch, all four loads issued before the first is used: a load inside a branch is
+        // waited for at its join, and two branches in a row were two table round trips per wave
+        const bool need0 = lo0 < (own & 0xffffu), need1 = lo1 < (own >> 16);
+        if (need0 || need1) {
+            const float a0 = vs[min(lo0 - kRankCodeBase, t_last)], b0 = vs[min((hi & 0xffffu) - kRankCodeBase, t_last)];
+            const float a1 = vs[a.vs_pitch + min(lo1 - kRankCodeBase, t_last)], b1 = vs[a.vs_pitch + min((hi >> 16) - kRankCodeBase, t_last)];
+            if (need0) med0 = (n & 1) ? a0 : 0.5f * (a0 + b0);
+            if (need1) med1 = (n & 1) ? a1 : 0.5f * (a1 + b1);
         }
     }
     const float m0 = soft_mask(v_own.x, med0, f0, a.cutoff), m1 = soft_mask(v_own.y, med1, f0 + 1, a.cutoff);
