@@ -175,6 +175,24 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
     return hipGetLastError();
 }
 
+// The row offsets of all network slots are computed ONCE in vector form -- lane l holds slots l and l + 64: the list entry
+// (one coalesced load of the whole list) times the row pitch, or the pad row of a slot past the list's end -- and handed to
+// the gathers through v_readlane. Written slot by slot ("k < n ? list[k] * row_bytes : pad") the compiler made a chain of
+// scalar branches with ONE s_load_dword + s_waitcnt per slot: 100 scalar-memory round trips in a row, 13 900 of a wave's
+// 30 400 cycles (tools/mask_spans.py).
+template <int NET>
+struct SlotOffsets {
+    int lo, hi;                     // byte offsets of slots lane and lane + 64
+    __device__ __forceinline__ SlotOffsets(const int* list, int n, int row_bytes, int pad_bytes, int lane) {
+        const int low_pads = (NET - n) >> 1;
+        const int e0 = list[lane], e1 = NET > 64 ? list[lane + 64] : 0;          // rows of idx hold at least 128 entries
+        lo = lane < n ? e0 * row_bytes : pad_bytes + ((lane - n < low_pads) ? 0 : row_bytes);
+        hi = lane + 64 < n ? e1 * row_bytes : pad_bytes + ((lane + 64 - n < low_pads) ? 0 : row_bytes);
+    }
+    template <int K>
+    __device__ __forceinline__ int of() const { return __builtin_amdgcn_readlane(K < 64 ? lo : hi, K & 63); }
+};
+
 // ---- REPET-SIM / online: list of similar frames per frame ----------------------------------------
 // SPLIT: F-1 (= W/2) is a multiple of 64, so the wave-per-64-bins kernel covers bins [0, F-1) in whole
 // blocks (4 per wave, balanced) and the lone Nyquist bin F-1 of 64 FRAMES is packed into one wave by
@@ -202,15 +220,23 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
     const int* list = idx + r * (int64_t)idx_pitch;
     const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
     RowGather g{channel_rsrc(Vc, a.chan_stride), 0};
+    // the slots' row offsets once per wave in vector form, handed to the gathers by v_readlane (see SlotOffsets); lists of
+    // more than 128 entries (bisection, NET == 0) keep the slot-by-slot form
+    int off_lo = 0, off_hi = 0;
+    if constexpr (NET > 0) {
+        const SlotOffsets<NET> so(list, n, row_bytes, pad_bytes, lane);
+        off_lo = so.lo; off_hi = so.hi;
+    }
     for (int fb = wave; fb < nfb; fb += 4) {
         const int f = fb * 64 + lane;
         const bool active = f < nbins;
         const int fc = active ? f : nbins - 1;
         g.bin_bytes = fc * 4;
-        // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the loop; hoisted, hipcc
-        // parks all NET offsets in VGPRs and halves the occupancy
+        // opaque copies: keep the per-slot offsets (readlanes / scalar ALU) inside the loop; hoisted, hipcc parks all NET
+        // offsets in registers and halves the occupancy
         int n_it = n;
         asm volatile("" : "+s"(n_it));
+        asm volatile("" : "+v"(off_lo), "+v"(off_hi));
         // the frame's own magnitude and spectrum bin do not depend on the median: fetch them before the network so
         // they arrive while it runs (3 more live registers) instead of after it
         const int64_t o = c * a.chan_stride + t * a.FS + fc;
@@ -218,7 +244,8 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
         float2 x_own = make_float2(0.f, 0.f);
         if (a.X) x_own = a.X[o];
         const float med = median_of<NET>(n_it, [&](int k) {
-            return g(k < n_it ? list[k] * row_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
+            if constexpr (NET > 0) return g(__builtin_amdgcn_readlane(k < 64 ? off_lo : off_hi, k & 63));
+            else return g(k < n_it ? list[k] * row_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
         if (active) {
             const float m = soft_mask(v_own, med, f, a.cutoff);
             if (a.mask) a.mask[o] = m;
@@ -234,13 +261,9 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
 // mask is bit-identical to mask_sim_kernel's -- at half the instructions per bin and half the gather bytes.
 template <int NET, size_t... Q>
 __device__ __forceinline__ void gather_codes_in_network_order(unsigned (&w)[NET], __amdgpu_buffer_rsrc_t rsrc, int bin_bytes,
-                                                              const int* list, int n, int row_bytes, int pad_bytes,
-                                                              std::index_sequence<Q...>) {
+                                                              const SlotOffsets<NET>& offsets, std::index_sequence<Q...>) {
     ((w[MedianNetPk<NET>::kLoadOrder[Q]] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
-          rsrc, bin_bytes,
-          (int)MedianNetPk<NET>::kLoadOrder[Q] < n ? list[MedianNetPk<NET>::kLoadOrder[Q]] * row_bytes
-                                                     : pad_offset<NET>((int)MedianNetPk<NET>::kLoadOrder[Q], n, pad_bytes, row_bytes),
-          0)), ...);
+          rsrc, bin_bytes, offsets.template of<MedianNetPk<NET>::kLoadOrder[Q]>(), 0)), ...);
 }
 
 // Scheduling: the unit of work is (channel, block of 128 bins, 4 consecutive frames) = one workgroup, one frame per
@@ -251,10 +274,25 @@ __device__ __forceinline__ void gather_codes_in_network_order(unsigned (&w)[NET]
 // Lookups: the frame's own code tells whether its magnitude is at or below the lower middle value -- then
 // min(V, median) = V and the mask is exactly 1 (about half of all cells: the frame is usually in its own list), and
 // the lane skips the scattered table reads.
+#ifdef REPET_MASK_STAMPS
+// diagnostic build (make stamps, tools/mask_spans.py): wave 0 of every fourth workgroup records its start and end on the
+// chip-wide 100 MHz clock and, in core cycles since its start, when its gathers were issued and when the network was done
+__device__ unsigned long long g_mask_span[4 * 16384];
+#define MSTAMP_BEGIN const bool ms_on = (blockIdx.x & 3) == 1 && (blockIdx.x >> 2) < 16384 && threadIdx.x == 0; \
+    const unsigned long long ms_r0 = __builtin_amdgcn_s_memrealtime(), ms_c0 = __builtin_amdgcn_s_memtime(); unsigned long long ms_c1 = 0, ms_c2 = 0;
+#define MSTAMP(v) v = __builtin_amdgcn_s_memtime() - ms_c0;
+#define MSTAMP_END if (ms_on) { unsigned long long* q_ = g_mask_span + 4 * (blockIdx.x >> 2); q_[0] = ms_r0; q_[1] = __builtin_amdgcn_s_memrealtime(); q_[2] = ms_c1; q_[3] = ms_c2; }
+#else
+#define MSTAMP_BEGIN
+#define MSTAMP(v)
+#define MSTAMP_END
+#endif
+
 template <int NET>
 __global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                             const int* __restrict__ count, int n_quads) {
     static_assert(NET >= 2, "the rank path has no bisection fallback");
+    MSTAMP_BEGIN
     // the wave number as a scalar: everything derived from it (frame, list, row offsets) then lives in SGPRs
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nfb = (a.F - 1) >> 7;                   // whole blocks of 128 bins; bin F-1: mask_sim_nyquist_kernel
@@ -281,8 +319,12 @@ __global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const in
     float med0 = __uint_as_float(0x7fc00000u), med1 = med0;              // np.median of an empty slice
     if (n > 0) {
         unsigned w[NET];
-        gather_codes_in_network_order<NET>(w, rsrc, f0 * 2, list, n, row_bytes, pad_bytes, std::make_index_sequence<NET>{});
+        const SlotOffsets<NET> offsets(list, n, row_bytes, pad_bytes, lane);
+        gather_codes_in_network_order<NET>(w, rsrc, f0 * 2, offsets, std::make_index_sequence<NET>{});
+        MSTAMP(ms_c1)
         MedianNetPk<NET>::run(w);
+        asm volatile("" :: "v"(w[NET / 2 - 1]), "v"(w[NET / 2]));
+        MSTAMP(ms_c2)
         const float* vs = a.Vs + ((int64_t)c * a.n_rank_cols + f0) * a.vs_pitch;
         const unsigned lo = w[NET / 2 - 1], hi = w[NET / 2];
         const unsigned lo0 = lo & 0xffffu, lo1 = lo >> 16;
@@ -302,7 +344,16 @@ __global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const in
     const float m0 = soft_mask(v_own.x, med0, f0, a.cutoff), m1 = soft_mask(v_own.y, med1, f0 + 1, a.cutoff);
     if (a.mask) *reinterpret_cast<float2*>(a.mask + o) = make_float2(m0, m1);
     if (a.X) *reinterpret_cast<float4*>(a.X + o) = make_float4(x_own.x * m0, x_own.y * m0, x_own.z * m1, x_own.w * m1);
+    MSTAMP_END
 }
+
+#ifdef REPET_MASK_STAMPS
+}  // namespace repet
+extern "C" int repet_debug_mask_spans(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(repet::g_mask_span), sizeof(unsigned long long) * 4 * n);
+}
+namespace repet {
+#endif
 
 // One lane per frame, bin F-1 only: the index list, its length and every row offset are per-lane here.
 template <int NET>
