@@ -323,6 +323,10 @@ __global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const in
         const SlotOffsets<NET> offsets(list, n, row_bytes, pad_bytes, lane);
         gather_codes_in_network_order<NET>(w, rsrc, f0 * 2, offsets, std::make_index_sequence<NET>{});
         MSTAMP(ms_c1)
+#ifdef REPET_MASK_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // diagnostic build only: all gathers landed
+        { const unsigned long long landed = __builtin_amdgcn_s_memtime() - ms_c0; ms_c1 |= landed << 32; }
+#endif
         MedianNetPk<NET>::run(w);
         asm volatile("" :: "v"(w[NET / 2 - 1]), "v"(w[NET / 2]));
         MSTAMP(ms_c2)

@@ -126,11 +126,16 @@ __global__ __launch_bounds__(256) void columns_from_rows_kernel(RankArgs a) {
     const int64_t t0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float* in = a.V + c * a.chan_stride;
+    // all sixteen loads first (clamped row: a load behind "t < T ?" sits in a branch and is waited for at its join, one
+    // memory round trip per row of the tile), the choice afterwards
+    float r[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int64_t t = t0 + ty + 4 * k;
-        tile[ty + 4 * k][tx] = t < a.T ? in[t * a.FS + f0 + tx] : 0.f;
+        r[k] = in[(t < a.T ? t : a.T - 1) * a.FS + f0 + tx];
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = (t0 + ty + 4 * k < a.T) ? r[k] : 0.f;
     __syncthreads();
     float* out = a.Vs + ((int64_t)c * a.n_cols + f0) * a.vs_pitch;
     if (t0 + tx < a.vs_pitch) {
@@ -148,10 +153,14 @@ __global__ __launch_bounds__(256) void rows_from_code_columns_kernel(RankArgs a)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const unsigned* in = reinterpret_cast<const unsigned*>(a.codes + ((int64_t)c * a.n_cols + f0) * a.vs_pitch + t0);
     const bool in_range = t0 + 2 * tx < a.vs_pitch;      // vs_pitch is even; codes of frames >= T are never stored
+    unsigned r[32];                                     // (loads first, choice afterwards: as above)
+    const int txc = in_range ? tx : 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r[k] = in[(int64_t)(ty + 4 * k) * (a.vs_pitch / 2) + txc];
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
         const int fl = ty + 4 * k;
-        tile[fl & 1][fl >> 1][tx] = in_range ? in[(int64_t)fl * (a.vs_pitch / 2) + tx] : 0u;
+        tile[fl & 1][fl >> 1][tx] = in_range ? r[k] : 0u;
     }
     __syncthreads();
     unsigned* out = reinterpret_cast<unsigned*>(a.R + c * a.r_chan_stride + f0);

@@ -21,8 +21,9 @@ t0 = start.min()
 span = end.max() - t0
 print("sampled waves %d (one in sixteen)  kernel span %.1f us  wave time: mean %.2f  median %.2f  p90 %.2f  max %.2f us" % (
     len(a), span, dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max()))
-print("cycles since the wave's start: gathers issued %.0f, network done %.0f (median); wave total %.0f cycles at 2.4 GHz" % (
-    np.median(a[:, 2]), np.median(a[:, 3]), np.median(dur) * 2400))
+issued, landed = a[:, 2] & 0xffffffff, a[:, 2] >> 32
+print("cycles since the wave's start (median): gathers issued %.0f, all landed %.0f, network done %.0f; wave total %.0f cycles at 2.4 GHz" % (
+    np.median(issued), np.median(landed), np.median(a[:, 3]), np.median(dur) * 2400))
 print("mean concurrency of all waves (x16): %.0f" % (16 * dur.sum() / span))
 for lo in range(0, int(span) + 1, 50):
     alive = 16 * np.sum((start - t0 <= lo) & (end - t0 > lo))
