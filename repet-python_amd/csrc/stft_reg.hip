@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace repet {
@@ -509,8 +510,20 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
             const int64_t n_base = t * N - a.trim;                       // output sample of the hop's first sample
             int lane = lane_id;                                          // opaque: no per-slot addresses kept across rounds
             asm volatile("" : "+v"(lane));
+            // an accumulating class of `extended` segments: the eight old values of this lane are fetched together before
+            // the first is used (each behind its own "mode == 1" branch they were eight memory round trips per hop)
+            using OldT = std::conditional_t<C == 2, Float4A, Float2A>;
+            const bool whole = n_base >= 0 && n_base + N <= a.n_out;    // wave-uniform: the hop lies inside the output
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s0 = 0; s0 < 8; s0 += 4) {                          // (four at a time: registers)
+            OldT old4[4];
+            if (mode == 1 && whole) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    old4[s] = *reinterpret_cast<const OldT*>(a.out + (a.out_offset + n_base + 2 * (lane + 64 * (s0 + s))) * C);
+            }
+#pragma unroll
+            for (int s = s0; s < s0 + 4; ++s) {
                 float o[C][2];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -520,20 +533,24 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                 }
                 const int64_t n0 = n_base + 2 * (lane + 64 * s);          // samples n0, n0 + 1
                 float* dst = a.out + (a.out_offset + n0) * C;
-                if (n0 >= 0 && n0 + 1 < a.n_out) {
+                if (whole || (n0 >= 0 && n0 + 1 < a.n_out)) {
                     float w0 = 1.f, w1 = 1.f;
                     if (mode != 0) { w0 = weight(n0); w1 = weight(n0 + 1); }
                     if constexpr (C == 2) {
                         Float4A* q = reinterpret_cast<Float4A*>(dst);
                         Float4A r{o[0][0], o[1][0], o[0][1], o[1][1]};
-                        if (mode == 1) { const Float4A old = *q; r = Float4A{old.x + w0 * r.x, old.y + w0 * r.y, old.z + w1 * r.z, old.w + w1 * r.w}; }
-                        else if (mode == 2) r = Float4A{w0 * r.x, w0 * r.y, w1 * r.z, w1 * r.w};
+                        if (mode == 1) {
+                            const Float4A was = whole ? old4[s - s0] : *q;
+                            r = Float4A{was.x + w0 * r.x, was.y + w0 * r.y, was.z + w1 * r.z, was.w + w1 * r.w};
+                        } else if (mode == 2) r = Float4A{w0 * r.x, w0 * r.y, w1 * r.z, w1 * r.w};
                         *q = r;
                     } else {
                         Float2A* q = reinterpret_cast<Float2A*>(dst);
                         Float2A r{o[0][0], o[0][1]};
-                        if (mode == 1) { const Float2A old = *q; r = Float2A{old.x + w0 * r.x, old.y + w1 * r.y}; }
-                        else if (mode == 2) r = Float2A{w0 * r.x, w1 * r.y};
+                        if (mode == 1) {
+                            const Float2A was = whole ? old4[s - s0] : *q;
+                            r = Float2A{was.x + w0 * r.x, was.y + w1 * r.y};
+                        } else if (mode == 2) r = Float2A{w0 * r.x, w1 * r.y};
                         *q = r;
                     }
                 } else {
@@ -550,6 +567,8 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                         }
                     }
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
