@@ -250,19 +250,39 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
                     const float4 v = ahead[q];
                     L.buf[phys4(64 * q + lane)] = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
                 }
-            } else {
+            } else if (vec_ok) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int g = 64 * q + lane;
                     const int i0 = s0 + 4 * g;
                     float4 v;
-                    if (vec_ok && i0 >= 0 && i0 + 3 < n) {
+                    if (i0 >= 0 && i0 + 3 < n) {
                         v = *reinterpret_cast<const float4*>(src + i0);
                         v = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
                     } else {
                         v = make_float4(fetch(i0), fetch(i0 + 1), fetch(i0 + 2), fetch(i0 + 3));
                     }
                     L.buf[phys4(g)] = v;
+                }
+            } else {
+                // circular-buffer order (simonline: element i of the row is a walk down a diagonal of the banded matrix) or
+                // an unaligned pitch: sixteen single loads per lane, ALL issued before the first is used -- element by element
+                // behind their bounds checks they were sixteen memory round trips per chunk, half of a short row's time
+                float e[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = s0 + 4 * (64 * q + lane) + k;
+                        e[4 * q + k] = fetch_inside((i >= 0 && i < n) ? i : 0);      // (one modulo per element: a lag recurrence
+                    }                                                                // over the four of a group measured slower)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i0 = s0 + 4 * (64 * q + lane);
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = (i0 + k >= 0 && i0 + k < n) ? nan_to_inf(e[4 * q + k]) : -INFINITY;
+                    L.buf[phys4(64 * q + lane)] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
             have_ahead = c + 1 < n_chunks && interior(c + 1);

@@ -3,9 +3,10 @@ sys.path[:0] = ["repet-python_amd", "."]
 os.environ["REPET_HIP_LIB"] = os.path.abspath("build_diag/lib_stamps.so")
 import repet
 from repet_synth import synth
-x = synth(180, 44100, 2, 0)
+algo = os.environ.get("PEAK_ALGO", "sim")                     # sim (180 s) or simonline (30 s): the two users of the peak kernel
+x = synth(180 if algo == "sim" else 30, 44100, 2, 0)
 ctx = repet.Context(0); ctx.upload(x); p = repet.derive_params(44100)
-ctx.execute("sim", p); ctx.execute("sim", p)
+ctx.execute(algo, p); ctx.execute(algo, p)
 lib = ctypes.CDLL(os.environ["REPET_HIP_LIB"])
 buf = (ctypes.c_ulonglong * 64)()
 print("rc", lib.repet_debug_peak_stamps(buf))
@@ -23,7 +24,7 @@ if hasattr(lib, "repet_debug_wave_stamps"):
             row[0], row[1], row[2], row[3], row[4], row[5], row[:6].sum()))
 
 if hasattr(lib, "repet_debug_wave_spans"):
-    T = ctx.last_frame_count()
+    T = ctx.last_frame_count() if algo == "sim" else ctx.last_frame_count() - p.buffer_frames + 1
     sp = (ctypes.c_ulonglong * (2 * T))()
     print("rc", lib.repet_debug_wave_spans(sp, T))
     sp = np.array(sp[:], dtype=np.int64).reshape(T, 2) * 10e-3          # 100 MHz ticks -> microseconds
@@ -38,7 +39,7 @@ if hasattr(lib, "repet_debug_wave_spans"):
         print("  t = %3d us: %5d waves alive, %5d start in the next 20 us" % (lo, alive, started))
 
 if hasattr(lib, "repet_debug_wave_phases") and os.environ.get("PEAK_PHASES"):
-    T = ctx.last_frame_count()
+    T = ctx.last_frame_count() if algo == "sim" else ctx.last_frame_count() - p.buffer_frames + 1
     ph = (ctypes.c_uint * (10 * T))()
     print("rc", lib.repet_debug_wave_phases(ph, T))
     ph = np.array(ph[:], dtype=np.int64).reshape(T, 10)
