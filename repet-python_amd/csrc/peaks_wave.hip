@@ -139,15 +139,8 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
     const int64_t j = a.row0 + r;                            // absolute row (mode 1: current frame)
     float dlt = a.delta;                                     // 0: no refinement
 
-    auto fetch = [&](int i) -> float {                       // element i of the row, -inf outside [0, n)
-        if (i < 0 || i >= n) return -INFINITY;
-        if (a.mode == 0) return nan_to_inf(a.M[j * a.pitch + i]);
-        int l = (int)(j - i) % n;                            // circular-buffer order of the online variant
-        if (l < 0) l += n;
-        return nan_to_inf(a.M[(j - l - a.shift) * a.pitch + l]);
-    };
-    // the same for an index known to lie in [0, n), without a branch: loads of a batch must not each sit behind their own
-    // control-flow join (the value is needed AT the join, so every load was waited for before the next was issued)
+    // element i of the row for an index known to lie in [0, n), without a branch: loads of a batch must not each sit behind
+    // their own control-flow join (the value is needed AT the join, so every load was waited for before the next was issued)
     auto fetch_inside = [&](int i) -> float {
         int l = (int)(j - i) % n;
         l += l < 0 ? n : 0;
@@ -250,24 +243,17 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
                     const float4 v = ahead[q];
                     L.buf[phys4(64 * q + lane)] = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
                 }
-            } else if (vec_ok) {
+            } else if (interior(c)) {                        // (a chunk inside the row that was not fetched ahead)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int g = 64 * q + lane;
-                    const int i0 = s0 + 4 * g;
-                    float4 v;
-                    if (i0 >= 0 && i0 + 3 < n) {
-                        v = *reinterpret_cast<const float4*>(src + i0);
-                        v = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
-                    } else {
-                        v = make_float4(fetch(i0), fetch(i0 + 1), fetch(i0 + 2), fetch(i0 + 3));
-                    }
-                    L.buf[phys4(g)] = v;
+                    const float4 v = *reinterpret_cast<const float4*>(src + s0 + 4 * (64 * q + lane));
+                    L.buf[phys4(64 * q + lane)] = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
                 }
             } else {
-                // circular-buffer order (simonline: element i of the row is a walk down a diagonal of the banded matrix) or
-                // an unaligned pitch: sixteen single loads per lane, ALL issued before the first is used -- element by element
-                // behind their bounds checks they were sixteen memory round trips per chunk, half of a short row's time
+                // the first and the last chunk of a row, circular-buffer order (simonline: element i of the row is a walk
+                // down a diagonal of the banded matrix) or an unaligned pitch: sixteen single loads per lane, ALL issued
+                // before the first is used -- element by element behind their bounds checks they were up to sixteen memory
+                // round trips per chunk (half of a short row's time, two chunks in nine of a long one's)
                 float e[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
