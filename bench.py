@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--algo", default="sim")
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed pre-warm before the warm-up steps (device clocks), by wall time")
     ap.add_argument("--scatter-limit", type=float, default=240.0, help="seconds the scatter/gather leg may take before it is given up")
     ap.add_argument("--clips", type=int, default=1, help="independent clips per rank and step (config 5: 64 in total)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5],
@@ -148,6 +149,7 @@ def main():
     if world > 1 or (os.environ.get("REPET_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ):   # the switch: 1-rank check of the RCCL path
         if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
             os.environ["NCCL_DEBUG"] = "WARN"        # RCCL prints its version banner on stdout: keep stdout to the one JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")    # ... and its warnings (topology, iommu) on stderr
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -174,6 +176,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The device reaches its steady clocks only after some tens of milliseconds of work (a 1.1-ms step measures 1.26 ms
+    # right after start, 1.16 after three steps, 1.11 after thirty): an untimed pre-warm by wall time, declared in the
+    # line as config.prewarm_ms, precedes the W warm-up steps so that small W / K do not measure the ramp.
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for ctx in ctxs:
+            ctx.execute(args.algo, params)
     for _ in range(args.warmup):
         for ctx in ctxs:
             ctx.execute(args.algo, params)
@@ -311,7 +320,7 @@ def main():
             "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
                                    f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
                        "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
-                       "frames": int(ctx.last_frame_count()), "parallelism": f"clip-parallel x{world}, no collective" + (", clips batched through every stage" if batched else "")},
+                       "frames": int(ctx.last_frame_count()), "prewarm_ms": args.prewarm_ms, "parallelism": f"clip-parallel x{world}, no collective" + (", clips batched through every stage" if batched else "")},
             "roofline": roof,
             "stages": stages,
             "device_ms_per_step": round(sum(s["ms"] for s in stages), 4),
@@ -340,7 +349,8 @@ def main():
         def bail(reason):
             if rank == 0:
                 line["scatter_gather"] = {"error": reason}
-                print(json.dumps(line), flush=True)
+                sys.stdout.write("\n" + json.dumps(line) + "\n")
+                sys.stdout.flush()
             os._exit(0)
 
         watchdog = threading.Timer(args.scatter_limit, bail, args=(f"no result within {args.scatter_limit:g} s",))
@@ -361,7 +371,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(line), flush=True)          # the ONE line, after everything that might write to stdout
+        sys.stdout.flush()
+        sys.stdout.write("\n" + json.dumps(line) + "\n")    # the ONE line, on a line of its own whatever a library left unfinished
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
