@@ -221,27 +221,33 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
         const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, t * 4, 0, 0));
         orig[4 * j] = v.x; orig[4 * j + 1] = v.y; orig[4 * j + 2] = v.z; orig[4 * j + 3] = v.w;
     }
-    // pos[e] walks PHYSICAL LDS indices, biased by the offset of the level's probe: a step of 2^m >= 32 keys is
-    // 2^m + 2^m / 8 words further on (one pad float4 per 32 keys) and its probe (key pos + step - 1, in the row before
-    // pos + step) sits at +inc - 5; a step below 32 stays inside a padded row (probe at +step - 1). A probe is then a
-    // ds_read of pos[e] itself, a compare, a select and one three-input add (the move to the next level's bias).
-    int off = (N / 2 + N / 16) - 5;
-#pragma unroll
-    for (int e = 0; e < 32; ++e) pos[e] = off;
+    // The search runs in two parts. Which ROW of 32 keys: the levels with steps >= 32 probe the last keys of rows,
+    // which in the padded array all fall into one or two banks (sixteen distinct addresses of one bank at the level of
+    // step 256: a sixteen-fold replay); a copy of those N/32 - 1 keys in breadth-first order (node n: children 2n, 2n+1)
+    // puts the 2^l probes of level l on consecutive words instead. Then five levels inside the row, on PHYSICAL indices
+    // biased by the offset of the level's probe (key pos + step - 1): a probe is a ds_read of pos[e] itself, a compare,
+    // a select and one three-input add (the move to the next level's bias).
+    constexpr int kTreeLevels = LOG2N - 5;
+    unsigned* tree = s + (N + N / 8);
+    __syncthreads();                                           // the sorted column is complete
+    if (tid > 0) {
+        const int l = 31 - __clz(tid), j = tid - (1 << l);     // node tid: level l, j-th from the left
+        tree[tid] = s[phys((((2 * j + 1) << (LOG2N - 1 - l))) - 1)];
+    }
     __syncthreads();
     if (!(a.ablate & 2)) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) pos[e] = 1;
 #pragma unroll 1
-        for (int m = LOG2N - 1; m >= 5; --m) {
-            const int step = 1 << m, inc = step + (step >> 3);
-            const int next_off = m > 5 ? (inc >> 1) - 5 : 15;
-            const int d = next_off - off;
+        for (int l = 0; l < kTreeLevels; ++l) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
-                const unsigned probe = s[pos[e]];
-                pos[e] += (probe < orig[e] ? inc : 0) + d;
+                const unsigned probe = tree[pos[e]];
+                pos[e] = 2 * pos[e] + (probe < orig[e] ? 1 : 0);
             }
-            off = next_off;
         }
+#pragma unroll
+        for (int e = 0; e < 32; ++e) pos[e] = (pos[e] - THREADS) * 36 + 15;      // row -> physical index of its probe of step 16
 #pragma unroll
         for (int m = 4; m >= 0; --m) {
             const int step = 1 << m, d = m > 0 ? -((step >> 1) + 0) : 0;      // (step/2 - 1) - (step - 1)
@@ -296,7 +302,7 @@ bool rank_columns_supported(int64_t T) { return T > kRankMinFrames && T <= kRank
 template <int LOG2N>
 static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     constexpr int N = 1 << LOG2N;
-    constexpr int lds = (N + N / 8) * 4;
+    constexpr int lds = (N + N / 8) * 4 + (N / 32) * 4;        // the padded keys + the breadth-first copy of the row ends
     const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N>);
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
