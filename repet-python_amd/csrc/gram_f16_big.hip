@@ -145,7 +145,11 @@ __global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __res
     // Both copies of the block leave through the wave's LDS patch (64 rows x 68 floats) so that every global store is
     // 16 bytes per lane, four 256-byte rows per instruction (the 4-byte stores of the fragment layout were 256 store
     // instructions per lane -- the epilogue was store-issue-bound): first the 64 x 64 half as it is, then transposed.
-    // The patches alias the tile buffers, which every wave left at the loop's last barrier.
+    // The patches alias the tile buffers, which every wave left at the loop's last barrier. (Measured against it at cfg 2,
+    // 0.197 ms: the natural copy straight from the accumulators as 4-byte stores, 128 contiguous bytes per half-wave --
+    // 0.198; the mirror straight from the accumulators as 16-byte stores, registers 4q..4q+3 being four consecutive i of
+    // row j, 32 bytes per row and instruction -- 0.211. With a quarter of the tiles in flight a workgroup's epilogue is
+    // 15 us instead of 31: half of it is the chip-wide burst of 134 MB at the end of a round, not the store sequence.)
     const int64_t gi0 = a_row0 + wr * 128;
     const int64_t gj0 = b_row0 + wc * 64;
     constexpr float unscale = 1.0f / (128.0f * 128.0f);          // the 2^7 scale of both operands, exact

@@ -4,7 +4,7 @@ os.environ["REPET_HIP_LIB"] = os.path.abspath("build_diag/lib_stamps.so")
 import repet
 from repet_synth import synth
 algo = os.environ.get("PEAK_ALGO", "sim")                     # sim (180 s) or simonline (30 s): the two users of the peak kernel
-x = synth(180 if algo == "sim" else 30, 44100, 2, 0)
+x = synth(float(os.environ.get("PEAK_SECONDS", 180 if algo == "sim" else 30)), 44100, 2, 0)
 ctx = repet.Context(0); ctx.upload(x); p = repet.derive_params(44100)
 ctx.execute(algo, p); ctx.execute(algo, p)
 lib = ctypes.CDLL(os.environ["REPET_HIP_LIB"])
