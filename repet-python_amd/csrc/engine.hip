@@ -1092,24 +1092,39 @@ int repet_derive_params(const repet_settings* settings, double fs, repet_params*
     repet_settings d;
     repet_default_settings(&d);
     const repet_settings& s = settings ? *settings : d;
-    // nearbyint under the default rounding mode is round-half-to-even, like Python's round() and np.round()
-    auto rnd = [](double x) { return (int64_t)std::nearbyint(x); };
+    // nearbyint under the default rounding mode is round-half-to-even, like Python's round() and np.round(). The
+    // conversions to integers are checked: a value that is not finite or does not fit is an argument error, not a cast
+    // with undefined behaviour (tools/asan_host_check.c runs this under UBSan).
+    bool fits = true;
+    auto rnd = [&fits](double x, double limit) -> int64_t {
+        const double r = std::nearbyint(x);
+        if (!(std::fabs(r) < limit)) { fits = false; return 0; }
+        return (int64_t)r;
+    };
+    constexpr double k31 = 2147483648.0, k62 = 4611686018427387904.0;
     std::memset(out, 0, sizeof(*out));
-    const int w = (int)std::ldexp(1.0, (int)std::ceil(std::log2(0.04 * fs)));               // repet.py:130
+    const double log_w = std::ceil(std::log2(0.04 * fs));                                    // repet.py:130
+    if (!(log_w >= 1.0)) return fail(REPET_ERR_BAD_ARG, "sampling frequency too low: the 40-ms window has fewer than two samples");
+    if (!(log_w <= 24.0)) return fail(REPET_ERR_LIMIT, "sampling frequency too high: window above 2^24 samples");
+    const int w = 1 << (int)log_w;
     const int h = w / 2;                                                                     // repet.py:132
     out->window_length = w;
     out->step_length = h;
-    out->period_lo = (int32_t)rnd(s.period_range[0] * fs / h);                               // repet.py:165
-    out->period_hi = (int32_t)rnd(s.period_range[1] * fs / h);
-    out->cutoff_bins = (int32_t)rnd(s.cutoff_frequency * w / fs);                            // repet.py:173
+    out->period_lo = (int32_t)rnd(s.period_range[0] * fs / h, k31);                          // repet.py:165
+    out->period_hi = (int32_t)rnd(s.period_range[1] * fs / h, k31);
+    out->cutoff_bins = (int32_t)rnd(s.cutoff_frequency * w / fs, k31);                       // repet.py:173
     out->filter_order = s.filter_order;
-    out->seg_len_frames = (int32_t)rnd(s.segment_length * fs / h);                           // repet.py:519
-    out->seg_step_frames = (int32_t)rnd(s.segment_step * fs / h);                            // repet.py:520
-    out->sim_distance_frames = (int32_t)rnd(s.similarity_distance * fs / h);                 // repet.py:670
+    out->seg_len_frames = (int32_t)rnd(s.segment_length * fs / h, k31);                      // repet.py:519
+    out->seg_step_frames = (int32_t)rnd(s.segment_step * fs / h, k31);                       // repet.py:520
+    out->sim_distance_frames = (int32_t)rnd(s.similarity_distance * fs / h, k31);            // repet.py:670
     out->sim_number = s.similarity_number;
-    out->buffer_frames = (int32_t)rnd((s.buffer_length * fs) / h);                           // repet.py:787
-    out->seg_len_samples = rnd(s.segment_length * fs);                                       // repet.py:266
-    out->seg_step_samples = rnd(s.segment_step * fs);                                        // repet.py:267
+    out->buffer_frames = (int32_t)rnd((s.buffer_length * fs) / h, k31);                      // repet.py:787
+    out->seg_len_samples = rnd(s.segment_length * fs, k62);                                  // repet.py:266
+    out->seg_step_samples = rnd(s.segment_step * fs, k62);                                   // repet.py:267
+    if (!fits) {
+        std::memset(out, 0, sizeof(*out));
+        return fail(REPET_ERR_BAD_ARG, "a setting times the sampling frequency is not a finite number that fits an integer");
+    }
     out->sim_threshold = s.similarity_threshold;
     return REPET_OK;
 }
