@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256) void rows_from_code_columns_kernel(RankArgs a)
     }
 }
 
+#ifndef REPET_RANK_LEAF_BITS
+#define REPET_RANK_LEAF_BITS 4
+#endif
+constexpr int kRankLeafBits = REPET_RANK_LEAF_BITS;          // the tree ends at leaves of 2^kRankLeafBits keys (<= 5: inside a padded row)
+
 template <int LOG2N>
 __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArgs a) {
     constexpr int N = 1 << LOG2N, THREADS = N / 32;
@@ -221,19 +226,22 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
         const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, t * 4, 0, 0));
         orig[4 * j] = v.x; orig[4 * j + 1] = v.y; orig[4 * j + 2] = v.z; orig[4 * j + 3] = v.w;
     }
-    // The search runs in two parts. Which ROW of 32 keys: the levels with steps >= 32 probe the last keys of rows,
-    // which in the padded array all fall into one or two banks (sixteen distinct addresses of one bank at the level of
-    // step 256: a sixteen-fold replay); a copy of those N/32 - 1 keys in breadth-first order (node n: children 2n, 2n+1)
-    // puts the 2^l probes of level l on consecutive words instead. Then five levels inside the row, on PHYSICAL indices
-    // biased by the offset of the level's probe (key pos + step - 1): a probe is a ds_read of pos[e] itself, a compare,
-    // a select and one three-input add (the move to the next level's bias).
-    constexpr int kTreeLevels = LOG2N - 5;
+    // The search runs in two parts. Which LEAF of 16 keys: the levels with large steps probe keys that, in the padded
+    // array, all fall into one or two banks (sixteen distinct addresses of one bank at the level of step 256: a
+    // sixteen-fold replay); a copy of those N/16 - 1 keys in breadth-first order (node n: children 2n, 2n+1) puts the
+    // 2^l probes of level l on consecutive words instead. Then four levels inside the leaf, on PHYSICAL indices biased
+    // by the offset of the level's probe (key pos + step - 1): a probe is a ds_read of pos[e] itself, a compare, a
+    // select and one three-input add (the move to the next level's bias). (cfg 2, the three kernels of the column sort:
+    // no tree 0.191 ms; leaves of 32 keys 0.151, of 16 0.148, of 8 0.147 with 4 KB of tree.)
+    constexpr int R = kRankLeafBits, kTreeLevels = LOG2N - R, kNodes = N >> R;
     unsigned* tree = s + (N + N / 8);
     __syncthreads();                                           // the sorted column is complete
-    if (tid > 0) {
-        const int l = 31 - __clz(tid), j = tid - (1 << l);     // node tid: level l, j-th from the left
-        tree[tid] = s[phys((((2 * j + 1) << (LOG2N - 1 - l))) - 1)];
-    }
+#pragma unroll
+    for (int n = tid; n < kNodes; n += THREADS)
+        if (n > 0) {
+            const int l = 31 - __clz(n), j = n - (1 << l);     // node n: level l, j-th from the left
+            tree[n] = s[phys((((2 * j + 1) << (LOG2N - 1 - l))) - 1)];
+        }
     __syncthreads();
     if (!(a.ablate & 2)) {
 #pragma unroll
@@ -247,9 +255,12 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
             }
         }
 #pragma unroll
-        for (int e = 0; e < 32; ++e) pos[e] = (pos[e] - THREADS) * 36 + 15;      // row -> physical index of its probe of step 16
+        for (int e = 0; e < 32; ++e) {                          // leaf -> physical index of its probe of step 2^(R-1)
+            const int g = pos[e] - kNodes;
+            pos[e] = (g << R) + ((g >> (5 - R)) << 2) + (1 << (R - 1)) - 1;
+        }
 #pragma unroll
-        for (int m = 4; m >= 0; --m) {
+        for (int m = R - 1; m >= 0; --m) {
             const int step = 1 << m, d = m > 0 ? -((step >> 1) + 0) : 0;      // (step/2 - 1) - (step - 1)
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
@@ -302,7 +313,7 @@ bool rank_columns_supported(int64_t T) { return T > kRankMinFrames && T <= kRank
 template <int LOG2N>
 static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     constexpr int N = 1 << LOG2N;
-    constexpr int lds = (N + N / 8) * 4 + (N / 32) * 4;        // the padded keys + the breadth-first copy of the row ends
+    constexpr int lds = (N + N / 8) * 4 + (N >> kRankLeafBits) * 4;        // the padded keys + the breadth-first copy of the leaf ends
     const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N>);
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
