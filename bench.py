@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--algo", default="sim")
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--sync-steps", action="store_true", help="one blocking call per step instead of K steps enqueued back to back")
     ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed pre-warm before the warm-up steps (device clocks), by wall time")
     ap.add_argument("--scatter-limit", type=float, default=240.0, help="seconds the scatter/gather leg may take before it is given up")
     ap.add_argument("--clips", type=int, default=1, help="independent clips per rank and step (config 5: 64 in total)")
@@ -189,8 +190,17 @@ def main():
     stage_ms, stage_meta = {}, {}
     barrier()
     t0 = time.perf_counter()
+    # The K steps are enqueued back to back on the context's stream, as a job that separates one clip after another would:
+    # no host wait between them (a blocking call per step left the device idle for 25-30 us while the host read its events).
+    # Every step still records its own per-stage HIP events on that stream (timing series): the stage times below are
+    # the means over exactly these K steps.
+    series = len(ctxs) == 1 and not args.sync_steps
+    if series:
+        ctxs[0].timing_series_begin(args.steps)
     for _ in range(args.steps):
-        if len(ctxs) == 1:
+        if series:
+            ctxs[0].execute_async(args.algo, params)
+        elif len(ctxs) == 1:
             tm = ctxs[0].execute(args.algo, params, timing=True)     # blocks until the stream is idle
             for s in tm["stages"]:
                 stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
@@ -200,8 +210,16 @@ def main():
                 ctx.execute_async(args.algo, params)
             for ctx in ctxs:
                 ctx.synchronize()
+    if series:
+        ctxs[0].synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if series:
+        tm = ctxs[0].timing_series_end()
+        assert tm["steps"] == args.steps, tm["steps"]
+        for s in tm["stages"]:
+            stage_ms[s["name"]] = s["ms"] * args.steps
+            stage_meta[s["name"]] = s
     if len(ctxs) > 1:                           # per-stage device times of one clip, outside the timed region
         for _ in range(args.steps):
             tm = ctxs[0].execute(args.algo, params, timing=True)

@@ -173,6 +173,12 @@ void repet_host_free(void* ptr);
  * returned here, device-side failures by repet_ctx_synchronize (or the next blocking call). */
 int repet_ctx_execute_async(repet_ctx* ctx, int algo, const repet_params* p);
 int repet_ctx_synchronize(repet_ctx* ctx);
+/* Per-stage device times of runs that are enqueued back to back (bench.py's timed region): between begin and end every
+ * repet_ctx_execute_async of this context (the first n_steps of them) records its own block of HIP events on the
+ * context's stream; end waits for the stream and returns the MEAN stage times over the runs made (names, bytes and
+ * flops as repet_ctx_execute's timing gives them). No host synchronisation happens between the runs. */
+int repet_ctx_timing_series_begin(repet_ctx* ctx, int32_t n_steps);
+int repet_ctx_timing_series_end(repet_ctx* ctx, repet_timing* mean, int32_t* n_steps /* nullable */);
 
 /* The steps either side of the path in every README example (README.md:64-98), kept on the device:
  * foreground_signal = audio_signal - background_signal (README.md:69) of the last run, float64 [n][C];

@@ -140,6 +140,9 @@ struct repet_ctx {
     std::vector<hipEvent_t> events;
     repet_timing* timing = nullptr;
     int n_marks = 0;
+    // timing series (repet_ctx_timing_series_begin): every asynchronous run records its own block of events
+    bool series_on = false; int series_cap = 0, series_steps = 0, series_marks = 0, event_base = 0;
+    repet_timing series_timing{};
 };
 
 namespace {
@@ -316,12 +319,12 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
 void mark(repet_ctx* c, const char* name, double bytes, double flops) {
     if (!c->timing) return;
     if (c->n_marks >= REPET_MAX_STAGES) return;
-    while ((int)c->events.size() < REPET_MAX_STAGES + 1) {
+    while ((int)c->events.size() < c->event_base + REPET_MAX_STAGES + 1) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
         c->events.push_back(e);
     }
-    (void)hipEventRecord(c->events[c->n_marks + 1], c->stream);
+    (void)hipEventRecord(c->events[c->event_base + c->n_marks + 1], c->stream);
     std::snprintf(c->timing->stage_name[c->n_marks], sizeof(c->timing->stage_name[0]), "%s", name);
     c->timing->stage_bytes[c->n_marks] = bytes;
     c->timing->stage_flops[c->n_marks] = flops;
@@ -333,20 +336,22 @@ void begin_timing(repet_ctx* c, repet_timing* t) {
     c->n_marks = 0;
     if (!t) return;
     std::memset(t, 0, sizeof(*t));
-    while ((int)c->events.size() < REPET_MAX_STAGES + 1) {
+    if (t != &c->series_timing) c->event_base = 0;
+    while ((int)c->events.size() < c->event_base + REPET_MAX_STAGES + 1) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { c->timing = nullptr; return; }
         c->events.push_back(e);
     }
-    (void)hipEventRecord(c->events[0], c->stream);
+    (void)hipEventRecord(c->events[c->event_base], c->stream);
 }
 
 void end_timing(repet_ctx* c) {
     if (!c->timing) return;
     repet_timing* t = c->timing;
     t->n_stages = c->n_marks;
-    for (int i = 0; i < c->n_marks; ++i) (void)hipEventElapsedTime(&t->stage_ms[i], c->events[i], c->events[i + 1]);
-    if (c->n_marks > 0) (void)hipEventElapsedTime(&t->total_ms, c->events[0], c->events[c->n_marks]);
+    const int b = c->event_base;
+    for (int i = 0; i < c->n_marks; ++i) (void)hipEventElapsedTime(&t->stage_ms[i], c->events[b + i], c->events[b + i + 1]);
+    if (c->n_marks > 0) (void)hipEventElapsedTime(&t->total_ms, c->events[b], c->events[b + c->n_marks]);
     c->timing = nullptr;
 }
 
@@ -1291,11 +1296,66 @@ int repet_ctx_execute_async(repet_ctx* c, int algo, const repet_params* p) {
     DeviceGuard guard(c->device);
     ChainScope chain(c);
     c->timing = nullptr;
+    const bool timed = c->series_on && c->series_steps < c->series_cap;
+    if (timed) {
+        c->event_base = c->series_steps * (REPET_MAX_STAGES + 1);
+        begin_timing(c, &c->series_timing);
+    }
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
     c->last_idx_batch = 1;
-    return run_algo(c, algo, p);
+    const int rc = run_algo(c, algo, p);
+    if (timed && c->timing) {
+        c->series_marks = c->n_marks;
+        c->series_steps++;
+    }
+    c->timing = nullptr;
+    return rc;
+}
+
+int repet_ctx_timing_series_begin(repet_ctx* c, int32_t n_steps) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    if (n_steps < 1 || n_steps > 4096) return fail(REPET_ERR_BAD_ARG, "timing series: 1 to 4096 steps");
+    DeviceGuard guard(c->device);
+    while ((int64_t)c->events.size() < (int64_t)n_steps * (REPET_MAX_STAGES + 1)) {      // created here, not inside the timed region
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->events.push_back(e);
+    }
+    c->series_on = true;
+    c->series_cap = n_steps;
+    c->series_steps = 0;
+    c->series_marks = 0;
+    return REPET_OK;
+}
+
+int repet_ctx_timing_series_end(repet_ctx* c, repet_timing* mean, int32_t* n_steps) {
+    if (!c || !mean) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    c->series_on = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *mean = c->series_timing;                                  // names, bytes, flops of the last run
+    mean->n_stages = c->series_marks;
+    mean->total_ms = 0.f;
+    for (int i = 0; i < REPET_MAX_STAGES; ++i) mean->stage_ms[i] = 0.f;
+    const int steps = c->series_steps;
+    for (int k = 0; k < steps; ++k) {
+        const int b = k * (REPET_MAX_STAGES + 1);
+        for (int i = 0; i < c->series_marks; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->events[b + i], c->events[b + i + 1]));
+            mean->stage_ms[i] += ms / steps;
+        }
+        if (c->series_marks > 0) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->events[b], c->events[b + c->series_marks]));
+            mean->total_ms += ms / steps;
+        }
+    }
+    if (n_steps) *n_steps = steps;
+    c->event_base = 0;
+    return REPET_OK;
 }
 
 int repet_ctx_synchronize(repet_ctx* c) {

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void rows_from_code_columns_kernel(RankArgs a)
 #ifndef REPET_RANK_LEAF_BITS
 #define REPET_RANK_LEAF_BITS 4
 #endif
-constexpr int kRankLeafBits = REPET_RANK_LEAF_BITS;          // the tree ends at leaves of 2^kRankLeafBits keys (<= 5: inside a padded row)
+// the tree ends at leaves of 2^bits keys (<= 5: inside a padded row); the 1 024-thread workgroup of N = 2^15 has 128 registers
+// per thread and keeps the one-node-per-thread form
+constexpr int rank_leaf_bits(int log2n) { return log2n >= 15 ? 5 : REPET_RANK_LEAF_BITS; }
 
 template <int LOG2N>
 __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArgs a) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
     // by the offset of the level's probe (key pos + step - 1): a probe is a ds_read of pos[e] itself, a compare, a
     // select and one three-input add (the move to the next level's bias). (cfg 2, the three kernels of the column sort:
     // no tree 0.191 ms; leaves of 32 keys 0.151, of 16 0.148, of 8 0.147 with 4 KB of tree.)
-    constexpr int R = kRankLeafBits, kTreeLevels = LOG2N - R, kNodes = N >> R;
+    constexpr int R = rank_leaf_bits(LOG2N), kTreeLevels = LOG2N - R, kNodes = N >> R;
     unsigned* tree = s + (N + N / 8);
     __syncthreads();                                           // the sorted column is complete
 #pragma unroll
@@ -313,7 +315,7 @@ bool rank_columns_supported(int64_t T) { return T > kRankMinFrames && T <= kRank
 template <int LOG2N>
 static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     constexpr int N = 1 << LOG2N;
-    constexpr int lds = (N + N / 8) * 4 + (N >> kRankLeafBits) * 4;        // the padded keys + the breadth-first copy of the leaf ends
+    constexpr int lds = (N + N / 8) * 4 + (N >> rank_leaf_bits(LOG2N)) * 4;        // the padded keys + the breadth-first copy of the leaf ends
     const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N>);
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;

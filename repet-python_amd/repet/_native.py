@@ -78,6 +78,8 @@ _SIGNATURES = {
     "repet_host_free": (None, [C.c_void_p]),
     "repet_ctx_execute_async": (C.c_int, [_P, C.c_int, C.POINTER(Params)]),
     "repet_ctx_synchronize": (C.c_int, [_P]),
+    "repet_ctx_timing_series_begin": (C.c_int, [_P, C.c_int32]),
+    "repet_ctx_timing_series_end": (C.c_int, [_P, C.POINTER(Timing), C.POINTER(C.c_int32)]),
     "repet_ctx_download_foreground": (C.c_int, [_P, _P]),
     "repet_ctx_spectrogram": (C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_int64]),
     "repet_extended_segment_count": (C.c_int64, [C.c_int64, C.POINTER(Params)]),
@@ -297,6 +299,18 @@ class Context:
 
     def synchronize(self):
         check(lib().repet_ctx_synchronize(self._h))
+
+    def timing_series_begin(self, n_steps):
+        """Every ``execute_async`` up to ``n_steps`` records its own per-stage events; no host wait between the runs."""
+        check(lib().repet_ctx_timing_series_begin(self._h, int(n_steps)))
+
+    def timing_series_end(self):
+        """Wait for the stream; mean per-stage device times over the runs since ``timing_series_begin``."""
+        t, n = Timing(), C.c_int32()
+        check(lib().repet_ctx_timing_series_end(self._h, C.byref(t), C.byref(n)))
+        d = t.as_dict()
+        d["steps"] = int(n.value)
+        return d
 
     def execute_extended_range(self, params, first, n_segments):
         check(lib().repet_ctx_execute_extended_range(self._h, C.byref(params), int(first), int(n_segments), None))

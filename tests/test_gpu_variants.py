@@ -873,3 +873,27 @@ def test_full_size_configs_against_reference_goldens(case, algo):
     ctx.execute(algo, p)
     assert rms_err(ctx.download(), 2.0 * y) < 2e-6
     ctx.close()
+
+
+@pytest.mark.parametrize("algo", ["sim", "extended"])
+def test_timing_series_of_back_to_back_runs(algo):
+    """bench.py's timed region: K runs enqueued without a host wait, each with its own per-stage events
+    (repet_ctx_timing_series_begin / _end). Same stages as the blocking call reports, same result bits."""
+    x = synth(40.0, 16000, 2, 5)
+    p = repet.derive_params(16000)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    blocking = ctx.execute(algo, p, timing=True)
+    want = ctx.download()
+    ctx.timing_series_begin(3)
+    for _ in range(4):                      # the fourth run is beyond the series: it runs, untimed
+        ctx.execute_async(algo, p)
+    series = ctx.timing_series_end()
+    assert series["steps"] == 3
+    assert [s["name"] for s in series["stages"]] == [s["name"] for s in blocking["stages"]]
+    assert all(s["ms"] > 0 for s in series["stages"])
+    assert [s["bytes"] for s in series["stages"]] == [s["bytes"] for s in blocking["stages"]]
+    assert abs(sum(s["ms"] for s in series["stages"]) - series["total_ms"]) <= 0.02 * series["total_ms"] + 1e-3
+    assert np.array_equal(ctx.download(), want)
+    again = ctx.execute(algo, p, timing=True)          # the blocking form still works afterwards
+    assert [s["name"] for s in again["stages"]] == [s["name"] for s in blocking["stages"]]
