@@ -119,6 +119,7 @@ struct repet_ctx {
     DevBuf amax;                  // inverse scale of every row of the matrix being split (scaled f16-split band Gram)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
     DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
+    bool refine_stats_cleared = false;   // ensure_spectra's housekeeping launch has zeroed them for the run being enqueued
     DevBuf R, Vs, rank_codes;     // rank codes of V, the sorted columns and the column-major codes (rank-domain median of `sim`, rank.hip)
     // geometry for which the constant median-pad rows of R are in place (they survive every run of that geometry)
     const void* r_pads_ptr = nullptr; int64_t r_pads_stride = 0, r_pads_row = 0; int r_pads_channels = 0, r_pads_fs = 0;
@@ -405,14 +406,16 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     HIP_TRY(c->V.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
     if (c->mask_plane) HIP_TRY(c->Mk.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
     if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
-    HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream));
     const size_t mean_elems = (size_t)g.Tpad * g.FS;
+    if (want_vn) HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
+    HIP_TRY(c->refine_stats.ensure(4 * sizeof(unsigned int)));
+    // one launch: the pad rows of V, zeros over the rows [T, Tpad) of every clip's unit spectra (the Gram tiles read
+    // them), the counters of the peak refinement (make_refine then skips its own clear)
+    HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream,
+                                 want_vn ? c->Vn.as<float>() + g.T * g.FS : nullptr, (int64_t)mean_elems,
+                                 (int64_t)(g.Tpad - g.T) * g.FS, B, c->refine_stats.as<unsigned int>()));
+    c->refine_stats_cleared = true;
     if (want_vn) {
-        HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
-        // rows [T, Tpad) of every clip must read as zero for the Gram tiles: one strided fill for the whole batch
-        if (g.Tpad > g.T)
-            HIP_TRY(hipMemset2DAsync(c->Vn.as<float>() + g.T * g.FS, mean_elems * sizeof(float), 0,
-                                     (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), (size_t)B, c->stream));
         if (split_in_stft()) {
             // the f16 planes of the unit rows, written by the STFT beside Vn (same bytes per row: 2 planes x 2 bytes);
             // the big-tile Gram kernel reads (and ignores) up to round_up(T, 256) rows of a single clip
@@ -766,7 +769,8 @@ float peak_refine_delta(int FS, bool f16_gram) {
 
 int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, PeakRefine* rf) {
     HIP_TRY(c->refine_stats.ensure(4 * sizeof(unsigned int)));
-    HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, 4 * sizeof(unsigned int), c->stream));
+    if (!c->refine_stats_cleared) HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, 4 * sizeof(unsigned int), c->stream));
+    c->refine_stats_cleared = false;
     rf->unit_rows = unit_rows; rf->pitch = FS; rf->delta = peak_refine_delta(FS, gram_f16_enabled()); rf->min_value = threshold;
     rf->stats = c->refine_stats.as<unsigned int>();
     return REPET_OK;

@@ -161,17 +161,26 @@ int median_network_instructions(int max_n, int* net_size) {
     return out;
 }
 
-__global__ void fill_pad_rows_kernel(float* V, int64_t chan_stride, int64_t pad_row, int FS) {
-    const int c = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= 2 * FS) return;
-    V[c * chan_stride + pad_row * FS + k] = (k < FS) ? -1.0f : INFINITY;
+// Housekeeping in front of a pipeline, one launch: the two pad rows of V (-1 and +inf: what the networks read for the slots
+// past a list's end), optionally zeros over `z_count` floats of each of `n_z` regions of Z (the rows [T, Tpad) of the unit
+// spectra, which the Gram tiles read), optionally the four counters of the peak refinement. (Three launches before: a
+// fill kernel, a 2-D memset, a 16-byte memset -- 14 us in front of a 68-us STFT.)
+__global__ void fill_pad_rows_kernel(float* V, int64_t chan_stride, int n_channels, int64_t pad_row, int FS,
+                                     float* Z, int64_t z_stride, int64_t z_count, int n_z, unsigned int* stats) {
+    const int y = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < n_channels && k < 2 * FS) V[y * chan_stride + pad_row * FS + k] = (k < FS) ? -1.0f : INFINITY;
+    if (y < n_z && 4 * k < z_count) *reinterpret_cast<float4*>(Z + y * z_stride + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (stats && y == 0 && k < 4) stats[k] = 0u;
 }
 
 hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)ceil_div(2 * FS, 256), (unsigned)n_channels), dim3(256), 0, s,
-                       V, chan_stride, pad_row, FS);
+                                hipStream_t s, float* Z, int64_t z_stride, int64_t z_count, int32_t n_z, unsigned int* stats) {
+    if (!Z || z_count <= 0) { Z = nullptr; z_count = 0; n_z = 0; }
+    if ((z_count & 3) || (z_stride & 3)) return hipErrorInvalidValue;
+    const int64_t per_row = std::max<int64_t>(2 * FS, z_count / 4);
+    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)ceil_div(per_row, 256), (unsigned)std::max(n_channels, n_z)), dim3(256), 0, s,
+                       V, chan_stride, n_channels, pad_row, FS, Z, z_stride, z_count, n_z, stats);
     return hipGetLastError();
 }
 
