@@ -194,7 +194,7 @@ def main():
     # no host wait between them (a blocking call per step left the device idle for 25-30 us while the host read its events).
     # Every step still records its own per-stage HIP events on that stream (timing series): the stage times below are
     # the means over exactly these K steps.
-    series = len(ctxs) == 1 and not args.sync_steps
+    series = len(ctxs) == 1 and not args.sync_steps and 1 <= args.steps <= 4096      # (the series holds 17 events per step)
     if series:
         ctxs[0].timing_series_begin(args.steps)
     for _ in range(args.steps):
