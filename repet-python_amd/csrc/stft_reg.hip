@@ -158,7 +158,7 @@ struct __attribute__((packed, aligned(4))) Float4A { float x, y, z, w; };       
 struct __attribute__((packed, aligned(4))) Float2A { float x, y; };
 
 template <int CMODE>      // 2: stereo float4 path, 1: mono float2 path, 0: any channel count, element loads
-__global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, int64_t units) {
+__global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, int64_t units, int balance) {
     constexpr int N = kRegN, W = 2 * kRegN;
     extern __shared__ __attribute__((aligned(16))) float2 fwd_lds[];
     float2* ex_all = fwd_lds;
@@ -187,8 +187,19 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
     // round k of the launch: workgroup b's twelve waves take the twelve CONSECUTIVE frames (k gridDim + b) 12 + wave, so
     // the half frame two neighbours share is asked for by the same CU at about the same time
     const int64_t stride = (int64_t)gridDim.x * kFwdWaves;
+    // the frames left after the whole rounds are dealt over ALL workgroups (`last` each, in the first waves) rather than
+    // twelve each to the first few
+    const int64_t whole = balance ? units / stride : (units + stride - 1) / stride;
+    const int64_t rest = units - whole * stride;
+    const int last = balance ? (int)((rest + gridDim.x - 1) / gridDim.x) : 0;
 
-    for (int64_t u = (int64_t)blockIdx.x * kFwdWaves + wave; u < units; u += stride) {
+    for (int64_t k = 0; k <= whole; ++k) {
+        int64_t u = k * stride + (int64_t)blockIdx.x * kFwdWaves + wave;
+        if (k == whole) {
+            if (wave >= last) break;
+            u = whole * stride + (int64_t)blockIdx.x * last + wave;
+        }
+        if (u >= units) break;
         const int64_t b = a.n_batch > 1 ? (int64_t)((uint32_t)u / (uint32_t)a.T) : 0;     // launch_stft_reg: units < 2^31
         const int64_t t = u - b * a.T;
         const int64_t start = t * a.H - (a.centred ? W / 2 : 0);
@@ -611,10 +622,11 @@ hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s) {
         return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(units, kFwdWaves), cus);
+    static const int balance = [] { const char* e = getenv("REPET_FWD_BALANCE"); return e ? atoi(e) : 1; }();
     const size_t dyn = (size_t)kFwdLdsFloat2 * sizeof(float2);
     auto go = [&](auto kernel) {
         (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)dyn);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * kFwdWaves), dyn, s, a, units);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * kFwdWaves), dyn, s, a, units, balance);
     };
     if (a.n_channels == 2) go(&stft_reg_kernel<2>);
     else if (a.n_channels == 1) go(&stft_reg_kernel<1>);
