@@ -156,8 +156,18 @@ __global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __res
     const bool diag = bi == bj;
     float* patch = reinterpret_cast<float*>(lds_big) + wave * (64 * kPatchPitch);
     const int srow = lane >> 4, scol = (lane & 15) * 4;          // store role: row srow + 4 k of the patch, floats scol .. scol+3
+    // a tile away from the diagonal and from the matrix's edge stores whole float4s without a test (wave-uniform choice:
+    // with the tests in the loop the compiler splits every float4 into a dword and a dwordx3 store under exec masks)
+    const bool interior = !diag && a_row0 + BT <= T && b_row0 + BT <= T;
     auto store_rows = [&](int64_t row0, int64_t col0, bool transposed) {
         // patch row p, float q is S[row0 + p][col0 + q]; on diagonal tiles the natural copy keeps i <= j, the mirror i < j
+        if (interior) {
+            float* dst0 = out + (row0 + srow) * pitch + col0 + scol;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                *reinterpret_cast<float4*>(dst0 + (int64_t)(4 * k) * pitch) = *reinterpret_cast<const float4*>(patch + (srow + 4 * k) * kPatchPitch + scol);
+            return;
+        }
 #pragma unroll 4
         for (int k = 0; k < 16; ++k) {
             const int p = srow + 4 * k;
