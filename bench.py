@@ -180,6 +180,12 @@ def main():
     # The device reaches its steady clocks only after some tens of milliseconds of work (a 1.1-ms step measures 1.26 ms
     # right after start, 1.16 after three steps, 1.11 after thirty): an untimed pre-warm by wall time, declared in the
     # line as config.prewarm_ms, precedes the W warm-up steps so that small W / K do not measure the ramp.
+    if dist is not None:
+        # A fresh RCCL communicator does its real set-up at its first collectives, and the device runs slower for a while
+        # afterwards (steps timed right behind the first barrier: 1.26 / 1.18 / 1.14 ms at K = 5 / 10 / 20 against 1.03):
+        # the first barriers are spent HERE, in front of the pre-warm, so that the timed region starts on a settled device.
+        for _ in range(4):
+            barrier()
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
         for ctx in ctxs:
