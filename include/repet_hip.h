@@ -284,6 +284,14 @@ int repet_ctx_last_frame_count(repet_ctx* ctx, int64_t* n_frames);
  * repet.py:1294-1345): out[0] rows with a decision inside the fp32 tolerance, out[1] near-tied elements
  * re-decided from float64 similarities, out[2] decisions that changed, out[3] flat rows left to fp32. */
 int repet_ctx_last_refine_stats(repet_ctx* ctx, int64_t out[4]);
+/* The second level of the same peak picking: the reference decides on float64 similarities of complex128 spectra
+ * (repet.py:149, :1220-1223, :1318-1326). Rows whose float64 re-decision on the fp32 spectra met a comparison the fp32
+ * spectra cannot settle (closer than 2.5e-7), and flat rows, are decided again from float64 spectra computed from the
+ * waveform. out[0] rows decided again, out[1] elements given float64 spectra, out[2] rows whose list changed,
+ * out[3] largest |fp32-spectra value - float64-spectra value| met, in units of 1e-12, out[4] float64 unit rows computed,
+ * out[5] 1 when the resident clip carries the fp32 remainders of a float64 upload (48-bit samples), out[6] rows taken up
+ * again from the first pass's records (the fast path), out[7] of those, rows handed on to the general path. */
+int repet_ctx_last_exact_stats(repet_ctx* ctx, int64_t out[8]);
 
 /* ---- streaming online REPET-SIM (the reference's simonline needs the whole signal, repet.py:712-911) ------
  * open  : state for one stream of n_channels (1, 2 or 4) with the parameters of derive_params(fs);

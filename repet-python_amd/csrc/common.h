@@ -215,17 +215,56 @@ hipError_t launch_expand_periods(const int32_t* win_period, int32_t n_windows, i
 //           re-taken from float64 similarities of those rows, so the index lists do not depend on the fp32
 //           rounding of the Gram kernel. stats (nullable, 4 counters, added to): rows refined, near-tied
 //           elements, decisions changed, flat rows left to fp32.
-struct PeakRefine { const float* unit_rows; int32_t pitch; float delta; double min_value; unsigned int* stats; };
+//           Second level (peaks_exact.hip; redo_list != nullptr): the float64 values above still carry the rounding of
+//           the fp32 spectra. Rows with such a comparison closer than delta2 (and flat rows) are appended to
+//           redo_list[2 k] = row, [2 k + 1] = clip (capacity rows x clips; count in stats[4]); redo_flag[clip * flag_stride
+//           + row] == gen marks a listed row. launch_local_maxima_exact then decides those rows from float64 spectra.
+constexpr int kRefineStats = 32;   // counters behind PeakRefine::stats: [0] rows refined, [1] near-tied elements, [2] decisions
+                                   // changed, [3] flat rows, [4] rows handed to the second level, [5] its work cursor,
+                                   // [6] elements given float64 spectra, [7] rows whose list the second level changed,
+                                   // [8] largest |level 1 - level 2| in units of 1e-12, [9] float64 unit rows computed,
+                                   // [10] frames queued for float64 spectra, [11] the queue's cursor, [12] rows with a record
+                                   // (fast path), [13] their cursor, [14] rows the fast path handed on to the general one
+struct PeakRefine {
+    const float* unit_rows; int32_t pitch; float delta; double min_value; unsigned int* stats;
+    double delta2; int32_t* redo_list; unsigned int* redo_flag; unsigned int gen; int64_t flag_stride;
+    // fast path of the wavefront kernel (peaks_wave.hip; nullable): records of the rows' lists, their list and flags, the
+    // queue of frames whose float64 unit rows are needed (frame = clip * frame_clip_stride + frame row)
+    unsigned char* records; int32_t record_bytes; int32_t* lite_list; unsigned int* lite_flag;
+    int32_t* frame_list; unsigned int* frame_flag; int64_t frame_clip_stride;
+};
 // batch (nullable): blockIdx.y = clip of a batch of equal-shape matrices; element strides between the clips
 struct PeakBatch { int32_t n_batch; int64_t m_stride, idx_stride, cnt_stride, unit_stride; };
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0,
                                const PeakRefine* refine = nullptr, const PeakBatch* batch = nullptr,
-                               void* scratch = nullptr);
+                               void* scratch = nullptr, const struct ExactSource* lite_src = nullptr);
+//   lite_src (second level, fast path): instead of the first pass, the rows it left records of (PeakRefine::records)
+//           are taken up again with the float64 unit rows of lite_src (same matrix arguments as the first call).
+bool local_maxima_wave_supported(int n_cols, int d, int* record_bytes);
+hipError_t launch_unit_rows_f64(const struct ExactSource& src, const PeakRefine* refine, hipStream_t s);
 //   scratch (nullable): local_maxima_scratch_bytes(n_rows, n_cols, d) bytes (0 for rows that fit one workgroup). With
 //           it, rows of any length are handled in segments; without it the limit is about 40 000 elements per row.
 size_t local_maxima_scratch_bytes(int64_t n_rows, int32_t n_cols, int32_t d);
+
+// K4, second level (peaks_exact.hip): where the float64 spectra of a frame row come from. Frame row fr of clip b covers the
+// samples frame_sample0 + fr * H .. + W - 1 of hi (+ lo, nullable: the fp32 remainder of a float64 upload), zero outside
+// [0, n_samples). u64[b * u64_clip_stride + fr * FS ..] caches the unit rows, valid where u64_gen[b * gen_clip_stride + fr]
+// equals the launch's generation (PeakRefine::gen).
+struct ExactSource {
+    const float* hi; const float* lo; int64_t n_samples; int32_t n_channels; int64_t clip_stride;
+    int64_t frame_sample0; int32_t W, H, F, FS;
+    const double* window64; const double2* twiddle64;      // twiddle64[m] = exp(-2 pi i m / W), m <= W
+    double* u64; int64_t u64_clip_stride; unsigned int* u64_gen; int64_t gen_clip_stride;
+};
+// Decides the rows listed by the first pass again (same matrix arguments as launch_local_maxima; fixed grid, the count is
+// read on the device). scratch: local_maxima_exact_scratch_bytes(n_cols) bytes.
+size_t local_maxima_exact_scratch_bytes(int32_t n_cols, int* grid_out = nullptr);
+hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_cols, int64_t pitch, int32_t mode, float min_value,
+                                     int32_t d, int32_t number, int32_t* idx, int32_t idx_pitch, int32_t* count, hipStream_t s,
+                                     int64_t shift, const PeakRefine* refine, const PeakBatch* batch, const ExactSource& src,
+                                     void* scratch);
 
 // K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
 // multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).
@@ -241,6 +280,12 @@ struct MaskArgs {
     // 0x7C00 at pad_row, pad_row+1) and the rank -> value table Vs[c][f][vs_pitch] of the first n_rank_cols bins of
     // every channel. R == nullptr: select on the floats themselves.
     const unsigned short* R; int64_t r_chan_stride; const float* Vs; int64_t vs_pitch; int32_t n_rank_cols;
+    // mask_sim (rank path and its Nyquist-bin kernel): rows whose list the second level of the peak picking is still
+    // deciding (flag_a[row] or flag_b[row] == defer_gen) are left out (defer_mode 1) or are the only ones taken (2)
+    const unsigned int* defer_a; const unsigned int* defer_b; unsigned int defer_gen; int32_t defer_mode;
+    // launch_mask_sim_rows: the frames are taken from row_list[2 k] for k < *row_count (one workgroup per entry and channel);
+    // defer_mode 3 leaves out the entries whose defer_b flag is set (they are on the other list too)
+    const int32_t* row_list; const unsigned int* row_count;
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
@@ -253,6 +298,10 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
                            hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3);
+// the same masks for the listed rows only (the rows the second level of the peak picking decided late), all F bins on the
+// float kernel -- bit-identical to the rank path; n_rows_cap: upper bound of the list length (grid size)
+hipError_t launch_mask_sim_rows(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
+                                int32_t max_count, int64_t n_rows_cap, hipStream_t s);
 int median_network_instructions(int max_n, int* net_size);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
@@ -282,14 +331,17 @@ struct StagingRing {
     static constexpr int kSlots = 6;
     static constexpr size_t kSlotElems = (size_t)1 << 20;      // 4 MB of fp32 per slot
     float* base = nullptr;
+    float* base_lo = nullptr;      // second ring for the fp32 remainders of float64 uploads (ensure_lo)
     hipEvent_t event[kSlots] = {};
     bool busy[kSlots] = {};
     hipError_t ensure();
+    hipError_t ensure_lo();
     void release();
     ~StagingRing();
 };
 // dtype: 0 float32, 1 float64, 2 int16 (REPET_F32 / F64 / I16)
-hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s);
+hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s,
+                         float* dst_lo = nullptr, bool* any_lo = nullptr);
 hipError_t staged_download(StagingRing& ring, const float* src, double* dst, size_t count, hipStream_t s);
 hipError_t staged_upload_bytes(StagingRing& ring, const void* src, void* dst, size_t n_bytes, hipStream_t s);
 // WAVE files (wav.hip): header parsing on the host, PCM decode + wavread's normalisation on the device

@@ -81,6 +81,7 @@ struct DevBuf {
 
 struct Tables {
     DevBuf window, twiddle;
+    DevBuf window64, twiddle64;   // the same in float64 (second level of the peak picking, peaks_exact.hip): W and W + 1 entries
     double cola = 1.0;   // sum(window[0:W:H]) for H = W/2 (repet.py:1103)
 };
 
@@ -120,7 +121,14 @@ struct repet_ctx {
     DevBuf beat_partial;          // chunk sums of the beat-spectrum windows (launch_band_window_sum)
     DevBuf amax;                  // inverse scale of every row of the matrix being split (scaled f16-split band Gram)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
-    DevBuf refine_stats;          // 4 counters of the last sim/simonline run (PeakRefine::stats)
+    DevBuf refine_stats;          // kRefineStats counters of the last sim/simonline run (PeakRefine::stats)
+    // second level of the peak picking (peaks_exact.hip): the fp32 remainders of a float64 upload (audio = hi, audio_lo = lo,
+    // hi + lo = 48 bits of the caller's sample; empty when every remainder was zero or the input was not float64), the rows
+    // handed over, the table of float64 unit rows with its generation stamps, the row workspaces of the fixed grid
+    DevBuf audio_lo; bool has_lo = false;
+    DevBuf redo_list, redo_flag, u64, u64_gen, exact_scratch;
+    DevBuf lite_list, lite_flag, lite_records, frame_list, frame_flag;   // the wavefront kernel's fast path (peaks_wave.hip)
+    unsigned int exact_gen = 0;
     bool refine_stats_cleared = false;   // ensure_spectra's housekeeping launch has zeroed them for the run being enqueued
     DevBuf R, Vs, rank_codes;     // rank codes of V, the sorted columns and the column-major codes (rank-domain median of `sim`, rank.hip)
     // geometry for which the constant median-pad rows of R are in place (they survive every run of that geometry)
@@ -174,6 +182,12 @@ int get_tables(repet_ctx* c, int W, Tables** out) {
         tw[n] = make_float2((float)std::cos(two_pi * n / W), (float)(-std::sin(two_pi * n / W)));
     }
     t->cola = wd[0] + wd[W / 2];
+    std::vector<double2> tw64(W + 1);
+    for (int n = 0; n <= W; ++n) tw64[n] = make_double2(std::cos(two_pi * n / W), -std::sin(two_pi * n / W));
+    HIP_TRY(t->window64.ensure(W * sizeof(double)));
+    HIP_TRY(t->twiddle64.ensure(tw64.size() * sizeof(double2)));
+    HIP_TRY(hipMemcpyAsync(t->window64.p, wd.data(), W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(t->twiddle64.p, tw64.data(), tw64.size() * sizeof(double2), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(t->window.ensure(W * sizeof(float)));
     HIP_TRY(t->twiddle.ensure(W * sizeof(float2)));
     HIP_TRY(hipMemcpyAsync(t->window.p, win.data(), W * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -410,7 +424,7 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
     const size_t mean_elems = (size_t)g.Tpad * g.FS;
     if (want_vn) HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
-    HIP_TRY(c->refine_stats.ensure(4 * sizeof(unsigned int)));
+    HIP_TRY(c->refine_stats.ensure(kRefineStats * sizeof(unsigned int)));
     // one launch: the pad rows of V, zeros over the rows [T, Tpad) of every clip's unit spectra (the Gram tiles read
     // them), the counters of the peak refinement (make_refine then skips its own clear)
     HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream,
@@ -769,12 +783,96 @@ float peak_refine_delta(int FS, bool f16_gram) {
     return scale * sqrtf((float)FS) * 5.9604645e-8f;
 }
 
-int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, PeakRefine* rf) {
-    HIP_TRY(c->refine_stats.ensure(4 * sizeof(unsigned int)));
-    if (!c->refine_stats_cleared) HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, 4 * sizeof(unsigned int), c->stream));
+// Second level (peaks_exact.hip): a float64 comparison of the fp32 spectra closer than this is decided again from float64
+// spectra. The level-1 values are off by up to 9.3e-8 against the float64 reference (rms 1.2e-8: fp32 FFT, magnitudes and
+// unit rows; tools/level_error_probe.py; on the device `level2_max_diff` of repet_ctx_last_exact_stats reports the largest
+// difference met), a comparison of two of them by up to twice that. REPET_PEAK_EXACT=0 turns the second level off,
+// REPET_PEAK_DELTA2 overrides the band.
+double peak_exact_delta2() {
+    static const double v = [] {
+        const char* off = getenv("REPET_PEAK_EXACT");
+        if (off && off[0] == '0') return 0.0;
+        const char* e = getenv("REPET_PEAK_DELTA2");
+        return e ? atof(e) : 2.5e-7;
+    }();
+    return v;
+}
+
+// A flag array of `count` generation stamps: grown (and cleared) when too small; stamps of earlier runs never match a new
+// generation, so it is not cleared between runs.
+int ensure_stamps(repet_ctx* c, DevBuf& buf, size_t count) {
+    if (buf.cap >= count * sizeof(unsigned int)) return REPET_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(buf.ensure(count * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(buf.p, 0, buf.cap, c->stream));
+    return REPET_OK;
+}
+
+// rows x clips: the rows one launch_local_maxima call may hand to the second level (0: no second level for this call);
+// n_cols, d: the call's row length and window (the wavefront kernel's fast path applies to its shapes); frames: frame
+// rows per clip (the float64 unit-row table)
+int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, PeakRefine* rf, int64_t rows = 0, int clips = 1,
+                int n_cols = 0, int d = 0, int64_t frames = 0) {
+    HIP_TRY(c->refine_stats.ensure(kRefineStats * sizeof(unsigned int)));
+    if (!c->refine_stats_cleared) HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, kRefineStats * sizeof(unsigned int), c->stream));
     c->refine_stats_cleared = false;
+    *rf = PeakRefine{};
     rf->unit_rows = unit_rows; rf->pitch = FS; rf->delta = peak_refine_delta(FS, gram_f16_enabled()); rf->min_value = threshold;
     rf->stats = c->refine_stats.as<unsigned int>();
+    if (rows > 0 && rf->delta > 0.0f && peak_exact_delta2() > 0.0) {
+        const size_t total = (size_t)rows * clips;
+        HIP_TRY(c->redo_list.ensure(total * 2 * sizeof(int32_t)));
+        RP_TRY(ensure_stamps(c, c->redo_flag, total));
+        rf->delta2 = peak_exact_delta2(); rf->redo_list = c->redo_list.as<int32_t>(); rf->redo_flag = c->redo_flag.as<unsigned int>();
+        rf->gen = ++c->exact_gen; rf->flag_stride = rows;
+        static const bool lite_on = [] { const char* e = getenv("REPET_PEAK_LITE"); return !(e && e[0] == '0'); }();
+        int record_bytes = 0;
+        if (lite_on && frames > 0 && local_maxima_wave_supported(n_cols, d, &record_bytes)) {
+            HIP_TRY(c->lite_list.ensure(total * 2 * sizeof(int32_t)));
+            RP_TRY(ensure_stamps(c, c->lite_flag, total));
+            HIP_TRY(c->lite_records.ensure(total * (size_t)record_bytes));
+            HIP_TRY(c->frame_list.ensure((size_t)frames * clips * sizeof(int32_t)));
+            RP_TRY(ensure_stamps(c, c->frame_flag, (size_t)frames * clips));
+            rf->records = c->lite_records.as<unsigned char>(); rf->record_bytes = record_bytes;
+            rf->lite_list = c->lite_list.as<int32_t>(); rf->lite_flag = c->lite_flag.as<unsigned int>();
+            rf->frame_list = c->frame_list.as<int32_t>(); rf->frame_flag = c->frame_flag.as<unsigned int>();
+            rf->frame_clip_stride = frames;
+        }
+    }
+    return REPET_OK;
+}
+
+// The second level behind a launch_local_maxima call with the same matrix arguments: float64 spectra of frame row fr of clip
+// b start at sample frame_sample0 + fr * H of `hi` (+ `lo`), clips clip_stride elements apart, n_frames rows per clip.
+int run_exact_rows(repet_ctx* c, const Tables* tb, const Geo& g, const float* M, int64_t row0, int n_cols, int64_t pitch, int mode,
+                   float min_value, int d, int number, int32_t* idx, int idx_pitch, int32_t* count, int64_t shift,
+                   const PeakRefine& rf, const PeakBatch* batch, const float* hi, const float* lo, int64_t n_samples,
+                   int64_t clip_stride, int64_t frame_sample0, int64_t n_frames, int clips, hipStream_t stream = nullptr) {
+    if (!rf.redo_list) return REPET_OK;
+    if (!stream) stream = c->stream;
+    ExactSource src{};
+    src.hi = hi; src.lo = lo; src.n_samples = n_samples; src.n_channels = g.C; src.clip_stride = clip_stride;
+    src.frame_sample0 = frame_sample0; src.W = g.W; src.H = g.H; src.F = g.F; src.FS = g.FS;
+    src.window64 = tb->window64.as<double>(); src.twiddle64 = tb->twiddle64.as<double2>();
+    const size_t rows = (size_t)n_frames * clips;
+    HIP_TRY(c->u64.ensure(rows * g.FS * sizeof(double)));
+    if (c->u64_gen.cap < rows * sizeof(unsigned int)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(c->u64_gen.ensure(rows * sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(c->u64_gen.p, 0, c->u64_gen.cap, c->stream));
+    }
+    src.u64 = c->u64.as<double>(); src.u64_clip_stride = n_frames * (int64_t)g.FS;
+    src.u64_gen = c->u64_gen.as<unsigned int>(); src.gen_clip_stride = n_frames;
+    if (rf.lite_list) {
+        // fast path: the float64 unit rows of the queued frames, then the recorded rows again with them
+        HIP_TRY(launch_unit_rows_f64(src, &rf, stream));
+        HIP_TRY(launch_local_maxima(M, 0, row0, n_cols, pitch, mode, min_value, d, number, idx, idx_pitch, count, stream, shift,
+                                    &rf, batch, nullptr, &src));
+    }
+    // general path: flat rows, rows of the workgroup kernel, rows the fast path handed on
+    HIP_TRY(c->exact_scratch.ensure(local_maxima_exact_scratch_bytes(n_cols)));
+    HIP_TRY(launch_local_maxima_exact(M, row0, n_cols, pitch, mode, min_value, d, number, idx, idx_pitch, count, stream, shift,
+                                      &rf, batch, src, c->exact_scratch.p));
     return REPET_OK;
 }
 
@@ -851,7 +949,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
     const int n_chunks = sim_chunks(T);
     PeakRefine rf{};
-    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf));
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf, n_chunks <= 1 ? T : 0, 1, (int)T, p->sim_distance_frames, T));
     if (n_chunks <= 1) {
         MaskArgs m = mask_args(c, g, p->cutoff_bins);
         const bool use_rank = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
@@ -877,6 +975,27 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
                                            nullptr, scratch > 0 ? c->peak_scratch.p : nullptr);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
+        // The second level of the peak picking (float64 spectra for the rows the fp32 spectra cannot settle: a few hundred of
+        // 7 753) takes 0.15 ms of small latency-bound kernels. With the rank-domain median it runs on the side stream
+        // behind the column sort, BESIDE the median mask of all the other rows; the rows it is deciding are masked
+        // afterwards (REPET_EXACT_DEFER=0: in line, before the mask).
+        static const bool defer_on = [] { const char* e = getenv("REPET_EXACT_DEFER"); return !(e && e[0] == '0'); }();
+        const bool defer = defer_on && beside && rf.redo_list != nullptr && rf.lite_flag != nullptr;
+        auto exact_rows = [&](hipStream_t st) {
+            return run_exact_rows(c, tb, g, c->S.as<float>(), 0, (int)T, TS, 0, (float)p->sim_threshold, p->sim_distance_frames, K,
+                                  c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, rf, nullptr,
+                                  c->audio.as<float>() + c->clip_base * g.C, c->has_lo ? c->audio_lo.as<float>() + c->clip_base * g.C : nullptr,
+                                  N, 0, -(int64_t)(g.W / 2), T, 1, st);
+        };
+        if (defer) {
+            RP_TRY(ensure_chunk_events(c, 2));
+            HIP_TRY(hipEventRecord(c->chunk_events[0], c->stream));                 // the first pass is done
+            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->chunk_events[0], 0));
+            RP_TRY(exact_rows(c->side_stream));
+            HIP_TRY(hipEventRecord(c->chunk_events[1], c->side_stream));
+        } else {
+            RP_TRY(exact_rows(c->stream));
+        }
         if (beside) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->join_event, 0));
             // one figure for the two concurrent launches: their bytes added up (S read once + the sort's passes over V)
@@ -885,8 +1004,22 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
             if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true));
         }
-        HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
-                                c->fork_event, c->join_event));
+        if (defer) {
+            m.defer_a = rf.lite_flag; m.defer_b = rf.redo_flag; m.defer_gen = rf.gen; m.defer_mode = 1;
+            HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
+                                    c->fork_event, c->join_event));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_events[1], 0));
+            // the rows decided late, from the two lists (a row the fast path handed on is on both: taken from the second)
+            MaskArgs late = m;
+            late.R = nullptr;
+            late.defer_mode = 3; late.row_list = rf.lite_list; late.row_count = rf.stats + 12;
+            HIP_TRY(launch_mask_sim_rows(late, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), max_peaks, T, c->stream));
+            late.defer_mode = 0; late.row_list = rf.redo_list; late.row_count = rf.stats + 4;
+            HIP_TRY(launch_mask_sim_rows(late, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), max_peaks, T, c->stream));
+        } else {
+            HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
+                                    c->fork_event, c->join_event));
+        }
         mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     } else {
         // Peak picking is LDS/latency-bound, the median mask VALU-bound: run them as a two-stage pipeline over
@@ -952,13 +1085,18 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->idx.ensure((size_t)nb * rows_alloc * KP * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)nb * rows_alloc * sizeof(int32_t)));
     PeakRefine rf{};
-    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf));
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf, rows, nb, B, p->sim_distance_frames, T));
     const PeakBatch pb{nb, band_stride, rows_alloc * KP, rows_alloc, mean_stride};
     hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
                                        p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf,
                                        nb > 1 ? &pb : nullptr);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
     HIP_TRY(e);
+    if (rows > 0)
+        RP_TRY(run_exact_rows(c, tb, g, c->band.as<float>(), B - 1, B, LP, 1, (float)p->sim_threshold, p->sim_distance_frames, K,
+                              c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, rf, nb > 1 ? &pb : nullptr,
+                              c->audio.as<float>() + c->clip_base * g.C, c->has_lo ? c->audio_lo.as<float>() + c->clip_base * g.C : nullptr,
+                              N, N * g.C, 0, T, nb));
     mark(c, "local_maxima", nb * (4.0 * rows * B + 4.0 * K * rows), 0);
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
     MaskArgs m = mask_args(c, g, p->cutoff_bins);
@@ -1131,9 +1269,11 @@ int repet_ctx_destroy(repet_ctx* c) {
     c->ring.release();
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Mk, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
                       &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
+                      &c->audio_lo, &c->redo_list, &c->redo_flag, &c->u64, &c->u64_gen, &c->exact_scratch,
+                      &c->lite_list, &c->lite_flag, &c->lite_records, &c->frame_list, &c->frame_flag,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
-    for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); }
+    for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); kv.second->window64.release(); kv.second->twiddle64.release(); }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     for (hipStream_t b : c->ballast_streams) (void)hipStreamDestroy(b);
@@ -1208,7 +1348,16 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     // narrowed to fp32 by host threads into the pinned ring, chunk by chunk, each chunk DMA'd while the next is
     // converted; the caller's array has been read completely when this returns (the last DMAs may still be in flight
     // on the context's stream, which every later operation of the context is ordered behind)
-    HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream));
+    // float64 input: the fp32 remainders travel too where they are not zero (peaks_exact.hip takes its float64 spectra from
+    // sample + remainder); REPET_INPUT_LO=0 drops them (the second level then works on the fp32 samples alone)
+    static const bool want_lo = [] { const char* e = getenv("REPET_INPUT_LO"); return !(e && e[0] == '0'); }();
+    c->has_lo = false;
+    float* lo_dst = nullptr;
+    if (dtype == REPET_F64 && want_lo && count > 0) {
+        HIP_TRY(c->audio_lo.ensure((size_t)count * sizeof(float)));
+        lo_dst = c->audio_lo.as<float>();
+    }
+    HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream, lo_dst, &c->has_lo));
     c->n_samples = n;
     c->n_channels = ch;
     c->n_clips = n_clips;
@@ -1227,6 +1376,7 @@ int repet_ctx_upload_device(repet_ctx* c, const float* dev_audio, int64_t n, int
     // device -> device (peer memory works as well); the source may be reused when this returns
     HIP_TRY(hipMemcpyAsync(c->audio.p, dev_audio, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->has_lo = false;
     c->n_samples = n; c->n_channels = ch; c->n_clips = n_clips; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
     return REPET_OK;
@@ -1480,6 +1630,7 @@ int repet_ctx_upload_wav(repet_ctx* c, const void* file_bytes, int64_t n_bytes, 
     HIP_TRY(c->staging.ensure(std::max<size_t>(raw_bytes, 256)));
     HIP_TRY(staged_upload_bytes(c->ring, static_cast<const unsigned char*>(file_bytes) + w.data_offset, c->staging.p, raw_bytes, c->stream));
     HIP_TRY(launch_decode_pcm(c->staging.p, w.format, w.bytes_per_sample, c->audio.as<float>(), count, c->stream));
+    c->has_lo = false;
     c->n_samples = w.n_samples; c->n_channels = w.n_channels; c->n_clips = 1; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
     c->last_fs = w.sampling_frequency;
@@ -1948,6 +2099,30 @@ int repet_ctx_last_frame_count(repet_ctx* c, int64_t* n_frames) {
     *n_frames = c->last_T;
     return REPET_OK;
 }
+
+int repet_ctx_last_exact_stats(repet_ctx* c, int64_t out[8]) {
+    if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    out[5] = c->has_lo ? 1 : 0;
+    if (!c->refine_stats.p) return REPET_OK;
+    DeviceGuard guard(c->device);
+    unsigned int host[kRefineStats] = {};
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->refine_stats.p, sizeof(host), hipMemcpyDeviceToHost));
+    out[0] = host[4] + host[12] - host[14]; out[1] = host[6]; out[2] = host[7]; out[3] = host[8]; out[4] = host[9];
+    out[6] = host[12]; out[7] = host[14];
+    return REPET_OK;
+}
+
+#ifdef REPET_EXACT_STAMPS
+int repet_debug_exact_phases(repet_ctx* c, int64_t out[6]) {
+    unsigned int host[kRefineStats] = {};
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->refine_stats.p, sizeof(host), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; ++k) out[k] = host[24 + k];
+    return REPET_OK;
+}
+#endif
 
 int repet_ctx_last_refine_stats(repet_ctx* c, int64_t out[4]) {
     if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");

@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -94,6 +95,20 @@ void narrow_part(const T* src, float* dst, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) dst[i] = (float)src[i];
 }
 
+// float64 -> the fp32 sample and the fp32 remainder (hi + lo carries 48 bits of the double); true when a remainder is not zero
+bool split_part(const double* src, float* dst_hi, float* dst_lo, size_t lo, size_t hi) {
+    bool any = false;
+    for (size_t i = lo; i < hi; ++i) {
+        const double x = src[i];
+        const float h = (float)x;
+        const float l = (float)(x - (double)h);
+        dst_hi[i] = h;
+        dst_lo[i] = l;
+        any = any || (l != 0.0f);       // (a NaN or infinite sample gives a NaN remainder: kept, it is what hi + lo must say)
+    }
+    return any;
+}
+
 }  // namespace
 
 // ---- staging ring ------------------------------------------------------------------------------------------------
@@ -105,6 +120,14 @@ void StagingRing::release() {
         busy[k] = false;
     }
     if (base) { (void)hipHostFree(base); base = nullptr; }
+    if (base_lo) { (void)hipHostFree(base_lo); base_lo = nullptr; }
+}
+
+hipError_t StagingRing::ensure_lo() {
+    if (base_lo) return hipSuccess;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&base_lo), (size_t)kSlots * kSlotElems * sizeof(float), hipHostMallocDefault);
+    if (e != hipSuccess) base_lo = nullptr;
+    return e;
 }
 
 hipError_t StagingRing::ensure() {
@@ -113,16 +136,23 @@ hipError_t StagingRing::ensure() {
     if (e != hipSuccess) { base = nullptr; return e; }
     for (int k = 0; k < kSlots; ++k) {
         e = hipEventCreateWithFlags(&event[k], hipEventDisableTiming);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) { release(); return e; }      // (a half-built ring must not pass the next ensure())
     }
     return hipSuccess;
 }
 
 // src (host, `dtype` elements) -> dst (device fp32), `count` elements; returns once the caller's memory has been read
 // (the last DMAs out of the ring may still be in flight on `s`).
-hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s) {
+// dst_lo (nullable, float64 sources only): the fp32 remainders src - (double)(float)src go there, chunk by chunk -- a chunk
+// whose remainders are all zero (samples that came from PCM or fp32 data) is cleared on the device instead of travelling;
+// *any_lo says whether any chunk travelled.
+hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s,
+                         float* dst_lo, bool* any_lo) {
     hipError_t e = ring.ensure();
     if (e != hipSuccess) return e;
+    const bool split = dst_lo && dtype == 1;
+    if (any_lo) *any_lo = false;
+    if (split) { e = ring.ensure_lo(); if (e != hipSuccess) return e; }
     HostWorkers& pool = HostWorkers::get();
     const size_t n_chunks = (count + StagingRing::kSlotElems - 1) / StagingRing::kSlotElems;
     for (size_t c = 0; c < n_chunks; ++c) {
@@ -130,14 +160,22 @@ hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* d
         if (ring.busy[slot]) { e = hipEventSynchronize(ring.event[slot]); if (e != hipSuccess) return e; }
         const size_t lo = c * StagingRing::kSlotElems, cnt = std::min(StagingRing::kSlotElems, count - lo);
         float* stage = ring.base + (size_t)slot * StagingRing::kSlotElems;
+        float* stage_lo = split ? ring.base_lo + (size_t)slot * StagingRing::kSlotElems : nullptr;
+        std::atomic<bool> chunk_lo{false};
         pool.run([&](int part, int parts) {
             const size_t a = cnt * part / parts, b = cnt * (part + 1) / parts;
-            if (dtype == 1) narrow_part(static_cast<const double*>(src) + lo, stage, a, b);
+            if (split) { if (split_part(static_cast<const double*>(src) + lo, stage, stage_lo, a, b)) chunk_lo.store(true, std::memory_order_relaxed); }
+            else if (dtype == 1) narrow_part(static_cast<const double*>(src) + lo, stage, a, b);
             else if (dtype == 2) narrow_part(static_cast<const int16_t*>(src) + lo, stage, a, b);
             else std::memcpy(stage + a, static_cast<const float*>(src) + lo + a, (b - a) * sizeof(float));
         }, cnt);
         e = hipMemcpyAsync(dst + lo, stage, cnt * sizeof(float), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return e;
+        if (split) {
+            if (chunk_lo.load()) { e = hipMemcpyAsync(dst_lo + lo, stage_lo, cnt * sizeof(float), hipMemcpyHostToDevice, s); if (any_lo) *any_lo = true; }
+            else e = hipMemsetAsync(dst_lo + lo, 0, cnt * sizeof(float), s);
+            if (e != hipSuccess) return e;
+        }
         e = hipEventRecord(ring.event[slot], s);
         if (e != hipSuccess) return e;
         ring.busy[slot] = true;

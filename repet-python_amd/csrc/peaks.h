@@ -14,7 +14,39 @@ struct PeakArgs {
     // and leave their candidates in cand_*[(row * n_seg + seg) * cand_cap ...]; STAGE 2 ranks a row's candidates
     int seg_len, n_seg, cand_cap;
     float* cand_val; int* cand_idx; int* cand_cnt;
+    // Second level: rows with a float64 verdict on the fp32 spectra closer than delta2, and flat rows, are decided again from
+    // float64 spectra. General path (peaks_exact.hip): (row, clip) pairs appended to redo_list (count in stats[4];
+    // redo_flag[clip * flag_stride + row] == gen marks a listed row). Fast path of the wavefront kernel (peaks_wave.hip):
+    // the row's lists go into records[slot * record_bytes ..], (row, clip) into lite_list (count in stats[12], lite_flag as
+    // above), the frames whose float64 unit rows will be needed into frame_list as clip * frame_clip_stride + frame
+    // (count in stats[10], frame_flag[...] == gen marks a queued frame). redo_list == nullptr: no second level.
+    double delta2; int* redo_list; unsigned int* redo_flag; unsigned int gen; int64_t flag_stride;
+    unsigned char* records; int record_bytes; int* lite_list; unsigned int* lite_flag;
+    int* frame_list; unsigned int* frame_flag; int64_t frame_clip_stride;
 };
+
+__device__ __forceinline__ void flag_row_for_exact(const PeakArgs& a, int64_t r, int clip) {
+    if (!a.redo_list) return;
+    if (atomicExch(a.redo_flag + (int64_t)clip * a.flag_stride + r, a.gen) != a.gen) {
+        const unsigned int s = atomicAdd(&a.stats[4], 1u);
+        a.redo_list[2 * s] = (int)r;
+        a.redo_list[2 * s + 1] = clip;
+    }
+}
+// a record slot for the row (fast path); -1: the row has one already, -2: no fast path in this launch
+__device__ __forceinline__ int claim_lite_slot(const PeakArgs& a, int64_t r, int clip) {
+    if (!a.lite_list) return -2;
+    if (atomicExch(a.lite_flag + (int64_t)clip * a.flag_stride + r, a.gen) == a.gen) return -1;
+    const unsigned int s = atomicAdd(&a.stats[12], 1u);
+    a.lite_list[2 * s] = (int)r;
+    a.lite_list[2 * s + 1] = clip;
+    return (int)s;
+}
+__device__ __forceinline__ void enqueue_frame_for_exact(const PeakArgs& a, int clip, int64_t frame) {
+    if (!a.frame_list) return;
+    const int64_t lin = (int64_t)clip * a.frame_clip_stride + frame;
+    if (atomicExch(a.frame_flag + lin, a.gen) != a.gen) a.frame_list[atomicAdd(&a.stats[10], 1u)] = (int)lin;
+}
 
 constexpr int kAmbCap = 96;    // near-tied elements refined per row; a row with more keeps its fp32 decisions
 constexpr int kRivalCap = 96;  // (near-tied element, rival) pairs per row, same fallback
@@ -167,6 +199,22 @@ __device__ __forceinline__ void exact_similarity_list(const float* __restrict__ 
     }
 }
 
+// float64 dot product of two float64 unit rows (one wave, result in every lane; len a multiple of 2)
+__device__ __forceinline__ double dot_rows_f64(const double* __restrict__ x, const double* __restrict__ y, int len, int lane) {
+    double acc = 0.0;
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    const int len2 = len >> 1;
+    for (int k0 = 0; k0 < len2; k0 += 512) {                                       // sixteen loads in flight per lane
+        double2 p[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = min(k0 + 64 * u + lane, len2 - 1); p[u] = x2[k]; q[u] = y2[k]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double live = (k0 + 64 * u + lane < len2) ? 1.0 : 0.0; acc += live * (p[u].x * q[u].x + p[u].y * q[u].y); }
+    }
+    return wave_sum_f64(acc);
+}
+
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
@@ -174,5 +222,7 @@ __device__ __forceinline__ float nan_to_inf(float v) { return (v != v) ? INFINIT
 
 // the wavefront-per-row kernel (peaks_wave.hip); hipErrorNotSupported when the shape is outside its range
 hipError_t launch_local_maxima_wave(const PeakArgs& a, int64_t n_rows, int n_batch, hipStream_t s);
+// does launch_local_maxima_wave take this shape (then the fast second level applies), and its record size
+bool local_maxima_wave_supported(int n_cols, int d, int* record_bytes);
 
 }  // namespace repet

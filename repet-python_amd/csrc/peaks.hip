@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     float4* M4 = reinterpret_cast<float4*>(smem);              // groups float4 (row, then window maxima)
     float* pval = smem + 4 * a.groups;                         // peak_cap (multiple of 4)
     int* pidx = reinterpret_cast<int*>(pval + a.peak_cap);     // peak_cap
-    __shared__ int n_peak, n_amb, n_riv, n_unl;
+    __shared__ int n_peak, n_amb, n_riv, n_unl, n_close;
     __shared__ float cutv[2];
     __shared__ double amb_exact[kAmbCap], riv_exact[kRivalCap];
+    __shared__ unsigned long long amb_best[kAmbCap];       // best rival of a near-tied element (bit pattern of a double >= 0)
     __shared__ int amb_idx[kAmbCap], riv_idx[kRivalCap];
     __shared__ float amb_val[kAmbCap];
     __shared__ short riv_owner[kRivalCap], riv_ref[kRivalCap], unl_list[kRivalCap];
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     if (a.unit) a.unit += blockIdx.y * a.unit_stride;
     const int64_t r = blockIdx.x;           // row within this launch
     const int64_t j = a.row0 + r;           // absolute row (mode 1: current frame)
-    if (tid == 0) { n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0; }
+    if (tid == 0) { n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0; n_close = 0; }
     float dlt = a.delta;                    // 0: no refinement
     const int seg = (STAGE == 1) ? (int)blockIdx.z : 0;
     const int seg_lo = (STAGE == 1) ? seg * a.seg_len : 0;                                  // elements tested here:
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
         __syncthreads();
         if (tid == 0) {
             n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0;
-            if (a.stats) atomicAdd(&a.stats[3], 1u);
+            if (a.stats) { atomicAdd(&a.stats[3], 1u); flag_row_for_exact(a, r, blockIdx.y); }    // (the second level decides the row again)
         }
         dlt = 0.0f;
         __syncthreads();
@@ -316,15 +317,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
         }
         __syncthreads();
         // phase 2: every rival pair, then the verdicts
+        for (int k = tid; k < n_near; k += 256) amb_best[k] = 0ull;
+        __syncthreads();
         for (int e = tid; e < n_rival; e += 256) {
             const int s = riv_owner[e], ref = riv_ref[e];
             const double er = ref >= 0 ? amb_exact[ref] : riv_exact[e];
             if (!(amb_exact[s] > er)) amb_lose[s] = 1;
+            atomicMax(&amb_best[s], (unsigned long long)__double_as_longlong(er));
         }
         __syncthreads();
         int changed = 0;
         for (int k = tid; k < n_near; k += 256) {
             const double ek = amb_exact[k];
+            // a verdict the fp32 spectra cannot settle (peaks_exact.hip): the element against its best rival, or against
+            // the threshold, closer than delta2
+            if (fabs(ek - __longlong_as_double((long long)amb_best[k])) < a.delta2 || fabs(ek - a.min_value64) < a.delta2) n_close = 1;
             const bool win = !amb_lose[k] && ek >= a.min_value64;
             if (win) {
                 const int slot = atomicAdd(&n_peak, 1);
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
             a.cand_val[slot * a.cand_cap + k] = pval[k];
             a.cand_idx[slot * a.cand_cap + k] = pidx[k];
         }
-        if (tid == 0) a.cand_cnt[slot] = cnt;
+        if (tid == 0) { a.cand_cnt[slot] = cnt; if (n_close) flag_row_for_exact(a, r, blockIdx.y); }
         return;
     }
     if constexpr (STAGE == 2) {
@@ -444,6 +451,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
                     int crank = 0;
                     for (int t = 0; t < n_band; ++t) crank += (amb_exact[t] > e) || (amb_exact[t] == e && amb_idx[t] > i);
                     const bool keep = n_above + crank < a.number;
+                    // the cut separates the lowest value kept from the highest one dropped: closer than delta2, the fp32
+                    // spectra cannot say on which side they belong (peaks_exact.hip). Kept k against every dropped t:
+                    if (keep)
+                        for (int t = 0; t < n_band; ++t)
+                            if (e - amb_exact[t] < a.delta2 && ((amb_exact[t] < e) || (amb_exact[t] == e && amb_idx[t] < i))) {
+                                int rank_t = 0;
+                                for (int u = 0; u < n_band; ++u) rank_t += (amb_exact[u] > amb_exact[t]) || (amb_exact[u] == amb_exact[t] && amb_idx[u] > amb_idx[t]);
+                                if (n_above + rank_t >= a.number) n_close = 1;
+                            }
                     if (keep) out[n_above + crank] = out_index(i);
                     changed += (keep != (amb_ok[k] != 0));
                 }
@@ -451,9 +467,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
                     if (tid == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
                     if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
                 }
-            } else if (a.stats && tid == 0) atomicAdd(&a.stats[3], 1u);
+            } else if (a.stats && tid == 0) { atomicAdd(&a.stats[3], 1u); n_close = 1; }
         }
     }
+    __syncthreads();
+    if (tid == 0 && n_close) flag_row_for_exact(a, r, blockIdx.y);
     STAMP(4)
     for (int k = kept + tid; k < a.number; k += 256) out[k] = -1;
     if (tid == 0) a.count[r] = kept;
@@ -500,11 +518,13 @@ size_t local_maxima_scratch_bytes(int64_t n_rows, int32_t n_cols, int32_t d) {
     return (size_t)(n_rows * n_seg * cap * 8 + n_rows * n_seg * 4 + 256);
 }
 
+hipError_t launch_local_maxima_lite(const PeakArgs& a, const ExactSource& src, hipStream_t s);      // peaks_wave.hip
+
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift, const PeakRefine* refine,
-                               const PeakBatch* batch, void* scratch) {
-    if (n_rows <= 0) return hipSuccess;
+                               const PeakBatch* batch, void* scratch, const ExactSource* lite_src) {
+    if (n_rows <= 0 && !lite_src) return hipSuccess;
     if (d > n_cols) d = n_cols;                                       // a wider window changes nothing
     PeakArgs a{};
     a.M = M; a.row0 = row0; a.n = n_cols; a.pitch = pitch; a.mode = mode; a.min_value = min_value; a.d = d;
@@ -513,6 +533,13 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
     if (refine && refine->unit_rows && refine->delta > 0.0f && (refine->pitch & 3) == 0) {
         a.unit = refine->unit_rows; a.unit_pitch = refine->pitch; a.delta = refine->delta;
         a.min_value64 = refine->min_value; a.stats = refine->stats;
+        if (refine->redo_list && refine->stats) {
+            a.delta2 = refine->delta2; a.redo_list = refine->redo_list; a.redo_flag = refine->redo_flag; a.gen = refine->gen;
+            a.flag_stride = refine->flag_stride;
+            a.records = refine->records; a.record_bytes = refine->record_bytes; a.lite_list = refine->lite_list;
+            a.lite_flag = refine->lite_flag; a.frame_list = refine->frame_list; a.frame_flag = refine->frame_flag;
+            a.frame_clip_stride = refine->frame_clip_stride;
+        }
     }
     int n_batch = 1;
     if (batch && batch->n_batch > 0) {
@@ -520,6 +547,7 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
         a.m_stride = batch->m_stride; a.idx_stride = batch->idx_stride; a.cnt_stride = batch->cnt_stride;
         a.unit_stride = batch->unit_stride;
     }
+    if (lite_src) return launch_local_maxima_lite(a, *lite_src, s);      // (the rows the first pass left records of)
     {   // one wavefront per row where the shape allows it (peaks_wave.hip); this kernel is the general fallback
         const hipError_t ew = launch_local_maxima_wave(a, n_rows, n_batch, s);
         if (ew != hipErrorNotSupported) return ew;

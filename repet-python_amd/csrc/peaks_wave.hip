@@ -121,6 +121,361 @@ __device__ __forceinline__ void wave_sync() {
 
 }  // namespace
 
+// The band of candidates around the top-`number` cut, ranked by the float64 values in L.amb_exact (higher index first on
+// ties): members that stay are written to the list. Returns false when the cut itself -- the lowest value kept against
+// the highest one dropped -- is closer than delta2; L.amb_lose then marks the members that may belong on the other side.
+template <bool LEVEL2, class OutIndex>
+__device__ __forceinline__ bool rank_cut_band(const PeakArgs& a, const WaveLds& L, int lane, int n_band, int n_above, int* out,
+                                              OutIndex out_index, bool count_stats) {
+    int changed = 0;
+    double low_kept = INFINITY, high_dropped = -INFINITY;
+    for (int k = lane; k < n_band; k += 64) {
+        const double e = L.amb_exact[k];
+        const int i = L.amb_idx[k];
+        int crank = 0;
+        for (int t = 0; t < n_band; ++t) crank += (L.amb_exact[t] > e) || (L.amb_exact[t] == e && L.amb_idx[t] > i);
+        const bool keep = n_above + crank < a.number;
+        if (keep) out[n_above + crank] = out_index(i);
+        if (keep) low_kept = fmin(low_kept, e); else high_dropped = fmax(high_dropped, e);
+        changed += (keep != (L.amb_ok[k] != 0));
+        L.amb_lose[k] = keep ? 1 : 0;                          // (kept, for the marking below)
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        low_kept = fmin(low_kept, __shfl_xor(low_kept, sh));
+        high_dropped = fmax(high_dropped, __shfl_xor(high_dropped, sh));
+    }
+    if (count_stats) {
+        if (lane == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
+        if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+    }
+    const bool settled = !(low_kept - high_dropped < a.delta2) || !(a.redo_list || LEVEL2);
+    wave_sync();
+    if (!settled)
+        for (int k = lane; k < n_band; k += 64) {
+            const double e = L.amb_exact[k];
+            const bool kept_now = L.amb_lose[k] != 0;
+            L.amb_lose[k] = ((kept_now && e < high_dropped + a.delta2) || (!kept_now && e > low_kept - a.delta2)) ? 1 : 0;
+        }
+    wave_sync();
+    return settled;
+}
+
+// (lite kernel) the marked members of the band get their level-2 values, then the band is ranked again
+template <class OutIndex, class ElemFrame, class Level2>
+__device__ __forceinline__ void finish_band_level2(const PeakArgs& a, const WaveLds& L, int lane, int n_band, int n_above, int* out,
+                                                   OutIndex out_index, ElemFrame elem_frame, Level2 level2, bool* missing) {
+    double worst = 0.0;
+    int n2 = 0;
+    for (int k = 0; k < n_band; ++k) {
+        if (!L.amb_lose[k]) continue;
+        const double e2 = level2(elem_frame(L.amb_idx[k]));
+        worst = fmax(worst, fabs(e2 - L.amb_exact[k]));
+        ++n2;
+        wave_sync();
+        if (lane == 0) L.amb_exact[k] = e2;
+    }
+    wave_sync();
+    if (*missing) return;
+    if (lane == 0 && a.stats) {
+        atomicAdd(&a.stats[6], (unsigned)n2);
+        if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
+    }
+    for (int k = lane; k < n_band; k += 64) {
+        const double e = L.amb_exact[k];
+        const int i = L.amb_idx[k];
+        int crank = 0;
+        for (int t = 0; t < n_band; ++t) crank += (L.amb_exact[t] > e) || (L.amb_exact[t] == e && L.amb_idx[t] > i);
+        if (n_above + crank < a.number) out[n_above + crank] = out_index(i);
+    }
+}
+
+// ---- second level, fast path (the general path is peaks_exact.hip) --------------------------------------
+// A row whose float64 verdicts on the fp32 spectra (level 1) are closer than delta2 leaves a RECORD of the wave's lists
+// where the close verdict was met, and the frames behind the elements involved go on a queue; a lean kernel computes their
+// float64 unit rows (launch_unit_rows_f64, peaks_exact.hip), and local_maxima_lite_kernel takes the row up again from the
+// record with those values (level 2) -- nothing of the row is scanned twice.
+//   type 1: met in the near-tie verdicts: the lists as they are after the level-1 values (candidates safe in fp32, near-tied
+//           elements, their rivals, all level-1 values); the lite kernel re-takes verdicts, ranking and cut;
+//   type 2: met only at the top-`number` cut: the ranked candidates and the band's level-1 values; the lite kernel
+//           re-ranks the band.
+struct LiteHeader { int type, n_peak, n_near, n_rival, n_unl, n_band, n_above, np; };
+__host__ __device__ inline size_t lite_record_bytes(int cap) {
+    return 32 + (size_t)kAmbCap * (4 + 8) + (size_t)kRivalCap * (2 + 2 + 2 + 2 + 4 + 8) + (size_t)cap * 12;
+}
+struct LiteRecord {
+    LiteHeader* h; int* amb_idx; double* amb_exact; short* riv_owner; short* riv_ref; short* unl_list; int* riv_idx;
+    double* riv_exact; float* pval; int* pidx; int* prank;
+};
+__device__ __forceinline__ LiteRecord carve_record(unsigned char* p, int cap) {
+    LiteRecord q;
+    q.h = reinterpret_cast<LiteHeader*>(p); p += 32;
+    q.amb_exact = reinterpret_cast<double*>(p); p += kAmbCap * 8;
+    q.riv_exact = reinterpret_cast<double*>(p); p += kRivalCap * 8;
+    q.amb_idx = reinterpret_cast<int*>(p); p += kAmbCap * 4;
+    q.riv_idx = reinterpret_cast<int*>(p); p += kRivalCap * 4;
+    q.riv_owner = reinterpret_cast<short*>(p); p += kRivalCap * 2;
+    q.riv_ref = reinterpret_cast<short*>(p); p += kRivalCap * 2;
+    q.unl_list = reinterpret_cast<short*>(p); p += kRivalCap * 4;          // (+ padding to a 4-byte boundary)
+    q.pval = reinterpret_cast<float*>(p); p += (size_t)cap * 4;
+    q.pidx = reinterpret_cast<int*>(p); p += (size_t)cap * 4;
+    q.prank = reinterpret_cast<int*>(p);
+    return q;
+}
+// where the lite kernel finds the float64 unit rows (written by launch_unit_rows_f64 earlier on the stream)
+struct LiteSource { const double* u64; const unsigned int* u64_gen; int64_t u64_clip_stride, gen_clip_stride; int FS; unsigned int gen; };
+
+// Everything of a row after the sweep: near-tie verdicts, ranking, top-`number` cut, the list. LEVEL2 = false: the first
+// pass (records and queue entries are written where a verdict is closer than delta2). LEVEL2 = true: the lite kernel, whose
+// lists and level-1 values come from a type-1 record (`rec`) and whose close verdicts are re-taken from float64 spectra.
+template <bool LEVEL2>
+__device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds& L, int lane, int64_t r, int64_t j, int clip, float dlt,
+                                                int n_peak, int n_amb, int n_riv, int n_unl, const LiteSource* ls, bool* missing) {
+    const int n = a.n;
+    auto elem_frame = [&](int i) -> int64_t {                 // unit row of the frame behind element i
+        if (a.mode == 0) return i;
+        int l = (int)(j - i) % n;
+        if (l < 0) l += n;
+        return j - l - a.shift;
+    };
+    auto elem_row = [&](int i) -> const float* { return a.unit + elem_frame(i) * (int64_t)a.unit_pitch; };
+    auto out_index = [&](int i) -> int { return a.mode == 0 ? i : (int)elem_frame(i); };
+    const int64_t self_frame = j - a.shift;
+    // level-2 value of the row against frame fr (LEVEL2 only); *missing when the float64 row is not there
+    auto level2 = [&](int64_t fr) -> double {
+        if constexpr (LEVEL2) {
+            const unsigned int* g = ls->u64_gen + (int64_t)clip * ls->gen_clip_stride;
+            if (__hip_atomic_load(&g[fr], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls->gen ||
+                __hip_atomic_load(&g[self_frame], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls->gen) { *missing = true; return 0.0; }
+            const double* base = ls->u64 + (int64_t)clip * ls->u64_clip_stride;
+            return dot_rows_f64(base + self_frame * (int64_t)ls->FS, base + fr * (int64_t)ls->FS, ls->FS, lane);
+        }
+        return 0.0;
+    };
+    bool listed = false;                                      // (first pass) this row has a record already
+
+    if (dlt > 0.0f && n_amb > 0) {
+        // Near-tie refinement (see peaks.hip): float64 similarities of the same fp32 spectra decide.
+        const int n_near = n_amb, n_rival = n_riv, n_items = n_near + n_unl;
+        if constexpr (!LEVEL2) {
+            const int len4 = a.unit_pitch >> 2;
+            const float* self_row = a.unit + self_frame * (int64_t)a.unit_pitch;
+            auto item_row = [&](int it) -> const float* {
+                return elem_row(it < n_near ? L.amb_idx[it] : L.riv_idx[L.unl_list[it - n_near]]);
+            };
+            exact_similarity_list(self_row, len4, lane, n_items, item_row, [&](int it, double e) {
+                if (lane == 0) {
+                    if (it < n_near) L.amb_exact[it] = e; else L.riv_exact[L.unl_list[it - n_near]] = e;
+                }
+            });
+            wave_sync();
+        }
+        // best[s]: the largest rival value of near-tied element s (similarities of magnitude spectra are >= 0: their bit
+        // patterns order like unsigned integers; a NaN rival's pattern is above every number, and NaN - x is never "close")
+        unsigned long long* best = reinterpret_cast<unsigned long long*>(L.buf);      // the window maxima are no longer needed
+        unsigned char* amb_n2 = reinterpret_cast<unsigned char*>(L.buf) + kAmbCap * 8;   // elements / rivals that need level 2
+        unsigned char* riv_n2 = amb_n2 + kAmbCap;
+        auto verdicts = [&]() {                                // amb_lose and best from the current values
+            for (int k = lane; k < n_near; k += 64) { best[k] = 0ull; L.amb_lose[k] = 0; }
+            wave_sync();
+            for (int e = lane; e < n_rival; e += 64) {
+                const int s = L.riv_owner[e], ref = L.riv_ref[e];
+                const double er = ref >= 0 ? L.amb_exact[ref] : L.riv_exact[e];
+                if (!(L.amb_exact[s] > er)) L.amb_lose[s] = 1;
+                atomicMax(&best[s], (unsigned long long)__double_as_longlong(er));
+            }
+            wave_sync();
+        };
+        verdicts();
+        // A verdict the fp32 spectra cannot settle: the element against its best rival, or against the threshold, closer
+        // than delta2. It is re-taken from float64 spectra of the element and of every rival that may be the best one.
+        bool close = false;
+        if (a.redo_list || LEVEL2) {
+            for (int k = lane; k < n_near; k += 64) {
+                const double ek = L.amb_exact[k];
+                const bool versus_rival = fabs(ek - __longlong_as_double((long long)best[k])) < a.delta2;
+                amb_n2[k] = (versus_rival || fabs(ek - a.min_value64) < a.delta2) ? (versus_rival ? 3 : 1) : 0;
+                close = close || amb_n2[k] != 0;
+            }
+            close = __any(close);
+        }
+        if (close) {
+            wave_sync();
+            for (int e = lane; e < n_rival; e += 64) {
+                const int s = L.riv_owner[e], ref = L.riv_ref[e];
+                const double er = ref >= 0 ? L.amb_exact[ref] : L.riv_exact[e];
+                const bool need = (amb_n2[s] & 2) && er > __longlong_as_double((long long)best[s]) - a.delta2;
+                riv_n2[e] = (need && ref < 0) ? 1 : 0;
+                if (need && ref >= 0 && !amb_n2[ref]) amb_n2[ref] = 1;      // (racing writers all store 1)
+            }
+            wave_sync();
+            if constexpr (!LEVEL2) {
+                // the frames go on the queue, the lists into the row's record
+                if (lane == 0) enqueue_frame_for_exact(a, clip, self_frame);
+                for (int k = lane; k < n_near; k += 64) if (amb_n2[k]) enqueue_frame_for_exact(a, clip, elem_frame(L.amb_idx[k]));
+                for (int e = lane; e < n_rival; e += 64) if (riv_n2[e]) enqueue_frame_for_exact(a, clip, elem_frame(L.riv_idx[e]));
+                int slot = -1;
+                if (lane == 0) { slot = claim_lite_slot(a, r, clip); if (slot == -2) flag_row_for_exact(a, r, clip); }
+                slot = __shfl(slot, 0);
+                if (slot >= 0) {
+                    listed = true;
+                    const LiteRecord q = carve_record(a.records + (size_t)slot * a.record_bytes, a.peak_cap);
+                    if (lane == 0) *q.h = LiteHeader{1, n_peak, n_near, n_rival, n_unl, 0, 0, 0};
+                    for (int k = lane; k < n_near; k += 64) { q.amb_idx[k] = L.amb_idx[k]; q.amb_exact[k] = L.amb_exact[k]; }
+                    for (int e = lane; e < n_rival; e += 64) {
+                        q.riv_owner[e] = L.riv_owner[e]; q.riv_ref[e] = L.riv_ref[e]; q.riv_idx[e] = L.riv_idx[e]; q.riv_exact[e] = L.riv_exact[e];
+                    }
+                    const int np0 = n_peak < a.peak_cap ? n_peak : a.peak_cap;
+                    for (int p = lane; p < np0; p += 64) { q.pval[p] = L.pval[p]; q.pidx[p] = L.pidx[p]; }
+                }
+            } else {
+                // level-2 values in place of the level-1 ones, then the verdicts again
+                double worst = 0.0;
+                int n2 = 0;
+                for (int k = 0; k < n_near; ++k) {
+                    if (!amb_n2[k]) continue;
+                    const double e2 = level2(elem_frame(L.amb_idx[k]));
+                    worst = fmax(worst, fabs(e2 - L.amb_exact[k]));
+                    ++n2;
+                    wave_sync();
+                    if (lane == 0) L.amb_exact[k] = e2;
+                }
+                for (int e = 0; e < n_rival; ++e) {
+                    if (!riv_n2[e]) continue;
+                    const double e2 = level2(elem_frame(L.riv_idx[e]));
+                    worst = fmax(worst, fabs(e2 - L.riv_exact[e]));
+                    ++n2;
+                    wave_sync();
+                    if (lane == 0) L.riv_exact[e] = e2;
+                }
+                wave_sync();
+                if (*missing) return;
+                if (lane == 0 && a.stats) {
+                    atomicAdd(&a.stats[6], (unsigned)n2);
+                    if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
+                }
+                verdicts();
+            }
+        }
+        int changed = 0;
+        for (int k0 = 0; k0 < n_near; k0 += 64) {
+            const int k = k0 + lane;
+            bool win = false;
+            if (k < n_near) {
+                const double ek = L.amb_exact[k];
+                win = !L.amb_lose[k] && ek >= a.min_value64;
+                if constexpr (!LEVEL2) changed += (win != (L.amb_ok[k] != 0));
+            }
+            int next;
+            const int slot = ballot_slot(win, n_peak, lane, &next);
+            if (win && slot < a.peak_cap) { L.pval[slot] = (float)L.amb_exact[k]; L.pidx[slot] = L.amb_idx[k]; }
+            n_peak = next;
+        }
+        if (a.stats && !LEVEL2) {
+            if (lane == 0) { atomicAdd(&a.stats[0], 1u); atomicAdd(&a.stats[1], (unsigned)n_near); }
+            if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+        }
+        wave_sync();
+    }
+
+    // rank by counting: value descending, higher index first on ties (np.argsort(...)[::-1])
+    int np_ = n_peak;
+    if (np_ > a.peak_cap) np_ = a.peak_cap;
+    const int kept = np_ < a.number ? np_ : a.number;
+    for (int k = np_ + lane; k < ((np_ + 3) & ~3); k += 64) L.pval[k] = -INFINITY;       // pad to a float4 boundary
+    wave_sync();
+    int* out = a.idx + r * (int64_t)a.idx_pitch;
+    const float4* pv4 = reinterpret_cast<const float4*>(L.pval);
+    const bool cut_check = dlt > 0.0f && np_ > a.number;
+    int* prank = reinterpret_cast<int*>(L.buf);               // the window maxima are no longer needed (cap <= 640 ints fit)
+    // Two candidates per lane and pass over the list; equal VALUES are only counted here -- every candidate meets itself
+    // in the list, so a tie branch inside the loop was taken by some lane in nearly every iteration (26 000 of a row's
+    // 125 000 cycles). A candidate with a real tie (count > 1: rare) settles it by index afterwards.
+    for (int pb = 0; pb < np_; pb += 128) {
+        const int pa = pb + lane, pc = pb + 64 + lane;
+        const bool has_a = pa < np_, has_c = pc < np_;
+        const float va = has_a ? L.pval[pa] : INFINITY, vc = has_c ? L.pval[pc] : INFINITY;
+        int gt_a = 0, eq_a = 0, gt_c = 0, eq_c = 0;
+#pragma unroll 4
+        for (int q4 = 0; 4 * q4 < np_; ++q4) {
+            const float4 u = pv4[q4];
+            gt_a += (u.x > va) + (u.y > va) + (u.z > va) + (u.w > va);
+            eq_a += (u.x == va) + (u.y == va) + (u.z == va) + (u.w == va);
+            gt_c += (u.x > vc) + (u.y > vc) + (u.z > vc) + (u.w > vc);
+            eq_c += (u.x == vc) + (u.y == vc) + (u.z == vc) + (u.w == vc);
+        }
+        auto settle = [&](bool has, int p, float v, int gt, int eq) {
+            if (!has) return;
+            const int i = L.pidx[p];
+            int rank = gt;
+            if (eq > 1)                                       // higher index first on ties
+                for (int q = 0; q < np_; ++q) rank += (L.pval[q] == v && L.pidx[q] > i);
+            if (rank < a.number) out[rank] = out_index(i);
+            if (cut_check) prank[p] = rank;
+        };
+        settle(has_a, pa, va, gt_a, eq_a);
+        settle(has_c, pc, vc, gt_c, eq_c);
+    }
+    if (cut_check) {
+        // Top-`number` cut with more candidates than slots (see peaks.hip): candidates within delta of the boundary
+        // are re-ranked by float64 similarity.
+        wave_sync();
+        for (int p = lane; p < np_; p += 64) {
+            if (prank[p] == a.number - 1) L.cutv[0] = L.pval[p];
+            if (prank[p] == a.number) L.cutv[1] = L.pval[p];
+        }
+        wave_sync();
+        const float c_in = L.cutv[0], c_out = L.cutv[1];
+        if (c_in - c_out <= dlt) {
+            const float lo = c_out - dlt, hi = c_in + dlt;
+            int n_band = 0, n_above = 0;
+            for (int p0 = 0; p0 < np_; p0 += 64) {
+                const int p = p0 + lane;
+                const float v = p < np_ ? L.pval[p] : -INFINITY;
+                const bool above = p < np_ && v > hi, band = p < np_ && !above && v >= lo;
+                n_above += __popcll(__ballot(above));
+                int next;
+                const int slot = ballot_slot(band, n_band, lane, &next);
+                if (band && slot < kAmbCap) { L.amb_idx[slot] = L.pidx[p]; L.amb_ok[slot] = prank[p] < a.number; }
+                n_band = next;
+            }
+            wave_sync();
+            if (n_band <= kAmbCap) {
+                const int len4 = a.unit_pitch >> 2;
+                const float* self_row = a.unit + self_frame * (int64_t)a.unit_pitch;
+                exact_similarity_list(self_row, len4, lane, n_band, [&](int it) { return elem_row(L.amb_idx[it]); },
+                                      [&](int it, double e) { if (lane == 0) L.amb_exact[it] = e; });
+                wave_sync();
+                const bool settled = rank_cut_band<LEVEL2>(a, L, lane, n_band, n_above, out, out_index, a.stats && !LEVEL2);
+                if (!settled) {
+                    // the cut is closer than delta2: the members that may belong on the other side (amb_lose marks them)
+                    if constexpr (!LEVEL2) {
+                        if (lane == 0) enqueue_frame_for_exact(a, clip, self_frame);
+                        for (int k = lane; k < n_band; k += 64) if (L.amb_lose[k]) enqueue_frame_for_exact(a, clip, elem_frame(L.amb_idx[k]));
+                        if (!listed) {
+                            int slot = -1;
+                            if (lane == 0) { slot = claim_lite_slot(a, r, clip); if (slot == -2) flag_row_for_exact(a, r, clip); }
+                            slot = __shfl(slot, 0);
+                            if (slot >= 0) {
+                                const LiteRecord q = carve_record(a.records + (size_t)slot * a.record_bytes, a.peak_cap);
+                                if (lane == 0) *q.h = LiteHeader{2, 0, 0, 0, 0, n_band, n_above, np_};
+                                for (int k = lane; k < n_band; k += 64) { q.amb_idx[k] = L.amb_idx[k]; q.amb_exact[k] = L.amb_exact[k]; }
+                            }
+                        }
+                    } else {
+                        finish_band_level2(a, L, lane, n_band, n_above, out, out_index, elem_frame, level2, missing);
+                        if (*missing) return;
+                    }
+                }
+            } else if (lane == 0) {
+                if (a.stats && !LEVEL2) atomicAdd(&a.stats[3], 1u);
+                flag_row_for_exact(a, r, clip);                // a flat cut: the general second level
+            }
+        }
+    }
+    for (int k = kept + lane; k < a.number; k += 64) out[k] = -1;
+    if (lane == 0) a.count[r] = kept;
+}
+
 // RD = d & 3: the two window reads at run-time offsets (-d and d-w+1) then have compile-time float4 remainders
 template <int RD>
 // One wavefront per WORKGROUP: rows take 30 .. 140 us (the refinement of near-ties varies), and a workgroup's LDS and
@@ -147,22 +502,6 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
         const int64_t at = a.mode == 0 ? j * a.pitch + i : (j - l - a.shift) * a.pitch + l;
         return a.M[at];
     };
-    auto elem_row = [&](int i) -> const float* {             // unit row of the frame behind element i
-        int64_t fr = i;
-        if (a.mode == 1) {
-            int l = (int)(j - i) % n;
-            if (l < 0) l += n;
-            fr = j - l - a.shift;
-        }
-        return a.unit + fr * (int64_t)a.unit_pitch;
-    };
-    auto out_index = [&](int i) -> int {                     // what the list holds for element i
-        if (a.mode == 0) return i;
-        int l = (int)(j - i) % n;
-        if (l < 0) l += n;
-        return (int)(j - l - a.shift);
-    };
-
     const bool vec_ok = (a.mode == 0) && ((a.pitch & 3) == 0);
     const float* src = a.M + j * a.pitch;
     int w = 1;
@@ -432,143 +771,78 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
         }
         WSTAMP(6)                                             // rivals of the near-tied elements
         if (!redo) break;
-        if (a.stats && lane == 0) atomicAdd(&a.stats[3], 1u);      // redo the test with the plain fp32 decisions
-        dlt = 0.0f;
+        if (a.stats && lane == 0) { atomicAdd(&a.stats[3], 1u); flag_row_for_exact(a, r, blockIdx.y); }   // redo the test with the plain
+        dlt = 0.0f;                                                // fp32 decisions (the second level decides the row again)
     }
     wave_sync();
-
-    if (dlt > 0.0f && n_amb > 0) {
-        // Near-tie refinement (see peaks.hip): float64 similarities of the same fp32 spectra decide.
-        const int n_near = n_amb, n_rival = n_riv, n_items = n_near + n_unl;
-        const int len4 = a.unit_pitch >> 2;
-        const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
-        auto item_row = [&](int it) -> const float* {
-            return elem_row(it < n_near ? L.amb_idx[it] : L.riv_idx[L.unl_list[it - n_near]]);
-        };
-        exact_similarity_list(self_row, len4, lane, n_items, item_row, [&](int it, double e) {
-            if (lane == 0) {
-                if (it < n_near) L.amb_exact[it] = e; else L.riv_exact[L.unl_list[it - n_near]] = e;
-            }
-        });
-        wave_sync();
-        WSTAMP(7)                                             // float64 similarities
-        for (int e = lane; e < n_rival; e += 64) {
-            const int s = L.riv_owner[e], ref = L.riv_ref[e];
-            const double er = ref >= 0 ? L.amb_exact[ref] : L.riv_exact[e];
-            if (!(L.amb_exact[s] > er)) L.amb_lose[s] = 1;
-        }
-        wave_sync();
-        int changed = 0;
-        for (int k0 = 0; k0 < n_near; k0 += 64) {
-            const int k = k0 + lane;
-            bool win = false;
-            if (k < n_near) {
-                const double ek = L.amb_exact[k];
-                win = !L.amb_lose[k] && ek >= a.min_value64;
-                changed += (win != (L.amb_ok[k] != 0));
-            }
-            int next;
-            const int slot = ballot_slot(win, n_peak, lane, &next);
-            if (win && slot < a.peak_cap) { L.pval[slot] = (float)L.amb_exact[k]; L.pidx[slot] = L.amb_idx[k]; }
-            n_peak = next;
-        }
-        if (a.stats) {
-            if (lane == 0) { atomicAdd(&a.stats[0], 1u); atomicAdd(&a.stats[1], (unsigned)n_near); }
-            if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
-        }
-        wave_sync();
-    }
 
     WSTAMP(4)
-    // rank by counting: value descending, higher index first on ties (np.argsort(...)[::-1])
-    int np_ = n_peak;
-    if (np_ > a.peak_cap) np_ = a.peak_cap;
-    const int kept = np_ < a.number ? np_ : a.number;
-    for (int k = np_ + lane; k < ((np_ + 3) & ~3); k += 64) L.pval[k] = -INFINITY;       // pad to a float4 boundary
-    wave_sync();
-    int* out = a.idx + r * (int64_t)a.idx_pitch;
-    const float4* pv4 = reinterpret_cast<const float4*>(L.pval);
-    const bool cut_check = dlt > 0.0f && np_ > a.number;
-    int* prank = reinterpret_cast<int*>(L.buf);               // the window maxima are no longer needed (cap <= 640 ints fit)
-    // Two candidates per lane and pass over the list; equal VALUES are only counted here -- every candidate meets itself
-    // in the list, so a tie branch inside the loop was taken by some lane in nearly every iteration (26 000 of a row's
-    // 125 000 cycles). A candidate with a real tie (count > 1: rare) settles it by index afterwards.
-    for (int pb = 0; pb < np_; pb += 128) {
-        const int pa = pb + lane, pc = pb + 64 + lane;
-        const bool has_a = pa < np_, has_c = pc < np_;
-        const float va = has_a ? L.pval[pa] : INFINITY, vc = has_c ? L.pval[pc] : INFINITY;
-        int gt_a = 0, eq_a = 0, gt_c = 0, eq_c = 0;
-#pragma unroll 4
-        for (int q4 = 0; 4 * q4 < np_; ++q4) {
-            const float4 u = pv4[q4];
-            gt_a += (u.x > va) + (u.y > va) + (u.z > va) + (u.w > va);
-            eq_a += (u.x == va) + (u.y == va) + (u.z == va) + (u.w == va);
-            gt_c += (u.x > vc) + (u.y > vc) + (u.z > vc) + (u.w > vc);
-            eq_c += (u.x == vc) + (u.y == vc) + (u.z == vc) + (u.w == vc);
-        }
-        auto settle = [&](bool has, int p, float v, int gt, int eq) {
-            if (!has) return;
-            const int i = L.pidx[p];
-            int rank = gt;
-            if (eq > 1)                                       // higher index first on ties
-                for (int q = 0; q < np_; ++q) rank += (L.pval[q] == v && L.pidx[q] > i);
-            if (rank < a.number) out[rank] = out_index(i);
-            if (cut_check) prank[p] = rank;
-        };
-        settle(has_a, pa, va, gt_a, eq_a);
-        settle(has_c, pc, vc, gt_c, eq_c);
-    }
-    if (cut_check) {
-        // Top-`number` cut with more candidates than slots (see peaks.hip): candidates within delta of the boundary
-        // are re-ranked by float64 similarity.
-        wave_sync();
-        for (int p = lane; p < np_; p += 64) {
-            if (prank[p] == a.number - 1) L.cutv[0] = L.pval[p];
-            if (prank[p] == a.number) L.cutv[1] = L.pval[p];
-        }
-        wave_sync();
-        const float c_in = L.cutv[0], c_out = L.cutv[1];
-        if (c_in - c_out <= dlt) {
-            const float lo = c_out - dlt, hi = c_in + dlt;
-            int n_band = 0, n_above = 0;
-            for (int p0 = 0; p0 < np_; p0 += 64) {
-                const int p = p0 + lane;
-                const float v = p < np_ ? L.pval[p] : -INFINITY;
-                const bool above = p < np_ && v > hi, band = p < np_ && !above && v >= lo;
-                n_above += __popcll(__ballot(above));
-                int next;
-                const int slot = ballot_slot(band, n_band, lane, &next);
-                if (band && slot < kAmbCap) { L.amb_idx[slot] = L.pidx[p]; L.amb_ok[slot] = prank[p] < a.number; }
-                n_band = next;
-            }
-            wave_sync();
-            if (n_band <= kAmbCap) {
-                const int len4 = a.unit_pitch >> 2;
-                const float* self_row = a.unit + (j - a.shift) * (int64_t)a.unit_pitch;
-                exact_similarity_list(self_row, len4, lane, n_band, [&](int it) { return elem_row(L.amb_idx[it]); },
-                                      [&](int it, double e) { if (lane == 0) L.amb_exact[it] = e; });
-                wave_sync();
-                int changed = 0;
-                for (int k = lane; k < n_band; k += 64) {
-                    const double e = L.amb_exact[k];
-                    const int i = L.amb_idx[k];
-                    int crank = 0;
-                    for (int t = 0; t < n_band; ++t) crank += (L.amb_exact[t] > e) || (L.amb_exact[t] == e && L.amb_idx[t] > i);
-                    const bool keep = n_above + crank < a.number;
-                    if (keep) out[n_above + crank] = out_index(i);
-                    changed += (keep != (L.amb_ok[k] != 0));
-                }
-                if (a.stats) {
-                    if (lane == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
-                    if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
-                }
-            } else if (a.stats && lane == 0) atomicAdd(&a.stats[3], 1u);
-        }
-    }
-    for (int k = kept + lane; k < a.number; k += 64) out[k] = -1;
-    if (lane == 0) a.count[r] = kept;
+    wave_finish_row<false>(a, L, lane, r, j, (int)blockIdx.y, dlt, n_peak, n_amb, n_riv, n_unl, nullptr, nullptr);
     WSTAMP(5)
     WSTAMP_OUT
+}
+
+
+// The rows the first pass left records of (see wave_finish_row), one wavefront per row, taken from the list until it is
+// empty (fixed grid). A row whose float64 unit rows are not all there (its band changed with the level-2 verdicts) goes
+// to the general kernel (peaks_exact.hip), which runs next on the stream.
+__global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, LiteSource ls) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lite_smem[];
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve(lite_smem, a0.peak_cap);
+    const unsigned int n_rows = a0.stats[12];
+    for (;;) {
+        unsigned int slot = 0;
+        if (lane == 0) slot = atomicAdd(&a0.stats[13], 1u);
+        slot = __shfl(slot, 0);
+        if (slot >= n_rows) return;
+        PeakArgs a = a0;
+        const int64_t r = a.lite_list[2 * slot];
+        const int clip = a.lite_list[2 * slot + 1];
+        a.M += clip * a.m_stride;
+        a.idx += clip * a.idx_stride;
+        a.count += clip * a.cnt_stride;
+        a.unit += clip * a.unit_stride;
+        const int64_t j = a.row0 + r;
+        const LiteRecord q = carve_record(a.records + (size_t)slot * a.record_bytes, a.peak_cap);
+        const LiteHeader h = *q.h;
+        bool missing = false;
+        wave_sync();
+        if (h.type == 1) {
+            for (int k = lane; k < h.n_near; k += 64) { L.amb_idx[k] = q.amb_idx[k]; L.amb_exact[k] = q.amb_exact[k]; }
+            for (int e = lane; e < h.n_rival; e += 64) {
+                L.riv_owner[e] = q.riv_owner[e]; L.riv_ref[e] = q.riv_ref[e]; L.riv_idx[e] = q.riv_idx[e]; L.riv_exact[e] = q.riv_exact[e];
+            }
+            const int np0 = h.n_peak < a.peak_cap ? h.n_peak : a.peak_cap;
+            for (int p = lane; p < np0; p += 64) { L.pval[p] = q.pval[p]; L.pidx[p] = q.pidx[p]; }
+            wave_sync();
+            wave_finish_row<true>(a, L, lane, r, j, clip, a.delta, h.n_peak, h.n_near, h.n_rival, h.n_unl, &ls, &missing);
+        } else {
+            for (int k = lane; k < h.n_band; k += 64) { L.amb_idx[k] = q.amb_idx[k]; L.amb_exact[k] = q.amb_exact[k]; L.amb_ok[k] = 0; }
+            wave_sync();
+            const int n = a.n;
+            auto elem_frame = [&](int i) -> int64_t {
+                if (a.mode == 0) return i;
+                int l = (int)(j - i) % n;
+                if (l < 0) l += n;
+                return j - l - a.shift;
+            };
+            auto out_index = [&](int i) -> int { return a.mode == 0 ? i : (int)elem_frame(i); };
+            const int64_t self_frame = j - a.shift;
+            auto level2 = [&](int64_t fr) -> double {
+                const unsigned int* g = ls.u64_gen + (int64_t)clip * ls.gen_clip_stride;
+                if (__hip_atomic_load(&g[fr], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls.gen ||
+                    __hip_atomic_load(&g[self_frame], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls.gen) { missing = true; return 0.0; }
+                const double* base = ls.u64 + (int64_t)clip * ls.u64_clip_stride;
+                return dot_rows_f64(base + self_frame * (int64_t)ls.FS, base + fr * (int64_t)ls.FS, ls.FS, lane);
+            };
+            int* out = a.idx + r * (int64_t)a.idx_pitch;
+            if (!rank_cut_band<true>(a, L, lane, h.n_band, h.n_above, out, out_index, false))
+                finish_band_level2(a, L, lane, h.n_band, h.n_above, out, out_index, elem_frame, level2, &missing);
+        }
+        if (missing && lane == 0) { atomicAdd(&a.stats[14], 1u); flag_row_for_exact(a, r, clip); }
+        wave_sync();
+    }
 }
 
 #if defined(REPET_PEAK_STAMPS) || defined(REPET_PEAK_SPANS)
@@ -591,15 +865,33 @@ static hipError_t launch_wave_rd(const PeakArgs& a, int64_t n_rows, int n_batch,
     return hipGetLastError();
 }
 
-hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_batch, hipStream_t s) {
-    static const bool off = [] { const char* e = getenv("REPET_PEAKS"); return e && e[0] == 'b'; }();   // REPET_PEAKS=block: the workgroup kernel
-    if (off) return hipErrorNotSupported;
-    PeakArgs a = a0;
+static bool wave_shape(int n_cols, int d, int* cap_out) {
     // windows of 4 .. 32 elements per doubling chain (4 <= d <= 63), lists that fit the wave's LDS share
-    if (a.d < 4 || a.d > 63 || a.n < 1) return hipErrorNotSupported;
+    if (d < 4 || d > 63 || n_cols < 1) return false;
+    const int cap = (int)round_up(n_cols / (d + 1) + 2, 4);
+    if (cap > kMaxWaveCap) return false;
+    *cap_out = cap;
+    return true;
+}
+static bool wave_kernel_off() {
+    static const bool off = [] { const char* e = getenv("REPET_PEAKS"); return e && e[0] == 'b'; }();   // REPET_PEAKS=block: the workgroup kernel
+    return off;
+}
+
+bool local_maxima_wave_supported(int n_cols, int d, int* record_bytes) {
+    int cap = 0;
+    if (d > n_cols) d = n_cols;
+    if (wave_kernel_off() || !wave_shape(n_cols, d, &cap)) return false;
+    if (record_bytes) *record_bytes = (int)round_up((int64_t)lite_record_bytes(cap), 16);
+    return true;
+}
+
+hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_batch, hipStream_t s) {
+    if (wave_kernel_off()) return hipErrorNotSupported;
+    PeakArgs a = a0;
+    int cap = 0;
+    if (!wave_shape(a.n, a.d, &cap)) return hipErrorNotSupported;
     a.dl = (int)round_up(a.d, 4);
-    const int cap = (int)round_up(a.n / (a.d + 1) + 2, 4);
-    if (cap > kMaxWaveCap) return hipErrorNotSupported;
     a.peak_cap = cap;
     const int per_wave = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
     const int bytes = per_wave;
@@ -609,6 +901,21 @@ hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_ba
         case 2: return launch_wave_rd<2>(a, n_rows, n_batch, bytes, per_wave, s);
         default: return launch_wave_rd<3>(a, n_rows, n_batch, bytes, per_wave, s);
     }
+}
+
+// the rows on PeakArgs::lite_list (count on the device): fixed grid of one-wave workgroups
+hipError_t launch_local_maxima_lite(const PeakArgs& a0, const ExactSource& src, hipStream_t s) {
+    PeakArgs a = a0;
+    int cap = 0;
+    if (!a.lite_list || !wave_shape(a.n, a.d, &cap)) return hipSuccess;
+    a.dl = (int)round_up(a.d, 4);
+    a.peak_cap = cap;
+    LiteSource ls{src.u64, src.u64_gen, src.u64_clip_stride, src.gen_clip_stride, src.FS, a.gen};
+    const int bytes = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_lite_kernel), bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(local_maxima_lite_kernel, dim3(2048), dim3(64), bytes, s, a, ls);
+    return hipGetLastError();
 }
 
 }  // namespace repet

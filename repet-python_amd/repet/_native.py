@@ -108,6 +108,7 @@ _SIGNATURES = {
     "repet_ctx_last_sim_indices": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "repet_ctx_last_frame_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "repet_ctx_last_refine_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "repet_ctx_last_exact_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "repet_online_open": (C.c_int, [C.c_int, C.c_int32, C.POINTER(Params), C.POINTER(_P)]),
     "repet_online_push": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "repet_online_finish": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -350,6 +351,13 @@ class Context:
         out = (C.c_int64 * 4)()
         check(lib().repet_ctx_last_refine_stats(self._h, out))
         return {"rows_refined": out[0], "elements_refined": out[1], "decisions_changed": out[2], "flat_rows": out[3]}
+
+    def last_exact_stats(self):
+        """Second level of the peak picking (float64 spectra; see repet_ctx_last_exact_stats)."""
+        out = (C.c_int64 * 8)()
+        check(lib().repet_ctx_last_exact_stats(self._h, out))
+        return {"rows_exact": out[0], "elements_exact": out[1], "rows_changed": out[2], "level2_max_diff": out[3] * 1e-12,
+                "unit_rows_f64": out[4], "input_has_remainders": bool(out[5]), "rows_fast_path": out[6], "rows_handed_on": out[7]}
 
     def last_sim_indices(self, n_rows, number):
         idx = np.empty((max(n_rows, 1), number), dtype=np.int32)

@@ -15,4 +15,4 @@ x = synth(dur, fs, 2, 0)
 ctx = _native.default_context(0)
 ctx.upload(x)
 ctx.execute("sim", repet.derive_params(fs))
-print(json.dumps({"clip": f"{dur}s {fs}Hz", "frames": ctx.last_frame_count(), **ctx.last_refine_stats()}))
+print(json.dumps({"clip": f"{dur}s {fs}Hz", "frames": ctx.last_frame_count(), **ctx.last_refine_stats(), **ctx.last_exact_stats()}))
