@@ -280,12 +280,6 @@ struct MaskArgs {
     // 0x7C00 at pad_row, pad_row+1) and the rank -> value table Vs[c][f][vs_pitch] of the first n_rank_cols bins of
     // every channel. R == nullptr: select on the floats themselves.
     const unsigned short* R; int64_t r_chan_stride; const float* Vs; int64_t vs_pitch; int32_t n_rank_cols;
-    // mask_sim (rank path and its Nyquist-bin kernel): rows whose list the second level of the peak picking is still
-    // deciding (flag_a[row] or flag_b[row] == defer_gen) are left out (defer_mode 1) or are the only ones taken (2)
-    const unsigned int* defer_a; const unsigned int* defer_b; unsigned int defer_gen; int32_t defer_mode;
-    // launch_mask_sim_rows: the frames are taken from row_list[2 k] for k < *row_count (one workgroup per entry and channel);
-    // defer_mode 3 leaves out the entries whose defer_b flag is set (they are on the other list too)
-    const int32_t* row_list; const unsigned int* row_count;
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
@@ -298,10 +292,6 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
                            hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3);
-// the same masks for the listed rows only (the rows the second level of the peak picking decided late), all F bins on the
-// float kernel -- bit-identical to the rank path; n_rows_cap: upper bound of the list length (grid size)
-hipError_t launch_mask_sim_rows(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
-                                int32_t max_count, int64_t n_rows_cap, hipStream_t s);
 int median_network_instructions(int max_n, int* net_size);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
@@ -354,7 +344,7 @@ void* host_alloc(size_t bytes);
 void host_free(void* ptr);
 
 // elementwise helpers
-hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s);
+hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t count, hipStream_t s, float* dst_lo = nullptr);
 hipError_t launch_convert_out(const float* src, double* dst, int64_t count, hipStream_t s);
 hipError_t launch_foreground(const float* audio, const float* background, double* dst, int64_t count, hipStream_t s);
 hipError_t launch_foreground_f32(const float* audio, const float* background, float* dst, int64_t count, hipStream_t s);

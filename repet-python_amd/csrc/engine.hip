@@ -847,9 +847,9 @@ int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, 
 int run_exact_rows(repet_ctx* c, const Tables* tb, const Geo& g, const float* M, int64_t row0, int n_cols, int64_t pitch, int mode,
                    float min_value, int d, int number, int32_t* idx, int idx_pitch, int32_t* count, int64_t shift,
                    const PeakRefine& rf, const PeakBatch* batch, const float* hi, const float* lo, int64_t n_samples,
-                   int64_t clip_stride, int64_t frame_sample0, int64_t n_frames, int clips, hipStream_t stream = nullptr) {
+                   int64_t clip_stride, int64_t frame_sample0, int64_t n_frames, int clips) {
     if (!rf.redo_list) return REPET_OK;
-    if (!stream) stream = c->stream;
+    hipStream_t stream = c->stream;
     ExactSource src{};
     src.hi = hi; src.lo = lo; src.n_samples = n_samples; src.n_channels = g.C; src.clip_stride = clip_stride;
     src.frame_sample0 = frame_sample0; src.W = g.W; src.H = g.H; src.F = g.F; src.FS = g.FS;
@@ -975,27 +975,14 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
                                            nullptr, scratch > 0 ? c->peak_scratch.p : nullptr);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
-        // The second level of the peak picking (float64 spectra for the rows the fp32 spectra cannot settle: a few hundred of
-        // 7 753) takes 0.15 ms of small latency-bound kernels. With the rank-domain median it runs on the side stream
-        // behind the column sort, BESIDE the median mask of all the other rows; the rows it is deciding are masked
-        // afterwards (REPET_EXACT_DEFER=0: in line, before the mask).
-        static const bool defer_on = [] { const char* e = getenv("REPET_EXACT_DEFER"); return !(e && e[0] == '0'); }();
-        const bool defer = defer_on && beside && rf.redo_list != nullptr && rf.lite_flag != nullptr;
-        auto exact_rows = [&](hipStream_t st) {
-            return run_exact_rows(c, tb, g, c->S.as<float>(), 0, (int)T, TS, 0, (float)p->sim_threshold, p->sim_distance_frames, K,
-                                  c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, rf, nullptr,
-                                  c->audio.as<float>() + c->clip_base * g.C, c->has_lo ? c->audio_lo.as<float>() + c->clip_base * g.C : nullptr,
-                                  N, 0, -(int64_t)(g.W / 2), T, 1, st);
-        };
-        if (defer) {
-            RP_TRY(ensure_chunk_events(c, 2));
-            HIP_TRY(hipEventRecord(c->chunk_events[0], c->stream));                 // the first pass is done
-            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->chunk_events[0], 0));
-            RP_TRY(exact_rows(c->side_stream));
-            HIP_TRY(hipEventRecord(c->chunk_events[1], c->side_stream));
-        } else {
-            RP_TRY(exact_rows(c->stream));
-        }
+        // The second level of the peak picking: float64 spectra for the rows the fp32 spectra cannot settle (a few hundred of
+        // 7 753 at cfg 2). Measured and dropped: running it on the side stream BESIDE the median mask of all the other rows
+        // and masking its rows afterwards -- its kernels hold whole register files (one wave per SIMD) and the issue-bound
+        // mask kernel loses more than the chain takes in line (1.256 against 1.178 ms per step).
+        RP_TRY(run_exact_rows(c, tb, g, c->S.as<float>(), 0, (int)T, TS, 0, (float)p->sim_threshold, p->sim_distance_frames, K,
+                              c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, rf, nullptr,
+                              c->audio.as<float>() + c->clip_base * g.C, c->has_lo ? c->audio_lo.as<float>() + c->clip_base * g.C : nullptr,
+                              N, 0, -(int64_t)(g.W / 2), T, 1));
         if (beside) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->join_event, 0));
             // one figure for the two concurrent launches: their bytes added up (S read once + the sort's passes over V)
@@ -1004,22 +991,8 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
             if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true));
         }
-        if (defer) {
-            m.defer_a = rf.lite_flag; m.defer_b = rf.redo_flag; m.defer_gen = rf.gen; m.defer_mode = 1;
-            HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
-                                    c->fork_event, c->join_event));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_events[1], 0));
-            // the rows decided late, from the two lists (a row the fast path handed on is on both: taken from the second)
-            MaskArgs late = m;
-            late.R = nullptr;
-            late.defer_mode = 3; late.row_list = rf.lite_list; late.row_count = rf.stats + 12;
-            HIP_TRY(launch_mask_sim_rows(late, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), max_peaks, T, c->stream));
-            late.defer_mode = 0; late.row_list = rf.redo_list; late.row_count = rf.stats + 4;
-            HIP_TRY(launch_mask_sim_rows(late, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), max_peaks, T, c->stream));
-        } else {
-            HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
-                                    c->fork_event, c->join_event));
-        }
+        HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
+                                c->fork_event, c->join_event));
         mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     } else {
         // Peak picking is LDS/latency-bound, the median mask VALU-bound: run them as a two-stage pipeline over
@@ -2150,8 +2123,12 @@ struct repet_online {
     repet_ctx* ctx = nullptr;       // stream, tables, tile cache, scratch buffers
     repet_params p{};
     int C = 0, W = 0, H = 0, F = 0, FS = 0, B = 0, Hh = 0, LP = 0;
-    DevBuf X[2], V[2], Vn[2], pend[2], band, outf, out64, staging;
+    DevBuf X[2], V[2], Vn[2], pend[2], pend_lo[2], band, outf, out64, staging;
     int cur = 0, pcur = 0;
+    // the pending buffers start with `pend_hist` samples of HISTORY (already transformed: the frames of the sliding window,
+    // whose float64 spectra the second level of the peak picking may ask for) followed by the pend_count unconsumed ones;
+    // pend_lo: the fp32 remainders of float64 pushes, sample for sample
+    int64_t pend_hist = 0;
     int64_t rows_cap = 0;           // frame rows per channel plane of the windows (without the 8 pad rows)
     int64_t pend_cap = 0, pend_count = 0;   // samples per channel
     int64_t hist_valid = 0;         // valid history rows, right-aligned at row Hh
@@ -2227,7 +2204,7 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
 
     if (n_new > 0) {
         StftArgs a{};
-        a.audio = o->pend[o->pcur].as<float>(); a.n_samples = o->pend_count; a.n_channels = o->C; a.sample_offset = 0;
+        a.audio = o->pend[o->pcur].as<float>(); a.n_samples = o->pend_count; a.n_channels = o->C; a.sample_offset = o->pend_hist;
         a.window = tb->window.as<float>(); a.twiddle = tb->twiddle.as<float2>();
         a.W = o->W; a.H = o->H; a.T = n_new; a.FS = o->FS; a.centred = 0;
         a.X = Xb + o->hist_valid * o->FS; a.V = Vb + o->hist_valid * o->FS; a.chan_stride = plane;
@@ -2246,12 +2223,19 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
             HIP_TRY(c->idx.ensure((size_t)n_active * KP * sizeof(int32_t)));
             HIP_TRY(c->cnt.ensure((size_t)n_active * sizeof(int32_t)));
             PeakRefine rf{};
-            RP_TRY(make_refine(c, Vnb, o->FS, o->p.sim_threshold, &rf));
+            RP_TRY(make_refine(c, Vnb, o->FS, o->p.sim_threshold, &rf, n_active, 1, o->B, o->p.sim_distance_frames, Tpad));
             hipError_t e = launch_local_maxima(o->band.as<float>(), n_active, first_active, o->B, o->LP, 1, (float)o->p.sim_threshold,
                                                o->p.sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream,
                                                first_global, &rf);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "online: buffer too long for the peak-picking kernel");
             HIP_TRY(e);
+            // second level: window row fr is global frame first_global + fr, whose first sample sits hist_valid - fr hops
+            // before the pending ones in the buffer (zero beyond what has been pushed, as in the offline run's last frame)
+            const Geo go = make_geo(o->W, o->H, Tw, o->C);
+            RP_TRY(run_exact_rows(c, tb, go, o->band.as<float>(), first_active, o->B, o->LP, 1, (float)o->p.sim_threshold,
+                                  o->p.sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), first_global, rf, nullptr,
+                                  o->pend[o->pcur].as<float>(), o->pend_lo[o->pcur].as<float>(), o->pend_hist + o->pend_count, 0,
+                                  o->pend_hist - o->hist_valid * (int64_t)o->H, Tpad, 1));
         }
         MaskArgs m{};
         m.V = Vb; m.chan_stride = plane; m.n_channels = o->C; m.T = Tw; m.F = o->F; m.FS = o->FS; m.X = Xb; m.mask = nullptr;
@@ -2293,10 +2277,17 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
         o->hist_valid = h2;
         const int64_t consumed = std::min<int64_t>(n_new * (int64_t)o->H, o->pend_count);
         const int64_t left = o->pend_count - consumed;
-        if (left > 0)
-            HIP_TRY(hipMemcpyAsync(o->pend[o->pcur ^ 1].p, o->pend[o->pcur].as<float>() + consumed * o->C,
-                                   (size_t)left * o->C * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        // the samples of the window's frames stay in front of the unconsumed ones (h2 hops of history)
+        const int64_t keep = std::min<int64_t>(h2 * (int64_t)o->H, o->pend_hist + consumed);
+        const int64_t from = o->pend_hist + consumed - keep;
+        if (keep + left > 0) {
+            HIP_TRY(hipMemcpyAsync(o->pend[o->pcur ^ 1].p, o->pend[o->pcur].as<float>() + from * o->C,
+                                   (size_t)(keep + left) * o->C * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(o->pend_lo[o->pcur ^ 1].p, o->pend_lo[o->pcur].as<float>() + from * o->C,
+                                   (size_t)(keep + left) * o->C * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
         o->pcur ^= 1;
+        o->pend_hist = keep;
         o->pend_count = left;
         o->frames_done += n_new;
     }
@@ -2329,7 +2320,7 @@ int repet_online_close(repet_online* o) {
     {
         DeviceGuard guard(o->ctx->device);
         (void)hipStreamSynchronize(o->ctx->stream);
-        for (int k = 0; k < 2; ++k) { o->X[k].release(); o->V[k].release(); o->Vn[k].release(); o->pend[k].release(); }
+        for (int k = 0; k < 2; ++k) { o->X[k].release(); o->V[k].release(); o->Vn[k].release(); o->pend[k].release(); o->pend_lo[k].release(); }
         o->band.release(); o->outf.release(); o->out64.release(); o->staging.release();
     }
     repet_ctx_destroy(o->ctx);
@@ -2351,27 +2342,35 @@ int repet_online_push(repet_online* o, const void* audio, int dtype, int64_t n, 
     const int64_t n_emit = n_new * (int64_t)o->H;
     if (n_emit > capacity || (n_emit > 0 && !out)) return fail(REPET_ERR_BAD_ARG, "online: output capacity too small (needs n_samples + window_length)");
     // append the new samples to the pending buffer (fp32, interleaved)
-    const int64_t need = o->pend_count + n;
+    const int64_t need = o->pend_hist + o->pend_count + n;
     if (need > o->pend_cap) {
-        const int64_t cap = std::max<int64_t>(need + o->W, 2 * o->pend_cap);
-        DevBuf a, b;
+        const int64_t cap = std::max<int64_t>(need + o->W + (int64_t)o->Hh * o->H, 2 * o->pend_cap);
+        DevBuf a, b, al, bl;
         HIP_TRY(a.ensure((size_t)cap * o->C * sizeof(float)));
         HIP_TRY(b.ensure((size_t)cap * o->C * sizeof(float)));
-        if (o->pend_count > 0)
-            HIP_TRY(hipMemcpy(a.p, o->pend[o->pcur].p, (size_t)o->pend_count * o->C * sizeof(float), hipMemcpyDeviceToDevice));
+        HIP_TRY(al.ensure((size_t)cap * o->C * sizeof(float)));
+        HIP_TRY(bl.ensure((size_t)cap * o->C * sizeof(float)));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        o->pend[0].release(); o->pend[1].release();
-        o->pend[0] = a; o->pend[1] = b; o->pcur = 0; o->pend_cap = cap;
+        const size_t live = (size_t)(o->pend_hist + o->pend_count) * o->C * sizeof(float);
+        if (live > 0) {
+            HIP_TRY(hipMemcpy(a.p, o->pend[o->pcur].p, live, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(al.p, o->pend_lo[o->pcur].p, live, hipMemcpyDeviceToDevice));
+        }
+        o->pend[0].release(); o->pend[1].release(); o->pend_lo[0].release(); o->pend_lo[1].release();
+        o->pend[0] = a; o->pend[1] = b; o->pend_lo[0] = al; o->pend_lo[1] = bl; o->pcur = 0; o->pend_cap = cap;
     }
     if (n > 0) {
-        float* dst = o->pend[o->pcur].as<float>() + o->pend_count * o->C;
+        const int64_t at = (o->pend_hist + o->pend_count) * o->C;
+        float* dst = o->pend[o->pcur].as<float>() + at;
+        float* dst_lo = o->pend_lo[o->pcur].as<float>() + at;
         const size_t esz = dtype == REPET_F64 ? 8 : (dtype == REPET_F32 ? 4 : 2);
         if (dtype == REPET_F32) {
             HIP_TRY(hipMemcpyAsync(dst, audio, (size_t)n * o->C * esz, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemsetAsync(dst_lo, 0, (size_t)n * o->C * sizeof(float), c->stream));
         } else {
             HIP_TRY(o->staging.ensure((size_t)n * o->C * esz));
             HIP_TRY(hipMemcpyAsync(o->staging.p, audio, (size_t)n * o->C * esz, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_convert_in(o->staging.p, dtype, dst, n * o->C, c->stream));
+            HIP_TRY(launch_convert_in(o->staging.p, dtype, dst, n * o->C, c->stream, dst_lo));
         }
         o->pend_count += n;
         o->total_in = total;

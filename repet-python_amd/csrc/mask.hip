@@ -210,12 +210,7 @@ struct SlotOffsets {
 template <int NET, bool SPLIT>
 __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                        const int* __restrict__ count, int64_t first_frame) {
-    int64_t t = a.frame0 + blockIdx.x;
-    if (a.row_list) {                                // (launch_mask_sim_rows: the listed frames only)
-        if (blockIdx.x >= *a.row_count) return;
-        t = a.row_list[2 * blockIdx.x];
-        if (a.defer_mode == 3 && a.defer_b[t] == a.defer_gen) return;
-    }
+    const int64_t t = a.frame0 + blockIdx.x;
     const int c = blockIdx.y;
     a.V += blockIdx.z * a.batch_stride;              // clip of a batch (n_batch == 1: blockIdx.z == 0)
     if (a.X) a.X += blockIdx.z * a.batch_stride;
@@ -318,10 +313,6 @@ __global__ __launch_bounds__(256) void mask_sim_rank_kernel(MaskArgs a, const in
     const int64_t t_end = a.frame_end > 0 ? a.frame_end : a.T;
     const int64_t t = a.frame0 + 4 * (int64_t)(i % n_quads) + wave;
     if (t >= t_end) return;
-    if (a.defer_mode) {
-        const bool flagged = a.defer_a[t] == a.defer_gen || a.defer_b[t] == a.defer_gen;
-        if (flagged != (a.defer_mode == 2)) return;
-    }
     const float* Vc = a.V + c * a.chan_stride;
     const int n = count[t];
     const int* list = idx + t * (int64_t)idx_pitch;
@@ -390,12 +381,8 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const 
     count += blockIdx.z * a.cnt_batch_stride;
     const int64_t r0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t n_rows = a.T - first_frame;       // first_frame >= frame0: rows before it are warm-up frames
-    bool active = r0 < n_rows;
+    const bool active = r0 < n_rows;
     const int64_t r = active ? r0 : n_rows - 1;
-    if (a.defer_mode) {
-        const bool flagged = a.defer_a[r] == a.defer_gen || a.defer_b[r] == a.defer_gen;
-        active = active && (flagged == (a.defer_mode == 2));
-    }
     const int64_t t = first_frame + r;
     const float* Vc = a.V + c * a.chan_stride;
     const int n = count[r];
@@ -449,17 +436,6 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
             hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
                                m, idx, idx_pitch, count, first_frame);
         }
-    });
-    return hipGetLastError();
-}
-
-hipError_t launch_mask_sim_rows(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
-                                int32_t max_count, int64_t n_rows_cap, hipStream_t s) {
-    if (!m.row_list || !m.row_count || n_rows_cap <= 0) return hipErrorInvalidValue;
-    dispatch_net(max_count, [&](auto net) {
-        constexpr int NET = decltype(net)::value;
-        hipLaunchKernelGGL((mask_sim_kernel<NET, false>), dim3((unsigned)n_rows_cap, (unsigned)m.n_channels, 1), dim3(256), 0, s,
-                           m, idx, idx_pitch, count, (int64_t)0);
     });
     return hipGetLastError();
 }

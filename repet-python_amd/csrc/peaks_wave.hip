@@ -195,23 +195,26 @@ __device__ __forceinline__ void finish_band_level2(const PeakArgs& a, const Wave
 // float64 unit rows (launch_unit_rows_f64, peaks_exact.hip), and local_maxima_lite_kernel takes the row up again from the
 // record with those values (level 2) -- nothing of the row is scanned twice.
 //   type 1: met in the near-tie verdicts: the lists as they are after the level-1 values (candidates safe in fp32, near-tied
-//           elements, their rivals, all level-1 values); the lite kernel re-takes verdicts, ranking and cut;
+//           elements, their rivals, all level-1 values) -- and, when the cut was close as well, its band; the lite kernel
+//           re-takes the verdicts and, if one changes, ranking and cut (else only the recorded band, if any);
 //   type 2: met only at the top-`number` cut: the ranked candidates and the band's level-1 values; the lite kernel
 //           re-ranks the band.
 struct LiteHeader { int type, n_peak, n_near, n_rival, n_unl, n_band, n_above, np; };
 __host__ __device__ inline size_t lite_record_bytes(int cap) {
-    return 32 + (size_t)kAmbCap * (4 + 8) + (size_t)kRivalCap * (2 + 2 + 2 + 2 + 4 + 8) + (size_t)cap * 12;
+    return 32 + (size_t)kAmbCap * (4 + 8) * 2 + (size_t)kRivalCap * (2 + 2 + 2 + 2 + 4 + 8) + (size_t)cap * 12;
 }
 struct LiteRecord {
-    LiteHeader* h; int* amb_idx; double* amb_exact; short* riv_owner; short* riv_ref; short* unl_list; int* riv_idx;
+    LiteHeader* h; int* amb_idx; double* amb_exact; int* band_idx; double* band_exact; short* riv_owner; short* riv_ref; short* unl_list; int* riv_idx;
     double* riv_exact; float* pval; int* pidx; int* prank;
 };
 __device__ __forceinline__ LiteRecord carve_record(unsigned char* p, int cap) {
     LiteRecord q;
     q.h = reinterpret_cast<LiteHeader*>(p); p += 32;
     q.amb_exact = reinterpret_cast<double*>(p); p += kAmbCap * 8;
+    q.band_exact = reinterpret_cast<double*>(p); p += kAmbCap * 8;
     q.riv_exact = reinterpret_cast<double*>(p); p += kRivalCap * 8;
     q.amb_idx = reinterpret_cast<int*>(p); p += kAmbCap * 4;
+    q.band_idx = reinterpret_cast<int*>(p); p += kAmbCap * 4;
     q.riv_idx = reinterpret_cast<int*>(p); p += kRivalCap * 4;
     q.riv_owner = reinterpret_cast<short*>(p); p += kRivalCap * 2;
     q.riv_ref = reinterpret_cast<short*>(p); p += kRivalCap * 2;
@@ -229,7 +232,7 @@ struct LiteSource { const double* u64; const unsigned int* u64_gen; int64_t u64_
 // lists and level-1 values come from a type-1 record (`rec`) and whose close verdicts are re-taken from float64 spectra.
 template <bool LEVEL2>
 __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds& L, int lane, int64_t r, int64_t j, int clip, float dlt,
-                                                int n_peak, int n_amb, int n_riv, int n_unl, const LiteSource* ls, bool* missing) {
+                                                int n_peak, int n_amb, int n_riv, int n_unl, const LiteSource* ls, bool* missing, bool* unchanged) {
     const int n = a.n;
     auto elem_frame = [&](int i) -> int64_t {                 // unit row of the frame behind element i
         if (a.mode == 0) return i;
@@ -244,14 +247,13 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
     auto level2 = [&](int64_t fr) -> double {
         if constexpr (LEVEL2) {
             const unsigned int* g = ls->u64_gen + (int64_t)clip * ls->gen_clip_stride;
-            if (__hip_atomic_load(&g[fr], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls->gen ||
-                __hip_atomic_load(&g[self_frame], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls->gen) { *missing = true; return 0.0; }
+            if (g[fr] != ls->gen || g[self_frame] != ls->gen) { *missing = true; return 0.0; }    // (written by an earlier kernel)
             const double* base = ls->u64 + (int64_t)clip * ls->u64_clip_stride;
             return dot_rows_f64(base + self_frame * (int64_t)ls->FS, base + fr * (int64_t)ls->FS, ls->FS, lane);
         }
         return 0.0;
     };
-    bool listed = false;                                      // (first pass) this row has a record already
+    int lite_slot = -1;                                       // (first pass) this row's record
 
     if (dlt > 0.0f && n_amb > 0) {
         // Near-tie refinement (see peaks.hip): float64 similarities of the same fp32 spectra decide.
@@ -286,6 +288,8 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
             wave_sync();
         };
         verdicts();
+        if constexpr (LEVEL2)                                  // the level-1 verdicts, to see whether level 2 changes any
+            for (int k = lane; k < n_near; k += 64) L.amb_ok[k] = (!L.amb_lose[k] && L.amb_exact[k] >= a.min_value64) ? 1 : 0;
         // A verdict the fp32 spectra cannot settle: the element against its best rival, or against the threshold, closer
         // than delta2. It is re-taken from float64 spectra of the element and of every rival that may be the best one.
         bool close = false;
@@ -317,7 +321,7 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                 if (lane == 0) { slot = claim_lite_slot(a, r, clip); if (slot == -2) flag_row_for_exact(a, r, clip); }
                 slot = __shfl(slot, 0);
                 if (slot >= 0) {
-                    listed = true;
+                    lite_slot = slot;
                     const LiteRecord q = carve_record(a.records + (size_t)slot * a.record_bytes, a.peak_cap);
                     if (lane == 0) *q.h = LiteHeader{1, n_peak, n_near, n_rival, n_unl, 0, 0, 0};
                     for (int k = lane; k < n_near; k += 64) { q.amb_idx[k] = L.amb_idx[k]; q.amb_exact[k] = L.amb_exact[k]; }
@@ -354,6 +358,11 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                     if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
                 }
                 verdicts();
+                bool differs = false;
+                for (int k = lane; k < n_near; k += 64)
+                    differs = differs || (((!L.amb_lose[k] && L.amb_exact[k] >= a.min_value64) ? 1 : 0) != L.amb_ok[k]);
+                if (!__any(differs)) { *unchanged = true; return; }         // the first pass's list stands (up to its cut band)
+                if (lane == 0 && a.stats) atomicAdd(&a.stats[7], 1u);
             }
         }
         int changed = 0;
@@ -451,14 +460,18 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                     if constexpr (!LEVEL2) {
                         if (lane == 0) enqueue_frame_for_exact(a, clip, self_frame);
                         for (int k = lane; k < n_band; k += 64) if (L.amb_lose[k]) enqueue_frame_for_exact(a, clip, elem_frame(L.amb_idx[k]));
-                        if (!listed) {
+                        if (lite_slot >= 0) {
+                            const LiteRecord q = carve_record(a.records + (size_t)lite_slot * a.record_bytes, a.peak_cap);
+                            if (lane == 0) { q.h->n_band = n_band; q.h->n_above = n_above; q.h->np = np_; }
+                            for (int k = lane; k < n_band; k += 64) { q.band_idx[k] = L.amb_idx[k]; q.band_exact[k] = L.amb_exact[k]; }
+                        } else {
                             int slot = -1;
                             if (lane == 0) { slot = claim_lite_slot(a, r, clip); if (slot == -2) flag_row_for_exact(a, r, clip); }
                             slot = __shfl(slot, 0);
                             if (slot >= 0) {
                                 const LiteRecord q = carve_record(a.records + (size_t)slot * a.record_bytes, a.peak_cap);
                                 if (lane == 0) *q.h = LiteHeader{2, 0, 0, 0, 0, n_band, n_above, np_};
-                                for (int k = lane; k < n_band; k += 64) { q.amb_idx[k] = L.amb_idx[k]; q.amb_exact[k] = L.amb_exact[k]; }
+                                for (int k = lane; k < n_band; k += 64) { q.band_idx[k] = L.amb_idx[k]; q.band_exact[k] = L.amb_exact[k]; }
                             }
                         }
                     } else {
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
     wave_sync();
 
     WSTAMP(4)
-    wave_finish_row<false>(a, L, lane, r, j, (int)blockIdx.y, dlt, n_peak, n_amb, n_riv, n_unl, nullptr, nullptr);
+    wave_finish_row<false>(a, L, lane, r, j, (int)blockIdx.y, dlt, n_peak, n_amb, n_riv, n_unl, nullptr, nullptr, nullptr);
     WSTAMP(5)
     WSTAMP_OUT
 }
@@ -806,7 +819,7 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
         const int64_t j = a.row0 + r;
         const LiteRecord q = carve_record(a.records + (size_t)slot * a.record_bytes, a.peak_cap);
         const LiteHeader h = *q.h;
-        bool missing = false;
+        bool missing = false, unchanged = false;
         wave_sync();
         if (h.type == 1) {
             for (int k = lane; k < h.n_near; k += 64) { L.amb_idx[k] = q.amb_idx[k]; L.amb_exact[k] = q.amb_exact[k]; }
@@ -816,9 +829,12 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
             const int np0 = h.n_peak < a.peak_cap ? h.n_peak : a.peak_cap;
             for (int p = lane; p < np0; p += 64) { L.pval[p] = q.pval[p]; L.pidx[p] = q.pidx[p]; }
             wave_sync();
-            wave_finish_row<true>(a, L, lane, r, j, clip, a.delta, h.n_peak, h.n_near, h.n_rival, h.n_unl, &ls, &missing);
-        } else {
-            for (int k = lane; k < h.n_band; k += 64) { L.amb_idx[k] = q.amb_idx[k]; L.amb_exact[k] = q.amb_exact[k]; L.amb_ok[k] = 0; }
+            wave_finish_row<true>(a, L, lane, r, j, clip, a.delta, h.n_peak, h.n_near, h.n_rival, h.n_unl, &ls, &missing, &unchanged);
+        }
+        if (h.type == 2 || (unchanged && !missing && h.n_band > 0)) {
+            // the recorded band of the cut: its close members get level-2 values, the band is ranked again
+            wave_sync();
+            for (int k = lane; k < h.n_band; k += 64) { L.amb_idx[k] = q.band_idx[k]; L.amb_exact[k] = q.band_exact[k]; L.amb_ok[k] = 0; }
             wave_sync();
             const int n = a.n;
             auto elem_frame = [&](int i) -> int64_t {
@@ -831,8 +847,7 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
             const int64_t self_frame = j - a.shift;
             auto level2 = [&](int64_t fr) -> double {
                 const unsigned int* g = ls.u64_gen + (int64_t)clip * ls.gen_clip_stride;
-                if (__hip_atomic_load(&g[fr], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls.gen ||
-                    __hip_atomic_load(&g[self_frame], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ls.gen) { missing = true; return 0.0; }
+                if (g[fr] != ls.gen || g[self_frame] != ls.gen) { missing = true; return 0.0; }
                 const double* base = ls.u64 + (int64_t)clip * ls.u64_clip_stride;
                 return dot_rows_f64(base + self_frame * (int64_t)ls.FS, base + fr * (int64_t)ls.FS, ls.FS, lane);
             };

@@ -1391,8 +1391,27 @@ static unsigned stream_grid(int64_t n) {
     return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
-hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t n, hipStream_t s) {
+// float64 -> the fp32 sample and its fp32 remainder (what hostio.hip's split_part does on the host)
+__global__ void convert_in_split_kernel(const double* src, float* dst, float* dst_lo, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double x = src[i];
+        const float h = (float)x;
+        dst[i] = h;
+        dst_lo[i] = (float)(x - (double)h);
+    }
+}
+hipError_t launch_convert_in(const void* src, int dtype, float* dst, int64_t n, hipStream_t s, float* dst_lo) {
     if (n <= 0) return hipSuccess;
+    if (dst_lo) {
+        if (dtype == 1) {
+            hipLaunchKernelGGL(convert_in_split_kernel, dim3(stream_grid(n)), dim3(256), 0, s, (const double*)src, dst, dst_lo, n);
+            return hipGetLastError();
+        }
+        const hipError_t e = hipMemsetAsync(dst_lo, 0, (size_t)n * sizeof(float), s);       // exact in fp32: no remainder
+        if (e != hipSuccess) return e;
+    }
     switch (dtype) {
         case 0: hipLaunchKernelGGL(convert_in_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, s, (const float*)src, dst, n); break;
         case 1: hipLaunchKernelGGL(convert_in_kernel<double>, dim3(stream_grid(n)), dim3(256), 0, s, (const double*)src, dst, n); break;

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import repet
-from helpers import golden_input, load_golden, periodic_clip, rms_err
+from helpers import list_difference_gaps, golden_input, load_golden, periodic_clip, rms_err
 from oracle import repet_oracle as orc
 from repet_synth import synth
 
@@ -107,9 +107,10 @@ def test_exactly_periodic_clip_with_ties_inside_the_window(algo, fs, period_hops
     every tied peak is rejected, the list is empty and np.median of nothing gives NaN (repet.py:1535). In the
     reference's float64 the tie is decided by the last bit of its BLAS dot products, i.e. by rounding noise: some
     rows keep one of the copies, most keep none.
-    The engine's documented policy is the exact-arithmetic one: tied elements are never local maxima (fp32 values
-    within delta are re-decided from float64 dot products of the fp32 unit rows, which tie exactly; rows with more
-    near-ties than the refinement takes -- flat_rows -- keep the fp32 decisions, which tie exactly as well).
+    The engine's documented policy is the exact-arithmetic one: tied elements are never local maxima. Every row is a
+    flat row for the first pass and is decided again from float64 spectra (peaks_exact.hip); the copies of a frame are
+    bit-identical samples, so their float64 unit rows are bit-identical and the float64 dot products -- the same sums in
+    the same order -- tie exactly.
     So: wherever the oracle says NaN the engine says NaN; the engine may say NaN where the oracle's rounding noise
     kept a copy; where both are finite (edge frames) they agree to 1e-4."""
     x = periodic_clip(fs, period_hops, seconds, 2)
@@ -125,32 +126,48 @@ def test_exactly_periodic_clip_with_ties_inside_the_window(algo, fs, period_hops
     for a, b in zip(ours, theirs):
         assert set(a.tolist()) <= set(b.tolist())
     assert sum(len(a) > 0 for a in ours) <= sum(len(b) > 0 for b in theirs) <= 0.2 * len(theirs)
-    # more near-ties per row than the float64 refinement takes on (kAmbCap, peaks.hip): flat rows, decided in fp32 --
-    # where identical spectra give bit-identical similarities, i.e. the same exact ties
+    # more near-ties per row than the first refinement takes on (kAmbCap, peaks.hip): flat rows, decided again from
+    # float64 spectra -- where identical samples give bit-identical similarities, i.e. the same exact ties
     assert stats["flat_rows"] in (0, len(theirs))
     print(f"periodic-inside {algo} fs {fs}: oracle nonempty {sum(len(b) > 0 for b in theirs)} engine nonempty "
           f"{sum(len(a) > 0 for a in ours)} of {len(theirs)} rows, refine stats {stats}")
 
 
 @pytest.mark.parametrize("algo", ["sim", "simonline"])
-def test_known_limit_jittered_ties_inside_the_window(algo):
-    """The documented limit of fp32 spectra. Same clip as above (copies INSIDE the +-d window) plus 1e-7 white noise:
-    the copies of a frame now differ by ~1e-9 in similarity. Float64 (the reference) resolves that and keeps ONE
-    winner per window; the engine's spectra are fp32 (north star), in which the copies are still bit-identical or
-    within rounding, so they stay ties and are rejected like exact ones (every row is a flat row). The engine then
-    finds fewer peaks than the reference and emits NaN for frames whose list came out empty. Asserted here: it never
-    does the opposite (a finite sample where the reference says NaN), and wherever both are finite they agree to
-    1e-4 -- a median over a subset of copies of the same frames."""
-    fs, k = 8000, 12
-    x = periodic_clip(fs, k, 24.0, 2, jitter=1e-7)
-    got, want, ours, theirs, stats, p = _run_with_lists(algo, x, fs)
-    assert k <= p.sim_distance_frames and stats["flat_rows"] == len(theirs)
-    assert not np.any(np.isnan(want) & ~np.isnan(got))
-    both = ~np.isnan(got) & ~np.isnan(want)
-    assert both.mean() > 0.5 and rms_err(got[both], want[both]) <= RMS_TOL
-    assert all(set((a % k).tolist()) <= set((b % k).tolist()) for a, b in zip(ours, theirs))    # never a frame class the oracle lacks
-    print(f"jittered ties inside the window, {algo}: engine lists {np.mean([len(a) for a in ours]):.2f} frames on average, "
-          f"oracle {np.mean([len(b) for b in theirs]):.2f}; {int(np.isnan(got).sum())} NaN samples the oracle does not have")
+@pytest.mark.parametrize("fs,k,seconds", [(8000, 12, 24.0), (44100, 20, 30.0)])
+def test_jittered_ties_inside_the_window_are_decided_in_float64(algo, fs, k, seconds):
+    """Same clips as above (copies of a frame INSIDE its own +-d window) plus 1e-7 white noise: the copies now differ by
+    ~1e-13 in similarity. The float64 reference resolves that and keeps one winner per window (repet.py:1318-1326 on
+    complex128 spectra, :149, :1223). fp32 spectra cannot: every row is a flat row for the first pass (round 2 documented
+    this as a limit: the engine emitted NaN frames where the reference is finite). The second level (peaks_exact.hip) decides
+    such rows from float64 spectra of the 48-bit samples: NaN positions EQUAL to the oracle's (none), plain RMS <= 1e-4,
+    no empty list, and every difference between a list and the oracle's NAMED as a tie inside the oracle's own dot-product
+    rounding."""
+    x = periodic_clip(fs, k, seconds, 2, jitter=1e-7)
+    tr = orc.Trace()
+    want = orc.ALGORITHMS[algo](x, fs, orc.Params(), tr)
+    theirs = tr.items["similarity_indices"]
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.upload(x)
+    ctx.execute(algo, p)
+    got = ctx.download()
+    idx, cnt = ctx.last_sim_indices(len(theirs), p.sim_number)
+    stats, exact = ctx.last_refine_stats(), ctx.last_exact_stats()
+    ctx.close()
+    ours = [idx[r, :cnt[r]] for r in range(len(theirs))]
+    assert k <= p.sim_distance_frames
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and not np.isnan(want).any()
+    assert rms_err(got, want) <= RMS_TOL
+    assert all(len(a) > 0 for a in ours) and exact["rows_exact"] == len(theirs) and exact["input_has_remainders"]
+    # where a list differs from the oracle's, the frame in question sits on a tie of the ORACLE's own float64 matrix: the two
+    # values are apart by less than the rounding of a 1 025-term float64 dot product (sqrt(F) 2^-53 = 3.6e-15; measured: up
+    # to 2.4e-15, half of them exactly 0 or 1 ulp), i.e. the reference's BLAS decided them by its summation order
+    differ, named = list_difference_gaps(algo, tr, ours, p)
+    assert all(gap <= 1e-14 for _, _, gap in named), sorted(g for _, _, g in named)[-5:]
+    print(f"jittered ties inside the window, {algo} fs {fs}: lists of {np.mean([len(a) for a in ours]):.2f} frames on average; "
+          f"{differ} of {len(theirs)} rows differ from the oracle's, all on ties of its own matrix (largest gap "
+          f"{max([g for _, _, g in named] or [0.0]):.1e}); refine stats {stats}, second level {exact}")
 
 
 @pytest.mark.parametrize("algo", ["sim", "simonline"])
