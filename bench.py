@@ -109,6 +109,7 @@ def main():
                          "mono, 5 simonline 30-s clips (64 over all ranks)")
     ap.add_argument("--wav", default="/root/reference/audio_file.wav", help="config 1: the reference's example clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scatter-lenient", action="store_true", help="exit 0 even when the scatter/gather leg fails (default: 1, after the headline line has been printed)")
     ap.add_argument("--no-scatter", action="store_true", help="skip the scatter -> separate -> gather leg (8 clips from the root's host RAM)")
     ap.add_argument("--no-batch", action="store_true", help="config 5: one context and stream per clip instead of one batch context")
     ap.add_argument("--cpu-seconds", type=float, default=180.0,
@@ -369,13 +370,22 @@ def main():
     # any rank ends every rank at once, rank 0 with the line (and the reason under "scatter_gather").
     if want_scatter:
         import threading
+        import traceback
+        once = threading.Lock()                      # the watchdog thread and the main thread: exactly one of them prints
 
-        def bail(reason):
+        def bail(reason, trace=None):
+            # every rank says why on stderr; rank 0 still prints the headline (with the reason under "scatter_gather"); the
+            # exit code is 1 -- a broken multi-GPU data path must not look like success -- unless --scatter-lenient asks for
+            # 0 (the headline above is complete either way)
+            sys.stderr.write(f"[bench rank {rank}] scatter/gather leg gave up: {reason}\n" + (trace or ""))
+            sys.stderr.flush()
+            if not once.acquire(blocking=False):
+                return
             if rank == 0:
                 line["scatter_gather"] = {"error": reason}
                 sys.stdout.write("\n" + json.dumps(line) + "\n")
                 sys.stdout.flush()
-            os._exit(0)
+            os._exit(0 if args.scatter_lenient else 1)
 
         watchdog = threading.Timer(args.scatter_limit, bail, args=(f"no result within {args.scatter_limit:g} s",))
         watchdog.daemon = True
@@ -387,8 +397,10 @@ def main():
             if dist is not None:
                 dist.barrier()
         except BaseException as exc:                 # noqa: BLE001 -- the other ranks wait in a collective: end them all
-            bail(f"{type(exc).__name__}: {exc}")
+            bail(f"{type(exc).__name__}: {exc}", traceback.format_exc())
         watchdog.cancel()
+        if not once.acquire(blocking=False):         # the watchdog fired while the leg was finishing: it owns the output
+            time.sleep(3600)
         if rank == 0 and scatter is not None:
             line["scatter_gather"] = scatter
     if dist is not None:

@@ -294,7 +294,7 @@ int repet_ctx_last_refine_stats(repet_ctx* ctx, int64_t out[4]);
 int repet_ctx_last_exact_stats(repet_ctx* ctx, int64_t out[8]);
 
 /* ---- streaming online REPET-SIM (the reference's simonline needs the whole signal, repet.py:712-911) ------
- * open  : state for one stream of n_channels (1, 2 or 4) with the parameters of derive_params(fs);
+ * open  : state for one stream of n_channels (any number, as repet.py:812 loops) with the parameters of derive_params(fs);
  * push  : feed n_samples more samples (NumPy C order); every frame that is now complete is processed and the
  *         newly final background samples (whole hops of W/2) are written to out (float64, interleaved,
  *         `capacity` samples per channel; n_samples + window_length always suffices), their count to *n_written;

@@ -133,6 +133,9 @@ struct IstftOlaArgs {
     // (nullable) the soft mask as a plane of its own, laid out like V (element strides of Y): the spectrum is multiplied
     // by it as it is fetched, so the mask kernels write 4 bytes per cell instead of reading and rewriting 8 + 8
     const float* M;
+    // channel groups (launch_istft_ola splits a clip with more channels than one workgroup's LDS holds): this launch writes
+    // channels [out_chan0, out_chan0 + n_channels) of an output interleaved over out_channels (0: n_channels, from 0)
+    int32_t out_channels, out_chan0;
 };
 hipError_t launch_istft_ola(const IstftOlaArgs& a, hipStream_t s);
 // register-resident variants for W = 2048 (stft_reg.hip); launch_stft / launch_istft_ola pick them themselves

@@ -822,7 +822,8 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     const int fade_in = (int)a.fade_in, overlap = (int)a.fade_out, step = (int)a.seg_step;
     const float den_in = (float)(2 * a.fade_in), den_ov = (float)(2 * a.fade_out);
     // whole float4 groups of the interleaved hop (positions inside a segment in 32 bits; otherwise element by element)
-    const int cshift = (mode != 0 && !narrow) ? -1 : C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : -1;
+    const int CT = a.out_channels > 0 ? a.out_channels : C;   // channels the output is interleaved over (a channel group: > C)
+    const int cshift = ((mode != 0 && !narrow) || CT != C) ? -1 : C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : -1;
     const int n_groups = N * C / 4;
 
     // Measured and dropped (cfg 2 / 3 / 5): fetching the next spectrum while the current one is inverted, and fetching
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
         const bool have = t >= 0 && t < a.T;                   // hop T holds only the last frame's tail
         const bool emit = t >= h0;
         const int64_t n_base = t * N - a.trim;                 // output sample of stage[0]; hop t = [t N, (t+1) N) padded
-        float* const dst0 = a.out + (a.out_offset + n_base) * C;
+        float* const dst0 = a.out + (a.out_offset + n_base) * CT + a.out_chan0;
         if (emit && mode != 0 && cshift >= 0) {                // read after the barriers of the channel loop
             for (int i = tid; i < N; i += kFftThreads) {
                 const int64_t n = n_base + i;
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
                 const int64_t n = n_base + i / C;
                 if (n < 0 || n >= a.n_out) continue;
                 const float v = stage[i] * a.scale;
-                float* dst = dst0 + i;
+                float* dst = dst0 + (int64_t)(i / C) * CT + (i % C);
                 const float w = mode != 0 ? segment_weight(n, a.fade_in, a.fade_out, a.seg_step, a.later) : 1.f;
                 if (mode == 1) *dst += w * v;
                 else *dst = mode == 2 ? w * v : v;
@@ -1290,11 +1291,11 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     if (a.last_hop > a.T) a.last_hop = a.T;                  // hop T holds the last frame's tail, later hops are empty
     const int64_t hops = a.last_hop - a.first_hop + 1;
     if (hops <= 0) return hipSuccess;
-    if (reg_fft_supported(a.W, a.n_channels, true)) {
+    if (a.out_channels == 0 && reg_fft_supported(a.W, a.n_channels, true)) {
         const hipError_t e = launch_istft_ola_reg(a, hops, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (use_wave_kernels() && a.W <= 4096 && a.n_channels <= 4 && a.n_channels != 3) {
+    if (a.out_channels == 0 && use_wave_kernels() && a.W <= 4096 && a.n_channels <= 4 && a.n_channels != 3) {
         const int C = a.n_channels;
         const int FI = 4 / C;
         const int run = (int)round_up(kOlaWaveRun + 1, FI) - 1;
@@ -1310,7 +1311,22 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
     }
     // tails [C][N/2] float2 + stage [N][C] (+ weights [N] for the cross-faded segments of `extended`)
     const size_t dyn = (size_t)a.n_channels * N * sizeof(float) * 2 + (a.accumulate_weighted ? (size_t)N * sizeof(float) : 0);
-    if (dyn > 96 * 1024) return hipErrorInvalidValue;
+    if (dyn > 96 * 1024) {
+        // more channels than one workgroup's LDS holds a frame tail and a hop image for (repet.py:152,179 loop over any
+        // number): groups of channels, one launch each, into their places of the interleaved output
+        const int per = (int)((96 * 1024 - (a.accumulate_weighted ? (size_t)N * sizeof(float) : 0)) / ((size_t)N * sizeof(float) * 2));
+        if (per < 1 || a.out_channels > 0) return hipErrorInvalidValue;
+        for (int c0 = 0; c0 < a.n_channels; c0 += per) {
+            IstftOlaArgs g = a0;
+            g.n_channels = std::min(per, a0.n_channels - c0);
+            g.Y = a0.Y + (int64_t)c0 * a0.chan_stride;
+            if (a0.M) g.M = a0.M + (int64_t)c0 * a0.chan_stride;
+            g.out_channels = a0.n_channels; g.out_chan0 = c0;
+            const hipError_t e = launch_istft_ola(g, s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     return dispatch_window(a.W, [&](auto w) {
         constexpr int Wc = decltype(w)::value;
         const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;

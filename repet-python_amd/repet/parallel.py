@@ -77,12 +77,15 @@ def _engine_separate(algo, device):
         import torch
         if isinstance(x, torch.Tensor) and x.is_cuda:
             ctx = _context(x.device.index)
-            torch.cuda.current_stream(x.device).synchronize()          # the recv that filled x has completed
-            ctx.upload_device(x.data_ptr(), x.shape[0], x.shape[1])
+            # the engine reads interleaved fp32: a float64 wire (or a strided view) is narrowed / packed first, and the result
+            # goes back in the wire's dtype. `x32` stays referenced until upload_device has returned (it copies).
+            x32 = x.to(torch.float32).contiguous()
+            torch.cuda.current_stream(x.device).synchronize()          # the recv that filled x (and the cast) have completed
+            ctx.upload_device(x32.data_ptr(), x32.shape[0], x32.shape[1])
             ctx.execute(algo, repet.derive_params(fs))
-            out = torch.empty_like(x)
+            out = torch.empty_like(x32)
             ctx.download_device(out.data_ptr())
-            return out
+            return out.to(x.dtype)
         repet.set_device(device)
         return getattr(repet, algo)(x, fs)
     return run
@@ -98,13 +101,14 @@ def _engine_extended_range(device):
         ctx = _context(window.device.index if isinstance(window, torch.Tensor) and window.is_cuda else device)
         params = repet.derive_params(fs)
         if isinstance(window, torch.Tensor) and window.is_cuda:
+            w32 = window.to(torch.float32).contiguous()                # (see _engine_separate: fp32, packed, kept alive)
             torch.cuda.current_stream(window.device).synchronize()
-            ctx.upload_device(window.data_ptr(), window.shape[0], window.shape[1])
+            ctx.upload_device(w32.data_ptr(), w32.shape[0], w32.shape[1])
             ctx.set_window(number_samples_total, first_sample)
             ctx.execute_extended_range(params, first, count)
-            out = torch.empty_like(window)
+            out = torch.empty_like(w32)
             ctx.download_device(out.data_ptr())
-            return out
+            return out.to(window.dtype)
         ctx.upload(np.asarray(window))
         ctx.set_window(number_samples_total, first_sample)
         ctx.execute_extended_range(params, first, count)
@@ -213,11 +217,15 @@ def extended_sharded(audio_signal, sampling_frequency, segment_length, segment_s
             lo, hi = windows[r]
             if r != root and hi > lo:
                 pending.append(dist.isend(_wire(x[lo:hi], wire_dtype, dev), dst=r))
-        total = torch.zeros((n, channels), dtype=tdtype, device=dev)
+        # the windows overlap by one cross-fade at every shard border: added up in float64, so the only rounding the sharded
+        # result has on top of a single-GPU run is the fp32 rounding of each rank's own window (a single GPU folds the second
+        # segment of a border into the first with one fused multiply-add; bit-identity would need the neighbour's border
+        # samples on every rank before its last accumulate, i.e. a chain of world - 1 dependent exchanges)
+        total = torch.zeros((n, channels), dtype=torch.float64, device=dev)
         lo, hi = windows[root]
         if hi > lo:
             mine = run_mine(_wire(x[lo:hi], wire_dtype, dev) if on_gpu else np.ascontiguousarray(x[lo:hi], dtype=wire_dtype))
-            total[lo:hi] += mine if isinstance(mine, torch.Tensor) else _wire(mine, wire_dtype, dev)
+            total[lo:hi] += (mine if isinstance(mine, torch.Tensor) else _wire(mine, wire_dtype, dev)).to(torch.float64)
         for req in pending:
             req.wait()
         for r in range(world):                                  # fixed order: the sums do not depend on arrival times
@@ -225,7 +233,7 @@ def extended_sharded(audio_signal, sampling_frequency, segment_length, segment_s
             if r != root and hi > lo:
                 part = torch.empty((hi - lo, channels), dtype=tdtype, device=dev)
                 dist.recv(part, src=r)
-                total[lo:hi] += part
+                total[lo:hi] += part.to(torch.float64)
         return _host(total).astype(np.float64)
 
     lo, hi = windows[rank]

@@ -196,3 +196,22 @@ def test_wav_roundtrip(tmp_path):
     repet.wavwrite(x, 8000, path)
     y, fs = repet.wavread(path)
     assert fs == 8000 and np.allclose(y, x / 32768.0)
+
+
+def test_no_compiled_binary_is_tracked():
+    """Executables and shared objects are build products (they travel to the GPU box with the snapshot, not with the history):
+    none of the files git tracks may be an ELF image."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        files = subprocess.run(["git", "ls-files"], cwd=root, capture_output=True, text=True, check=True).stdout.split("\n")
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("not a git checkout")
+    elf = []
+    for name in files:
+        path = os.path.join(root, name)
+        if name and os.path.isfile(path):
+            with open(path, "rb") as fh:
+                if fh.read(4) == b"\x7fELF":
+                    elf.append(name)
+    assert not elf, elf

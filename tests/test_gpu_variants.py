@@ -384,10 +384,12 @@ def test_sim_headline_config_properties():
 
 
 @pytest.mark.parametrize("fs,channels,seconds", [(4000, 1, 24), (8000, 3, 14), (22050, 4, 13), (96000, 1, 11),
-                                                  (48000, 2, 12), (11025, 5, 12)])
+                                                  (48000, 2, 12), (11025, 5, 12), (44100, 16, 12), (16000, 26, 13)])
 @pytest.mark.parametrize("algo", ALGOS)
 def test_other_rates_and_channel_counts(algo, fs, channels, seconds):
-    """Window lengths 256..4096, 1-5 channels (block and per-channel kernel paths), every variant."""
+    """Window lengths 256..4096, 1-26 channels (block and per-channel kernel paths; 16 channels at W = 2048 and 26 at
+    W = 1024 are more than one workgroup of the fused inverse STFT holds: channel groups), every variant. The reference
+    loops over any number of channels (repet.py:152, :179, :510, :543)."""
     x = synth(seconds, fs, channels, 40 + channels)
     if algo in ("sim", "simonline"):
         assert assert_parity_modulo_near_ties(algo, x, fs).branch == "strict"       # plain RMS <= 1e-4, no tie allowance
@@ -689,7 +691,8 @@ def test_foreground_and_spectrograms_on_device():
     ctx.close()
 
 
-@pytest.mark.parametrize("fs,channels,seconds,seed", [(8000, 2, 16, 2), (16000, 1, 14, 8), (44100, 2, 13, 4)])
+@pytest.mark.parametrize("fs,channels,seconds,seed", [(8000, 2, 16, 2), (16000, 1, 14, 8), (44100, 2, 13, 4), (11025, 3, 14, 6),
+                                                       (22050, 6, 13, 7)])
 def test_streaming_online_equals_offline_simonline(fs, channels, seconds, seed):
     """push() in arbitrary chunks + finish() reproduces repet.simonline of the whole signal exactly."""
     x = synth(seconds, fs, channels, seed)
@@ -721,8 +724,8 @@ def test_streaming_online_errors():
     with pytest.raises(ValueError):
         stream.finish()                          # the reference raises for such a clip (repet.py:802)
     stream.close()
-    with pytest.raises(RuntimeError):
-        repet.online(fs, 3)                      # 1, 2 or 4 channels
+    with pytest.raises(ValueError):
+        repet.online(fs, 0)                      # at least one channel (any number works: the streaming test runs 3 and 6)
     stream = repet.online(fs, 1)
     with pytest.raises(ValueError):
         stream.push(np.zeros((10, 2)))
