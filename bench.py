@@ -31,7 +31,11 @@ MFMA_F16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: ~2.5 PF dense f16 / bf16
 # v_min / v_max / v_pk_min_u16-class VALU instructions: one wave64 instruction per 4 cycles per SIMD (measured 4.2-4.75,
 # tools/microbench/cex_rate.hip), 1 024 SIMDs, 2.4 GHz max clock (MI355X_MICROARCH.md) -> 614.4 G wave-instructions/s
 VALU_QUARTER_RATE_GINSTR = 1024 * 2.4 / 4.0
-PMC_FILE = "r02_pmc_traffic.json"
+# the guide's VALU issue rate for a full-rate instruction (wave64 over two cycles on a SIMD-32): the frame every VALU figure can
+# be put in, whatever its instruction class -- profiles/r03_valu_rate.txt holds the control rows (v_add / v_fma / v_and at
+# 2.0-2.4 cycles) beside the min / max / packed-min classes (4.2-4.75 cycles) at the measured shader clock
+VALU_FULL_RATE_GINSTR = 1024 * 2.4 / 2.0
+PMC_FILE = "r03_pmc_traffic.json"
 # arithmetic type of the path: fp32 end to end, except that the similarity GEMM of sim / simonline runs on the f16 matrix
 # cores as a three-product split of the fp32 operands (22 significant bits per product, fp32 accumulate; gram_f16.hip)
 DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on 16-bit rank codes)",
@@ -94,6 +98,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--series", type=int, default=5, help="timed regions of exactly --steps steps each; value / ms_per_step are the MEDIAN series, all of them are listed")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fp32-GEMM variant (a child run of this script under REPET_GRAM=f32)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=180.0, help="clip length in seconds (config 2: 180)")
     ap.add_argument("--algo", default="sim")
@@ -194,50 +200,57 @@ def main():
     for _ in range(args.warmup):
         for ctx in ctxs:
             ctx.execute(args.algo, params)
-    stage_ms, stage_meta = {}, {}
-    barrier()
-    t0 = time.perf_counter()
     # The K steps are enqueued back to back on the context's stream, as a job that separates one clip after another would:
     # no host wait between them (a blocking call per step left the device idle for 25-30 us while the host read its events).
     # Every step still records its own per-stage HIP events on that stream (timing series): the stage times below are
-    # the means over exactly these K steps.
+    # the means over exactly the K steps of the series that is reported.
     series = len(ctxs) == 1 and not args.sync_steps and 1 <= args.steps <= 4096      # (the series holds 17 events per step)
-    if series:
-        ctxs[0].timing_series_begin(args.steps)
-    for _ in range(args.steps):
+
+    def timed_region():
+        """Exactly K steps between two barriers; returns (elapsed seconds, per-stage totals, per-stage metadata)."""
+        st_ms, st_meta = {}, {}
+        barrier()
+        t0 = time.perf_counter()
         if series:
-            ctxs[0].execute_async(args.algo, params)
-        elif len(ctxs) == 1:
-            tm = ctxs[0].execute(args.algo, params, timing=True)     # blocks until the stream is idle
+            ctxs[0].timing_series_begin(args.steps)
+        for _ in range(args.steps):
+            if series:
+                ctxs[0].execute_async(args.algo, params)
+            elif len(ctxs) == 1:
+                tm = ctxs[0].execute(args.algo, params, timing=True)     # blocks until the stream is idle
+                for s in tm["stages"]:
+                    st_ms[s["name"]] = st_ms.get(s["name"], 0.0) + s["ms"]
+                    st_meta[s["name"]] = s
+            else:                                   # independent clips: one stream each, enqueued back to back
+                for ctx in ctxs:
+                    ctx.execute_async(args.algo, params)
+                for ctx in ctxs:
+                    ctx.synchronize()
+        if series:
+            ctxs[0].synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if series:
+            tm = ctxs[0].timing_series_end()
+            assert tm["steps"] == args.steps, tm["steps"]
             for s in tm["stages"]:
-                stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
-                stage_meta[s["name"]] = s
-        else:                                   # independent clips: one stream each, enqueued back to back
-            for ctx in ctxs:
-                ctx.execute_async(args.algo, params)
-            for ctx in ctxs:
-                ctx.synchronize()
-    if series:
-        ctxs[0].synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if series:
-        tm = ctxs[0].timing_series_end()
-        assert tm["steps"] == args.steps, tm["steps"]
-        for s in tm["stages"]:
-            stage_ms[s["name"]] = s["ms"] * args.steps
-            stage_meta[s["name"]] = s
+                st_ms[s["name"]] = s["ms"] * args.steps
+                st_meta[s["name"]] = s
+        if dist is not None:                        # the slowest rank's time
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, st_ms, st_meta
+
+    regions = [timed_region() for _ in range(max(args.series, 1))]
+    all_elapsed = [r[0] for r in regions]
+    elapsed, stage_ms, stage_meta = sorted(regions, key=lambda r: r[0])[(len(regions) - 1) // 2]      # the median series
     if len(ctxs) > 1:                           # per-stage device times of one clip, outside the timed region
         for _ in range(args.steps):
             tm = ctxs[0].execute(args.algo, params, timing=True)
             for s in tm["stages"]:
                 stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
                 stage_meta[s["name"]] = s
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     out = ctxs[-1].download()
     assert out.shape[-2:] == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
     want_scatter = not args.no_scatter and args.config == 2 and example_clip is None
@@ -273,6 +286,8 @@ def main():
                 ach = net_instr * waves / sec / 1e9
                 entry.update({"bound": "valu", "achieved": round(ach, 1), "peak": VALU_QUARTER_RATE_GINSTR, "unit": "G wave-instr/s",
                               "frac": round(ach / VALU_QUARTER_RATE_GINSTR, 4), "algorithmic": net_instr * waves,
+                              "peak_note": "measured issue rate of the v_min / v_max / v_pk_min_u16 class: one per 4 cycles per SIMD (profiles/r03_valu_rate.txt)",
+                              "frac_vs_full_rate_valu": round(ach / VALU_FULL_RATE_GINSTR, 4), "full_rate_valu_peak": VALU_FULL_RATE_GINSTR,
                               "network": {"wires": net_size, "instructions": net_instr, "waves": waves, "codes": "2 x u16 per lane" if rank_path else "f32"}})
                 # the byte view SURVEY 8d defines for K5 (reads 4FTC + gathers 4FTC*Kmean, writes 4FTC), beside it:
                 # cache-resident gathers, so this is NOT the roof that binds
@@ -331,7 +346,7 @@ def main():
             pass
         roof["ms_per_launch"] = dom["ms"]
         roof["algorithmic_per_launch"] = dom.get("algorithmic")
-        for extra in ("network", "survey_8d_bytes", "fp32_equivalent"):
+        for extra in ("network", "survey_8d_bytes", "fp32_equivalent", "frac_vs_full_rate_valu", "full_rate_valu_peak", "peak_note"):
             if extra in dom:
                 roof[extra] = dom[extra]
         line = {
@@ -340,28 +355,62 @@ def main():
             "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+            "series_ms_per_step": [round(e / max(args.steps, 1) * 1e3, 3) for e in all_elapsed],
+            "ms_per_step_min": round(min(all_elapsed) / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NOTE.get(args.algo, "f32"), "data": "synthetic" if example_clip is None else "the reference's example clip (audio_file.wav, read in place)",
             "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
                                    f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
                        "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
-                       "frames": int(ctx.last_frame_count()), "prewarm_ms": args.prewarm_ms, "parallelism": f"clip-parallel x{world}, no collective" + (", clips batched through every stage" if batched else "")},
+                       "frames": int(ctx.last_frame_count()), "prewarm_ms": args.prewarm_ms,
+                       "series": f"{len(all_elapsed)} timed regions of {args.steps} steps; value and ms_per_step are the median region", "parallelism": f"clip-parallel x{world}, no collective" + (", clips batched through every stage" if batched else "")},
             "roofline": roof,
             "stages": stages,
             "device_ms_per_step": round(sum(s["ms"] for s in stages), 4),
         }
+        if sim_like:
+            ex = ctxs[0].last_exact_stats()
+            line["peak_picking_second_level"] = {
+                "rows": ex["rows_exact"], "of": rows, "rows_fast_path": ex["rows_fast_path"], "float64_unit_rows": ex["unit_rows_f64"],
+                "largest_level1_minus_level2": ex["level2_max_diff"], "input_has_remainders": ex["input_has_remainders"],
+                "note": "rows whose float64 verdicts on the fp32 spectra are closer than 2.5e-7 are decided again from float64 spectra "
+                        "(inside the peak-picking stage's time); REPET_PEAK_EXACT=0 turns it off"}
         if world == 1:
             # PCIe-inclusive drop-in call (float64 NumPy in host RAM -> float64 NumPy out): reported beside `value`,
-            # never as `value`. Includes upload, f64->f32, the run, f32->f64 and download.
+            # never as `value`. Includes upload, f64->f32, the run, f32->f64 and download. Twice: the synthetic
+            # clip as it is (float64 noise: the fp32 remainders of the samples travel too, for the float64 spectra of the
+            # peak picking's second level) and rounded to 16-bit PCM values (what wavread yields: no remainders).
             repet.set_device(local_rank)
-            wall = []
-            for _ in range(4):
-                t1 = time.perf_counter()
-                getattr(repet, args.algo)(clip, fs)
-                wall.append(time.perf_counter() - t1)
-            line["array_in_array_out"] = {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
-                                          "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2),
-                                          "note": "repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads narrow/widen through a pinned ring, fp32 over PCIe)" % args.algo}
+
+            def drop_in(x):
+                wall = []
+                for _ in range(4):
+                    t1 = time.perf_counter()
+                    getattr(repet, args.algo)(x, fs)
+                    wall.append(time.perf_counter() - t1)
+                return {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
+                        "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2)}
+            line["array_in_array_out"] = drop_in(clip)
+            line["array_in_array_out"]["note"] = ("repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads "
+                                                  "narrow/widen through a pinned ring; fp32 samples + their fp32 remainders over PCIe)" % args.algo)
+            if example_clip is None:
+                line["array_in_array_out_pcm16"] = drop_in(np.round(clip * 32768.0).clip(-32768, 32767) / 32768.0)
+                line["array_in_array_out_pcm16"]["note"] = "the same call on the clip rounded to 16-bit PCM values (float64 array, exact in fp32: no remainders travel)"
+        if world == 1 and args.config == 2 and not args.no_variants and example_clip is None:
+            # north_star names an fp32 MFMA GEMM for the similarity matrix; the default is the f16x3 split of the fp32 operands.
+            # The exact-fp32 kernel (REPET_GRAM=f32, read once per process) is timed by a child run of this script.
+            import subprocess
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                        "--series", "3", "--no-cpu-baseline", "--no-scatter", "--no-variants"],
+                                       env=dict(os.environ, REPET_GRAM="f32"), capture_output=True, text=True, timeout=600)
+                cj = json.loads(child.stdout.strip().splitlines()[-1])
+                gemm = [st for st in cj["stages"] if st["name"].startswith("similarity_gemm")][0]
+                line["fp32_gemm_variant"] = {"ms_per_step": cj["ms_per_step"], "gemm_ms": gemm["ms"], "gemm_TFLOP/s_fp32": gemm.get("achieved"),
+                                             "gemm_frac_of_fp32_mfma_peak": gemm.get("frac"), "value": cj["value"],
+                                             "note": "REPET_GRAM=f32: v_mfma_f32_32x32x2_f32, exact fp32 k-ordered accumulation (gram.hip)"}
+            except Exception as exc:  # noqa: BLE001 -- a variant figure must never cost the headline
+                line["fp32_gemm_variant"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
 

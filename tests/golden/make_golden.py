@@ -10,6 +10,7 @@ the module attributes, not by editing the reference). No reference source text i
 
     python tests/golden/make_golden.py --cases small,mid,g44k,edge      (~1 min)
     python tests/golden/make_golden.py --cases config                   (~6 CPU-min)
+    python tests/golden/make_golden.py --cases groove,groove_config     (second clip family; ~4 CPU-min)
 """
 import argparse
 import hashlib
@@ -25,7 +26,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "repet-python_amd"))
-from repet_synth import synth  # noqa: E402
+from repet_synth import synth, synth_groove  # noqa: E402
 
 ALGOS = ("original", "extended", "adaptive", "sim", "simonline")
 
@@ -35,6 +36,16 @@ CASES = {
     "small_stereo": (16, 8000, 2, 2, 7, ALGOS),
     "mid_stereo": (20, 16000, 2, 3, 31, ALGOS),
     "g44k_stereo": (16, 44100, 2, 4, 97, ALGOS),
+}
+# the second clip family (repet_synth.synth_groove: drifting tempo, broadband transients, level steps, inharmonic partials,
+# a bar of digital silence, a bar that changes length) -- same tuple, generated with synth_groove
+GROOVE_CASES = {
+    "groove_small": (16, 8000, 2, 1, 7, ALGOS),
+    "groove_mid": (22, 16000, 2, 2, 31, ALGOS),
+    "groove_44k": (20, 44100, 2, 3, 97, ALGOS),
+}
+GROOVE_CONFIG_CASES = {
+    "cfg2_groove": (180, 44100, 2, 0, 1009, ("sim", "original")),
 }
 CONFIG_CASES = {
     "cfg2_sim": (180, 44100, 2, 0, 1009, ("sim", "original")),
@@ -103,10 +114,10 @@ def per_second_rms(y, fs):
     return np.sqrt(np.mean(y[:n].reshape(-1, fs, y.shape[1]) ** 2, axis=1))
 
 
-def run_case(ref, name, spec, frame_stride, clip=None):
+def run_case(ref, name, spec, frame_stride, clip=None, family="synth"):
     dur, fs, ch, seed, stride, algos = spec
-    x = synth(dur, fs, ch, seed) if clip is None else clip
-    data = {"fs": fs, "duration": dur, "channels": ch, "seed": seed, "sample_stride": stride,
+    x = (synth_groove if family == "groove" else synth)(dur, fs, ch, seed) if clip is None else clip
+    data = {"fs": fs, "duration": dur, "channels": ch, "seed": seed, "sample_stride": stride, "family": family,
             "input_samples": x[::stride].copy(),
             "frame_stride": frame_stride}
     meta = {}
@@ -223,6 +234,13 @@ def main():
     if "config" in want:
         for name, spec in CONFIG_CASES.items():
             run_case(ref, name, spec, 16)
+    if "groove" in want:
+        run_case(ref, "groove_small", GROOVE_CASES["groove_small"], 1, family="groove")
+        run_case(ref, "groove_mid", GROOVE_CASES["groove_mid"], 2, family="groove")
+        run_case(ref, "groove_44k", GROOVE_CASES["groove_44k"], 2, family="groove")
+    if "groove_config" in want:
+        for name, spec in GROOVE_CONFIG_CASES.items():
+            run_case(ref, name, spec, 16, family="groove")
     if "cfg1" in want:
         # BASELINE.json configs[0]: the reference's own example clip (README.md:62-75), read the way its wavread
         # does (repet.py:914-931). Only outputs/statistics are stored; the audio itself is not redistributed.

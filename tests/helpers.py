@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from repet_synth import synth
+from repet_synth import synth, synth_groove
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REFERENCE_WAV = "/root/reference/audio_file.wav"
@@ -38,7 +38,8 @@ def golden_input(name):
         _, pcm = scipy.io.wavfile.read(REFERENCE_WAV)
         x = pcm / pow(2, pcm.itemsize * 8 - 1)             # what the reference's wavread returns (repet.py:929)
     else:
-        x = synth(float(g["duration"]), int(g["fs"]), int(g["channels"]), int(g["seed"]))
+        make = synth_groove if "family" in g and str(g["family"]) == "groove" else synth
+        x = make(float(g["duration"]), int(g["fs"]), int(g["channels"]), int(g["seed"]))
     stride = int(g["sample_stride"])
     assert np.max(np.abs(x[::stride] - g["input_samples"])) < 1e-12, "synth() drifted on this host"
     x.setflags(write=False)

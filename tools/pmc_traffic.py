@@ -16,7 +16,8 @@ from collections import defaultdict
 root, out = sys.argv[1], sys.argv[2]
 # kernel name fragment -> (stage, fetch correction k, note)
 KERNELS = [
-    ("stft_pair_kernel", "stft", 1, "4-8 B/lane"), ("stft_kernel", "stft", 1, "4-8 B/lane"), ("stft_reg_kernel", "stft", 1, "4-8 B/lane"),
+    ("stft_pair_kernel", "stft", 1, "4-8 B/lane"), ("stft_kernel", "stft", 1, "4-8 B/lane"),
+    ("stft_reg_kernel", "stft", 2, "16 B/lane: one float4 per lane and point"),
     ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("split_f16_rows_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_f16_big_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_kernel", "similarity_gemm", 2, "16 B/lane"),
@@ -25,8 +26,16 @@ KERNELS = [
     ("rows_from_code_columns_kernel", "rank_columns", 1, "4 B/lane"),
     ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("mask_sim_kernel", "mask_sim", 1, "4 B/lane gathers"),
-    ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
+    ("istft_ola_reg_kernel", "istft_ola", 2, "16 B/lane spectrum loads"), ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
+    # the second level of the peak picking (inside the peak-picking stage)
+    ("unit_rows_f64_kernel", "local_maxima", 1, "4-16 B/lane"), ("local_maxima_lite_kernel", "local_maxima", 2, "16 B/lane"),
+    ("local_maxima_exact_kernel", "local_maxima", 1, "4 B/lane"),
 ]
+# compulsory bytes of the streaming stages at cfg 2 (N = 7 938 000, C = 2, T = 7 753, F = 1 025, K = 99.85): a
+# "measured" figure below them means a wrong correction factor, and the tool refuses to write it
+N_, C_, T_, F_, K_ = 7938000, 2, 7753, 1025, 99.85
+COMPULSORY = {"stft": 4 * N_ * C_ + 12 * F_ * T_ * C_ + 4 * F_ * T_, "similarity_gemm": 4 * F_ * T_ + 4 * T_ * T_,
+              "local_maxima": 4 * T_ * T_ + 4 * K_ * T_, "istft_ola": 8 * F_ * T_ * C_ + 4 * N_ * C_}
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
@@ -51,5 +60,10 @@ doc = {"_about": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tool
                  "reads are 16-byte-per-lane streams (gfx950 counts those at one half), k = 1 (uncalibrated) for narrower loads and gathers. "
                  "Infinity-Cache hits are included in FETCH_SIZE (MI355X_MICROARCH.md), so this is an upper bound on HBM traffic.",
        "stages": stages}
+for stage, need in COMPULSORY.items():
+    if stage in stages:
+        stages[stage]["compulsory_bytes"] = need
+        stages[stage]["measured_over_compulsory"] = round(stages[stage]["hbm_bytes_per_launch"] / need, 3)
+        assert stages[stage]["hbm_bytes_per_launch"] >= 0.97 * need, (stage, stages[stage]["hbm_bytes_per_launch"], need, "below the bytes the stage must move: wrong fetch correction?")
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in stages.items()}))
