@@ -208,10 +208,20 @@ int repet_release_thread_ctx(void);
 int repet_run(int algo, const void* audio, int dtype, int64_t n_samples, int32_t n_channels,
               const repet_params* p, double* out, int device, repet_timing* timing /* nullable */);
 
-/* Batch of independent clips dealt round-robin (longest first) over n_devices GPUs of this process. */
+/* Batch of independent clips dealt round-robin (longest first) over n_devices GPUs of this process: one host thread,
+ * context and stream per device; every device uploads its own clips from the caller's arrays and downloads its own
+ * results (each over its own PCIe link). REPET_LOGICAL_DEVICES=n (test switch) lets n_devices exceed the visible GPUs:
+ * logical device d runs on physical device d % visible. */
 int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype,
                     const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
                     double* const* out, int32_t n_devices);
+/* The same with the waveforms travelling over xGMI: the clips enter through device 0, go to their devices as
+ * ONE group of ncclSend / ncclRecv (fp32, interleaved; ncclCommInitAll over devices 0 .. n_devices-1, librccl opened on
+ * first use), are separated from the received device buffers, and the results return the same way. repet_run_batch takes
+ * this path when REPET_BATCH_TRANSPORT=rccl. */
+int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype,
+                         const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
+                         double* const* out, int32_t n_devices);
 
 /* ---- stage-level exports (parity tests; layouts follow the reference helper they replace) ---- */
 

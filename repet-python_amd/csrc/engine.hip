@@ -6,6 +6,8 @@
 #include "../../include/repet_hip.h"
 #include "common.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1768,41 +1770,195 @@ int repet_run(int algo, const void* audio, int dtype, int64_t n, int32_t ch, con
     return repet_ctx_download(c, out);
 }
 
-int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
-                    const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {
+namespace {
+
+// Logical devices (test switch): REPET_LOGICAL_DEVICES=n lets repet_run_batch deal its clips over n "devices" although
+// fewer GPUs are visible -- logical device d runs on physical device d % visible, in its own thread, context and stream.
+// Dealing, per-device threads and result placement of the multi-GPU path can then be exercised on a one-GPU box.
+int logical_device_count(int physical) {
+    const char* e = getenv("REPET_LOGICAL_DEVICES");
+    const int n = e ? atoi(e) : 0;
+    return n > physical ? n : physical;
+}
+
+// ---- RCCL over xGMI, inside the library --------------------------------------------------------------
+// librccl is opened on first use (dlopen by soname: a process that has PyTorch's RCCL loaded gets that one) -- the library
+// carries no link-time dependency on it. One communicator per physical device from ncclCommInitAll, one process.
+struct Rccl {
+    using comm_t = void*;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    static constexpr int kFloat = 7;          // ncclFloat32
+    static Rccl& get() {
+        static Rccl r = [] {
+            Rccl x;
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return x;
+            auto sym = [&](const char* name) { return dlsym(h, name); };
+            x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+            x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+            x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+            x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+            x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
+            x.Recv = reinterpret_cast<decltype(x.Recv)>(sym("ncclRecv"));
+            x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+            x.ok = x.CommInitAll && x.CommDestroy && x.GroupStart && x.GroupEnd && x.Send && x.Recv;
+            return x;
+        }();
+        return r;
+    }
+};
+
+#define NCCL_TRY(expr)                                                                                           \
+    do {                                                                                                         \
+        const int r_ = (expr);                                                                                   \
+        if (r_ != 0) return fail(REPET_ERR_HIP, std::string(#expr) + ": " + (rc.GetErrorString ? rc.GetErrorString(r_) : "RCCL error")); \
+    } while (0)
+
+// transport 0: every device's worker thread uploads its own clips from the caller's host arrays and downloads its own
+// results (with the data in host RAM this uses every device's own PCIe link: SURVEY 8e's "honest comparison").
+// transport 1: the clips enter through device 0, travel to their devices as ONE group of ncclSend / ncclRecv over xGMI
+// (fp32, interleaved), are separated there from the received device buffers, and the results come back the same way.
+int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
+                   const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices, int transport) {
     if (n_clips < 0 || (n_clips > 0 && (!audio || !n_samples || !n_channels || !out)))
         return fail(REPET_ERR_BAD_ARG, "null argument");
-    int avail = repet_device_count();
+    const int physical = repet_device_count();
+    if (physical < 1) return fail(REPET_ERR_HIP, "no HIP device");
+    const int avail = transport == 1 ? physical : logical_device_count(physical);     // (RCCL needs distinct physical devices)
     if (n_devices < 1 || n_devices > avail) return fail(REPET_ERR_BAD_ARG, "n_devices out of range");
     // longest first, dealt round-robin: clip order[i] -> device i % n_devices
     std::vector<int> order(n_clips);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
+    std::vector<int> device_of(n_clips);
+    for (int i = 0; i < n_clips; ++i) device_of[order[i]] = i % n_devices;
     std::vector<int> rcs(n_devices, REPET_OK);
     std::vector<std::string> msgs(n_devices);
-    auto worker = [&](int dev) {
-        repet_ctx* c = nullptr;
-        int rc = repet_ctx_create(dev, &c);
-        for (int i = dev; rc == REPET_OK && i < n_clips; i += n_devices) {
-            const int k = order[i];
-            rc = repet_ctx_upload(c, audio[k], dtype, n_samples[k], n_channels[k]);
-            if (rc == REPET_OK) rc = repet_ctx_execute(c, algo, p, nullptr);
-            if (rc == REPET_OK) rc = repet_ctx_download(c, out[k]);
-        }
-        if (rc != REPET_OK) msgs[dev] = g_last_error;
-        rcs[dev] = rc;
-        repet_ctx_destroy(c);
-    };
-    if (n_devices == 1) {
-        worker(0);
-    } else {
+    auto run_threads = [&](const std::function<void(int)>& worker) {
+        if (n_devices == 1) { worker(0); return; }
         std::vector<std::thread> th;
         for (int d = 0; d < n_devices; ++d) th.emplace_back(worker, d);
         for (auto& t : th) t.join();
+    };
+    auto first_error = [&]() -> int {
+        for (int d = 0; d < n_devices; ++d)
+            if (rcs[d] != REPET_OK) return fail(rcs[d], msgs[d]);
+        return REPET_OK;
+    };
+
+    if (transport != 1) {
+        run_threads([&](int dev) {
+            repet_ctx* c = nullptr;
+            int rc = repet_ctx_create(dev % physical, &c);
+            for (int i = dev; rc == REPET_OK && i < n_clips; i += n_devices) {
+                const int k = order[i];
+                rc = repet_ctx_upload(c, audio[k], dtype, n_samples[k], n_channels[k]);
+                if (rc == REPET_OK) rc = repet_ctx_execute(c, algo, p, nullptr);
+                if (rc == REPET_OK) rc = repet_ctx_download(c, out[k]);
+            }
+            if (rc != REPET_OK) msgs[dev] = g_last_error;
+            rcs[dev] = rc;
+            repet_ctx_destroy(c);
+        });
+        return first_error();
     }
-    for (int d = 0; d < n_devices; ++d)
-        if (rcs[d] != REPET_OK) return fail(rcs[d], msgs[d]);
-    return REPET_OK;
+
+    Rccl& rc = Rccl::get();
+    if (!rc.ok) return fail(REPET_ERR_HIP, "librccl could not be loaded (RCCL transport of repet_run_batch)");
+    std::vector<int> devs(n_devices);
+    std::iota(devs.begin(), devs.end(), 0);
+    std::vector<Rccl::comm_t> comms(n_devices, nullptr);
+    NCCL_TRY(rc.CommInitAll(comms.data(), n_devices, devs.data()));
+    std::vector<repet_ctx*> ctx(n_devices, nullptr);
+    std::vector<float*> in_dev(n_clips, nullptr), out_dev(n_clips, nullptr), in_root(n_clips, nullptr), out_root(n_clips, nullptr);
+    int status = REPET_OK;
+    auto cleanup = [&]() {
+        for (int k = 0; k < n_clips; ++k) {
+            for (float* q : {in_dev[k], out_dev[k]}) if (q) { DeviceGuard g(device_of[k]); (void)hipFree(q); }
+            for (float* q : {in_root[k], out_root[k]}) if (q) { DeviceGuard g(0); (void)hipFree(q); }
+        }
+        for (int d = 0; d < n_devices; ++d) { if (ctx[d]) repet_ctx_destroy(ctx[d]); if (comms[d]) (void)rc.CommDestroy(comms[d]); }
+    };
+    auto body = [&]() -> int {
+        for (int d = 0; d < n_devices; ++d) RP_TRY(repet_ctx_create(d, &ctx[d]));
+        // the clips enter through device 0 (fp32, narrowed on their way by the host threads of hostio.hip)
+        for (int k = 0; k < n_clips; ++k) {
+            const size_t count = (size_t)n_samples[k] * n_channels[k];
+            const size_t bytes = std::max<size_t>(count * sizeof(float), 256);
+            { DeviceGuard g(0); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&in_root[k]), bytes)); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_root[k]), bytes)); }
+            if (device_of[k] != 0) { DeviceGuard g(device_of[k]); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&in_dev[k]), bytes)); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev[k]), bytes)); }
+            DeviceGuard g(0);
+            HIP_TRY(staged_upload(ctx[0]->ring, audio[k], dtype, in_root[k], count, ctx[0]->stream));
+        }
+        { DeviceGuard g(0); HIP_TRY(hipStreamSynchronize(ctx[0]->stream)); }
+        // scatter: one group of sends (root) and receives (workers), all links at once
+        NCCL_TRY(rc.GroupStart());
+        for (int k = 0; k < n_clips; ++k) {
+            const int g = device_of[k];
+            if (g == 0) continue;
+            const size_t count = (size_t)n_samples[k] * n_channels[k];
+            NCCL_TRY(rc.Send(in_root[k], count, Rccl::kFloat, g, comms[0], ctx[0]->stream));
+            NCCL_TRY(rc.Recv(in_dev[k], count, Rccl::kFloat, 0, comms[g], ctx[g]->stream));
+        }
+        NCCL_TRY(rc.GroupEnd());
+        for (int d = 0; d < n_devices; ++d) { DeviceGuard g(d); HIP_TRY(hipStreamSynchronize(ctx[d]->stream)); }
+        // every device separates its clips from the received device buffers, results stay on the device
+        run_threads([&](int dev) {
+            int r = REPET_OK;
+            for (int i = dev; r == REPET_OK && i < n_clips; i += n_devices) {
+                const int k = order[i];
+                float* src = dev == 0 ? in_root[k] : in_dev[k];
+                float* dst = dev == 0 ? out_root[k] : out_dev[k];
+                r = repet_ctx_upload_device(ctx[dev], src, n_samples[k], n_channels[k], 1);
+                if (r == REPET_OK) r = repet_ctx_execute(ctx[dev], algo, p, nullptr);
+                if (r == REPET_OK) r = repet_ctx_download_device(ctx[dev], dst);
+            }
+            if (r != REPET_OK) msgs[dev] = g_last_error;
+            rcs[dev] = r;
+        });
+        RP_TRY(first_error());
+        // gather: the mirror image
+        NCCL_TRY(rc.GroupStart());
+        for (int k = 0; k < n_clips; ++k) {
+            const int g = device_of[k];
+            if (g == 0) continue;
+            const size_t count = (size_t)n_samples[k] * n_channels[k];
+            NCCL_TRY(rc.Send(out_dev[k], count, Rccl::kFloat, 0, comms[g], ctx[g]->stream));
+            NCCL_TRY(rc.Recv(out_root[k], count, Rccl::kFloat, g, comms[0], ctx[0]->stream));
+        }
+        NCCL_TRY(rc.GroupEnd());
+        for (int d = 0; d < n_devices; ++d) { DeviceGuard g(d); HIP_TRY(hipStreamSynchronize(ctx[d]->stream)); }
+        DeviceGuard g(0);
+        for (int k = 0; k < n_clips; ++k)
+            HIP_TRY(staged_download(ctx[0]->ring, out_root[k], out[k], (size_t)n_samples[k] * n_channels[k], ctx[0]->stream));
+        return REPET_OK;
+    };
+    status = body();
+    const std::string keep = g_last_error;
+    cleanup();
+    if (status != REPET_OK) g_last_error = keep;
+    return status;
+}
+
+}  // namespace
+
+int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
+                    const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {
+    const char* e = getenv("REPET_BATCH_TRANSPORT");
+    return run_batch_impl(algo, n_clips, audio, dtype, n_samples, n_channels, p, out, n_devices, (e && e[0] == 'r') ? 1 : 0);
+}
+
+int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
+                         const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {
+    return run_batch_impl(algo, n_clips, audio, dtype, n_samples, n_channels, p, out, n_devices, 1);
 }
 
 // ---- stage-level exports ---------------------------------------------------------------------------

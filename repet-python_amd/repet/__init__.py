@@ -127,8 +127,10 @@ def online(sampling_frequency, number_channels):
     return _OnlineSeparator(derive_params(sampling_frequency), number_channels, _device)
 
 
-def run_batch(algo, audio_signals, sampling_frequency, n_devices=1):
-    """Separate a list of independent clips, dealt longest-first over ``n_devices`` GPUs of this process."""
+def run_batch(algo, audio_signals, sampling_frequency, n_devices=1, transport="host"):
+    """Separate a list of independent clips, dealt longest-first over ``n_devices`` GPUs of this process. ``transport``:
+    "host" -- every device moves its own clips over its own PCIe link; "rccl" -- the clips enter through device 0 and
+    travel to their devices (and the results back) as grouped ncclSend / ncclRecv over xGMI."""
     import ctypes as C
     params = derive_params(sampling_frequency)
     ins, outs, ns, cs, code = [], [], [], [], None
@@ -149,7 +151,8 @@ def run_batch(algo, audio_signals, sampling_frequency, n_devices=1):
     count = len(ins)
     in_ptrs = (C.c_void_p * count)(*[x.ctypes.data for x in ins])
     out_ptrs = (C.c_void_p * count)(*[x.ctypes.data for x in outs])
-    _native.check(_native.lib().repet_run_batch(
+    entry = _native.lib().repet_run_batch_rccl if transport == "rccl" else _native.lib().repet_run_batch
+    _native.check(entry(
         _native.ALGO_IDS[algo], count, in_ptrs, code if code is not None else _native.F64,
         (C.c_int64 * count)(*ns), (C.c_int32 * count)(*cs), params, out_ptrs, int(n_devices)))
     return outs

@@ -392,6 +392,36 @@ def test_batch_api_matches_single_calls():
         assert np.array_equal(y, repet.original(x, fs))
 
 
+@pytest.mark.parametrize("n_devices", [2, 4])
+def test_batch_api_deals_over_logical_devices(n_devices, monkeypatch):
+    """repet_run_batch with n_devices > 1 on the one-GPU box: REPET_LOGICAL_DEVICES maps logical device d onto physical
+    device d % visible, so the dealing (longest first, round-robin), the per-device threads, contexts and streams and the
+    placement of the results are the multi-GPU path's. Seven clips of different lengths and channel counts, every
+    result bit-identical to its single call; without the switch more devices than GPUs is an argument error."""
+    fs = 8000
+    clips = [synth(d, fs, c, s) for d, c, s in [(11, 2, 1), (13.5, 1, 2), (12, 2, 3), (16, 2, 4), (11.2, 3, 5), (14, 1, 6), (12.7, 2, 7)]]
+    want = [repet.sim(x, fs) for x in clips]
+    if _native.lib().repet_device_count() < n_devices:
+        with pytest.raises(ValueError):
+            repet.run_batch("sim", clips, fs, n_devices=n_devices)
+    monkeypatch.setenv("REPET_LOGICAL_DEVICES", str(n_devices))
+    outs = repet.run_batch("sim", clips, fs, n_devices=n_devices)
+    assert len(outs) == len(clips)
+    for y, w in zip(outs, want):
+        assert y.shape == w.shape and np.array_equal(y, w)
+
+
+def test_batch_api_rccl_transport_on_one_device():
+    """The in-library xGMI transport (ncclCommInitAll + grouped ncclSend / ncclRecv) with the one device this box
+    has: librccl is opened, a communicator is made and destroyed, the clips go through device buffers (upload_device /
+    download_device) -- everything but the sends themselves, which need a second GPU."""
+    fs = 8000
+    clips = [synth(d, fs, 2, s) for d, s in [(5, 1), (8, 2)]]
+    outs = repet.run_batch("original", clips, fs, n_devices=1, transport="rccl")
+    for x, y in zip(clips, outs):
+        assert np.array_equal(y, repet.original(x, fs))
+
+
 @pytest.mark.slow
 def test_sim_headline_config_properties():
     """cfg 2 (180 s, 44.1 kHz stereo): strided golden samples + size-independent properties."""
