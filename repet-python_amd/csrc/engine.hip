@@ -969,6 +969,9 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         // (Measured and dropped: starting the sort behind the first pass of the peak picking, beside its second level --
         // peaks + sort 0.446 against 0.419 ms: the second level's kernels hold a whole register file per wave and do not share
         // a CU with the sort any better than the first pass does.)
+        // (Measured and dropped: starting the sort behind the first pass of the peak picking, beside its second level --
+        // peaks + sort 0.416 against 0.373 ms: the sort fills the first pass's tail better than it shares the GPU with the
+        // one-wave-per-SIMD kernels of the second level.)
         if (beside) {
             HIP_TRY(hipEventRecord(c->fork_event, c->stream));          // V is complete (so is S)
             HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));

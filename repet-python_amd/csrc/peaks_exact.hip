@@ -103,6 +103,15 @@ __device__ __forceinline__ void wave_unit_row_f64(const ExactSource& s, int logM
     const int64_t s0 = s.frame_sample0 + fr * (int64_t)s.H;
     const float* hi = s.hi + (int64_t)clip * s.clip_stride;
     const float* lo = s.lo ? s.lo + (int64_t)clip * s.clip_stride : nullptr;
+    const float* lo_or_hi = lo ? lo : hi;                      // (see wave_unit_row_f64_reg)
+    const double lo_scale = lo ? 1.0 : 0.0;
+    int rel_lo = (int)min(max(-s0, (int64_t)0), (int64_t)W);
+    int rel_hi = (int)min(max(s.n_samples - s0, (int64_t)0), (int64_t)W);
+    const bool none = rel_hi <= rel_lo;
+    const int64_t anchor = none ? 0 : s0;
+    if (none) rel_hi = rel_lo + 1;
+    const float* frame_hi = hi + anchor * C;
+    const float* frame_lo = lo_or_hi + anchor * C;
     constexpr int kAcc = ACC_REGS ? 17 : 1;
     double acc[kAcc];
 #pragma unroll
@@ -119,19 +128,18 @@ __device__ __forceinline__ void wave_unit_row_f64(const ExactSource& s, int logM
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = min(r0 + 64 * u + lane, M - 1);
-                const int64_t p0 = s0 + 2 * r;
-                const int64_t q0 = min(max(p0, (int64_t)0), s.n_samples - 1), q1 = min(max(p0 + 1, (int64_t)0), s.n_samples - 1);
-                h0[u] = hi[q0 * C + c]; h1[u] = hi[q1 * C + c];
-                l0[u] = lo ? lo[q0 * C + c] : 0.f; l1[u] = lo ? lo[q1 * C + c] : 0.f;
+                const int q0 = min(max(2 * r, rel_lo), rel_hi - 1), q1 = min(max(2 * r + 1, rel_lo), rel_hi - 1);     // (32-bit, frame-relative)
+                h0[u] = frame_hi[q0 * C + c]; h1[u] = frame_hi[q1 * C + c];
+                l0[u] = frame_lo[q0 * C + c]; l1[u] = frame_lo[q1 * C + c];
                 w0[u] = s.window64[2 * r]; w1[u] = s.window64[2 * r + 1];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = r0 + 64 * u + lane;
-                const int64_t p0 = s0 + 2 * r;
-                const bool in0 = p0 >= 0 && p0 < s.n_samples, in1 = p0 + 1 >= 0 && p0 + 1 < s.n_samples;
-                const double re = in0 ? ((double)h0[u] + (double)l0[u]) * w0[u] : 0.0;
-                const double im = in1 ? ((double)h1[u] + (double)l1[u]) * w1[u] : 0.0;
+                const int p0 = 2 * r;
+                const bool in0 = !none && p0 >= rel_lo && p0 < rel_hi, in1 = !none && p0 + 1 >= rel_lo && p0 + 1 < rel_hi;
+                const double re = in0 ? ((double)h0[u] + lo_scale * (double)l0[u]) * w0[u] : 0.0;
+                const double im = in1 ? ((double)h1[u] + lo_scale * (double)l1[u]) * w1[u] : 0.0;
                 if (r < M) Zw[(int)(__brev((unsigned)r) >> (32 - logM))] = make_double2(re, im);
             }
         }
@@ -201,33 +209,84 @@ __device__ __forceinline__ void wave_unit_row_f64_reg(const ExactSource& s, int 
     const int64_t s0 = s.frame_sample0 + fr * (int64_t)s.H;
     const float* hi = s.hi + (int64_t)clip * s.clip_stride;
     const float* lo = s.lo ? s.lo + (int64_t)clip * s.clip_stride : nullptr;
+    // without remainders the same loads read the samples again and count for nothing: a wave-uniform branch around every
+    // load kept them from being issued together
+    const float* lo_or_hi = lo ? lo : hi;
+    const double lo_scale = lo ? 1.0 : 0.0;
+    // the part [rel_lo, rel_hi) of the frame's W samples that exists (relative to its first sample s0; a frame over an edge
+    // of the clip -- or beyond it -- reads clamped positions and counts them as zero)
+    const int W2 = 2 * M;
+    int rel_lo = (int)min(max(-s0, (int64_t)0), (int64_t)W2);
+    int rel_hi = (int)min(max(s.n_samples - s0, (int64_t)0), (int64_t)W2);
+    const bool none = rel_hi <= rel_lo;
+    const int64_t anchor = none ? 0 : s0;                      // (nothing of the frame exists: any readable address will do)
+    if (none) rel_hi = rel_lo + 1;
+    const float* frame_hi = hi + anchor * C;
+    const float* frame_lo = lo_or_hi + anchor * C;
     double acc[17];
 #pragma unroll
     for (int jj = 0; jj < 17; ++jj) acc[jj] = 0.0;
     USTAMP_DECL
     for (int c = 0; c < C; ++c) {
         double2 v[16];
+        // Samples 2r and 2r+1 of a stereo clip are ONE 16-byte load per lane with both channels in it (an 8-byte load for a
+        // mono clip): lanes read consecutive addresses. As two 4-byte loads per channel, 16 bytes apart from lane to lane,
+        // the texture path took 16 us per channel of a transform's 68; the second channel re-reads the lines from cache.
+        const bool pair_ok = !none && rel_lo == 0 && rel_hi == W2;          // (wave-uniform: the whole frame exists)
+        if (pair_ok && C == 2) {
+            struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 h4[8], l4[8];
+                double2 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = 64 * (8 * half + u) + lane;
+                    const F4 a4 = *reinterpret_cast<const F4*>(frame_hi + 4 * r), b4 = *reinterpret_cast<const F4*>(frame_lo + 4 * r);
+                    h4[u] = make_float4(a4.x, a4.y, a4.z, a4.w); l4[u] = make_float4(b4.x, b4.y, b4.z, b4.w);
+                    w[u] = *reinterpret_cast<const double2*>(s.window64 + 2 * r);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float a0 = c ? h4[u].y : h4[u].x, a1 = c ? h4[u].w : h4[u].z, b0 = c ? l4[u].y : l4[u].x, b1 = c ? l4[u].w : l4[u].z;
+                    v[8 * half + u] = make_double2(((double)a0 + lo_scale * (double)b0) * w[u].x, ((double)a1 + lo_scale * (double)b1) * w[u].y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (pair_ok && C == 1) {
+            struct __attribute__((packed, aligned(4))) F2 { float x, y; };
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = 64 * u + lane;
+                const F2 a2 = *reinterpret_cast<const F2*>(frame_hi + 2 * r), b2 = *reinterpret_cast<const F2*>(frame_lo + 2 * r);
+                const double2 w = *reinterpret_cast<const double2*>(s.window64 + 2 * r);
+                v[u] = make_double2(((double)a2.x + lo_scale * (double)b2.x) * w.x, ((double)a2.y + lo_scale * (double)b2.y) * w.y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                    // eight points per lane in flight, no branch around a load
             float h0[8], h1[8], l0[8], l1[8];
             double2 w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
+                // positions relative to the frame's first sample, in 32 bits (the 64-bit clamps and products of absolute
+                // sample numbers were 1 500 quarter-rate instructions per channel: most of the transform's load phase)
                 const int r = 64 * (8 * half + u) + lane;
-                const int64_t p0 = s0 + 2 * r;
-                const int64_t q0 = min(max(p0, (int64_t)0), s.n_samples - 1), q1 = min(max(p0 + 1, (int64_t)0), s.n_samples - 1);
-                h0[u] = hi[q0 * C + c]; h1[u] = hi[q1 * C + c];
-                l0[u] = lo ? lo[q0 * C + c] : 0.f; l1[u] = lo ? lo[q1 * C + c] : 0.f;
+                const int q0 = min(max(2 * r, rel_lo), rel_hi - 1), q1 = min(max(2 * r + 1, rel_lo), rel_hi - 1);
+                h0[u] = frame_hi[q0 * C + c]; h1[u] = frame_hi[q1 * C + c];
+                l0[u] = frame_lo[q0 * C + c]; l1[u] = frame_lo[q1 * C + c];       // (no branch around a load: see lo_scale)
                 w[u] = *reinterpret_cast<const double2*>(s.window64 + 2 * r);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int64_t p0 = s0 + 2 * (64 * (8 * half + u) + lane);
-                const bool in0 = p0 >= 0 && p0 < s.n_samples, in1 = p0 + 1 >= 0 && p0 + 1 < s.n_samples;
-                v[8 * half + u] = make_double2(in0 ? ((double)h0[u] + (double)l0[u]) * w[u].x : 0.0,
-                                               in1 ? ((double)h1[u] + (double)l1[u]) * w[u].y : 0.0);
+                const int p0 = 2 * (64 * (8 * half + u) + lane);
+                const bool in0 = !none && p0 >= rel_lo && p0 < rel_hi, in1 = !none && p0 + 1 >= rel_lo && p0 + 1 < rel_hi;
+                v[8 * half + u] = make_double2(in0 ? ((double)h0[u] + lo_scale * (double)l0[u]) * w[u].x : 0.0,
+                                               in1 ? ((double)h1[u] + lo_scale * (double)l1[u]) * w[u].y : 0.0);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         USTAMP(0)
         f64fft::wave_fft1024(v, ex, tw, lane);
@@ -322,12 +381,14 @@ __global__ __launch_bounds__(64 * kUnitWaves) void unit_rows_f64_kernel(UnitRows
         const int64_t lin = x.frame_list[slot];
         const int clip = (int)(lin / x.src.gen_clip_stride);
         const int64_t fr = lin - (int64_t)clip * x.src.gen_clip_stride;
+        // (No fence, no acquire / release here: the queue holds every frame once, and the rows are read by LATER kernels on
+        // the stream. An agent-scope release per transform wrote back this XCD's whole L2 -- the similarity matrix had just
+        // been written -- and an acquire invalidated it: 11 + 9 us of a 68-us transform.)
         unsigned int* g = x.src.u64_gen + lin;
-        if (__hip_atomic_load(g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == x.gen) continue;
+        if (*g == x.gen) continue;
         unit_row_variant<V>(x.src, x.logM, clip, fr, Zw, accw, tws, rtw, lane);
-        __threadfence();
         if (lane == 0) {
-            __hip_atomic_store(g, x.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            *g = x.gen;
             atomicAdd(&x.stats[9], 1u);
         }
     }
