@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 pass() {
   name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-scatter "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 3 --warmup 1 --series 1 --prewarm-ms 0 --no-cpu-baseline --no-scatter --no-variants "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 BENCH_ARGS=("$@")

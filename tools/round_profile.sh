@@ -11,7 +11,7 @@ for cfg in 3 4 5; do
   timeout 600 python3 bench.py --config $cfg --no-cpu-baseline > "$out/bench_cfg$cfg.json" 2> "$out/bench_cfg$cfg.err"
 done
 for cfg in 2 3 4 5; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_cfg$cfg" -- python3 bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-scatter > "$out/prof_cfg$cfg.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_cfg$cfg" -- python3 bench.py --config $cfg --steps 20 --warmup 5 --series 1 --no-cpu-baseline --no-scatter --no-variants > "$out/prof_cfg$cfg.log" 2>&1
   f=$(find "$out/prof_cfg$cfg" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$out/cfg${cfg}_kernel_stats.csv"
 done
