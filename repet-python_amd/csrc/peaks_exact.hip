@@ -22,6 +22,7 @@
 #include "fft_wave_f64.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace repet {
@@ -59,7 +60,7 @@ struct ExactArgs {
     int logM;                       // log2(W / 2)
     unsigned char* scratch; size_t scratch_per_wg; int n4;
     // LDS: [stage twiddles, M/2 complex doubles (tw_in_lds)] [work: fft_waves transforms side by side | the two scan buffers]
-    int tw_in_lds, fft_waves, acc_in_regs, wave_bytes, scan_in_lds;
+    int tw_count, fft_waves, wave_bytes, scan_in_lds;
     int reg_fft;                    // W = 2048: the transform in the wave's registers (fft_wave_f64.h); LDS: its twiddles, then the work region
 };
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ void exact_wave_sync() {
 // waves of a workgroup transform different frames side by side): Hamming window, real FFT of W samples as a W/2-point
 // complex FFT in the wave's LDS region Zw + a split pass, magnitudes summed over the channels in registers (ACC_REGS:
 // W <= 2048, the lane owns bins lane + 64 j) or in accw, channel mean (repet.py:667), norm (repet.py:1220).
-template <bool ACC_REGS>
+template <bool ACC_REGS, bool STOCKHAM>
 __device__ __forceinline__ void wave_unit_row_f64(const ExactSource& s, int logM, int clip, int64_t fr, double2* Zw, double* accw, const double2* tws, int lane) {
     const int W = s.W, M = W >> 1, F = s.F, C = s.n_channels;
     const int64_t s0 = s.frame_sample0 + fr * (int64_t)s.H;
@@ -140,22 +141,87 @@ __device__ __forceinline__ void wave_unit_row_f64(const ExactSource& s, int logM
                 const bool in0 = !none && p0 >= rel_lo && p0 < rel_hi, in1 = !none && p0 + 1 >= rel_lo && p0 + 1 < rel_hi;
                 const double re = in0 ? ((double)h0[u] + lo_scale * (double)l0[u]) * w0[u] : 0.0;
                 const double im = in1 ? ((double)h1[u] + lo_scale * (double)l1[u]) * w1[u] : 0.0;
-                if (r < M) Zw[(int)(__brev((unsigned)r) >> (32 - logM))] = make_double2(re, im);
+                if (r < M) Zw[STOCKHAM ? r : (int)(__brev((unsigned)r) >> (32 - logM))] = make_double2(re, im);
             }
         }
         exact_wave_sync();
-        for (int h = 1; h < M; h <<= 1) {
-            const int ts = M / (2 * h);                          // exp(-2 pi i k / (2h)) = tws[k * M / (2h)] = twiddle64[2 k M / (2h)]
-            for (int b = lane; b < (M >> 1); b += 64) {
-                const int k = b & (h - 1);
-                const int i0 = ((b - k) << 1) + k, i1 = i0 + h;
-                const double2 w = tws ? tws[k * ts] : s.twiddle64[2 * k * ts];
-                const double2 u = Zw[i0], t = Zw[i1];
-                const double tr = t.x * w.x - t.y * w.y, ti = t.x * w.y + t.y * w.x;
-                Zw[i0] = make_double2(u.x + tr, u.y + ti);
-                Zw[i1] = make_double2(u.x - tr, u.y - ti);
+        if constexpr (STOCKHAM) {
+            // M <= 1024: in-place Stockham passes of radix 4 (a closing radix 2 when log2 M is odd), the wave-synchronous
+            // scheme of stft.hip's wave_fft in float64: every lane reads the operands of its (up to four) butterflies into
+            // registers, then writes the results to their sorted places -- five passes instead of ten, natural order in
+            // and out, and few registers (the kernel shares a CU with other kernels' waves). tws[m] = exp(-2 pi i m / M), m < M.
+            for (int p = 1; p < M;) {
+                if (M / p >= 4) {
+                    const int tstep = M / (p * 4);
+                    double2 u[4][4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int i = min(lane + 64 * b, (M >> 2) - 1);
+                        u[b][0] = Zw[i]; u[b][1] = Zw[i + (M >> 2)]; u[b][2] = Zw[i + (M >> 1)]; u[b][3] = Zw[i + 3 * (M >> 2)];
+                    }
+                    exact_wave_sync();
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int i = lane + 64 * b;
+                        if (i < (M >> 2)) {
+                            const int k = i & (p - 1);
+                            const int j = ((i - k) << 2) + k;
+                            double2 u0 = u[b][0], u1 = u[b][1], u2 = u[b][2], u3 = u[b][3];
+                            if (p > 1) {
+                                const double2 w1 = tws[k * tstep], w2 = tws[2 * k * tstep], w3 = tws[3 * k * tstep];
+                                u1 = make_double2(u1.x * w1.x - u1.y * w1.y, u1.x * w1.y + u1.y * w1.x);
+                                u2 = make_double2(u2.x * w2.x - u2.y * w2.y, u2.x * w2.y + u2.y * w2.x);
+                                u3 = make_double2(u3.x * w3.x - u3.y * w3.y, u3.x * w3.y + u3.y * w3.x);
+                            }
+                            const double2 t0 = make_double2(u0.x + u2.x, u0.y + u2.y), t1 = make_double2(u0.x - u2.x, u0.y - u2.y);
+                            const double2 t2 = make_double2(u1.x + u3.x, u1.y + u3.y), d = make_double2(u1.x - u3.x, u1.y - u3.y);
+                            const double2 t3 = make_double2(d.y, -d.x);                       // -i d
+                            Zw[j] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                            Zw[j + p] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                            Zw[j + 2 * p] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                            Zw[j + 3 * p] = make_double2(t1.x - t3.x, t1.y - t3.y);
+                        }
+                    }
+                    p *= 4;
+                } else {
+                    const int tstep = M / (p * 2);
+                    double2 u[8][2];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int i = min(lane + 64 * b, (M >> 1) - 1);
+                        u[b][0] = Zw[i]; u[b][1] = Zw[i + (M >> 1)];
+                    }
+                    exact_wave_sync();
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int i = lane + 64 * b;
+                        if (i < (M >> 1)) {
+                            const int k = i & (p - 1);
+                            const int j = ((i - k) << 1) + k;
+                            const double2 w1 = tws[k * tstep];
+                            const double2 u1 = make_double2(u[b][1].x * w1.x - u[b][1].y * w1.y, u[b][1].x * w1.y + u[b][1].y * w1.x);
+                            Zw[j] = make_double2(u[b][0].x + u1.x, u[b][0].y + u1.y);
+                            Zw[j + p] = make_double2(u[b][0].x - u1.x, u[b][0].y - u1.y);
+                        }
+                    }
+                    p *= 2;
+                }
+                exact_wave_sync();
             }
-            exact_wave_sync();
+        } else {
+        for (int h = 1; h < M; h <<= 1) {
+                const int ts = M / (2 * h);                          // exp(-2 pi i k / (2h)) = tws[k * M / (2h)] = twiddle64[2 k M / (2h)]
+                for (int b = lane; b < (M >> 1); b += 64) {
+                    const int k = b & (h - 1);
+                    const int i0 = ((b - k) << 1) + k, i1 = i0 + h;
+                    const double2 w = tws ? tws[k * ts] : s.twiddle64[2 * k * ts];
+                    const double2 u = Zw[i0], t = Zw[i1];
+                    const double tr = t.x * w.x - t.y * w.y, ti = t.x * w.y + t.y * w.x;
+                    Zw[i0] = make_double2(u.x + tr, u.y + ti);
+                    Zw[i1] = make_double2(u.x - tr, u.y - ti);
+                }
+                exact_wave_sync();
+            }
         }
         // split: X[k] = (Z[k] + conj Z[M-k]) / 2 + exp(-2 pi i k / W) (Z[k] - conj Z[M-k]) / (2i), k = 0 .. M
         auto magnitude = [&](int k, double2 w) -> double {
@@ -332,14 +398,39 @@ __device__ __forceinline__ void wave_unit_row_f64_reg(const ExactSource& s, int 
 }
 
 // Which transform a kernel instance carries (one per instance: their registers must not add up): the register transform of the
-// 2048-sample window, the LDS transform with the magnitude sums in registers (W < 2048) or in LDS (W > 2048).
-constexpr int kFftReg = 0, kFftLdsRegAcc = 1, kFftLdsAcc = 2;
+// 2048-sample window, the radix-4 Stockham transform in LDS (W < 2048; REPET_EXACT_FFT=lds: W = 2048 too), the radix-2 one
+// (W > 2048).
+constexpr int kFftReg = 0, kFftLds4 = 1, kFftLdsAcc = 2;
 template <int V>
 __device__ __forceinline__ void unit_row_variant(const ExactSource& src, int logM, int clip, int64_t fr, double2* Zw, double* accw,
                                                  const double2* tws, const f64fft::Twiddles& rtw, int lane) {
     if constexpr (V == kFftReg) wave_unit_row_f64_reg(src, clip, fr, Zw, rtw, lane);
-    else if constexpr (V == kFftLdsRegAcc) wave_unit_row_f64<true>(src, logM, clip, fr, Zw, accw, tws, lane);
-    else wave_unit_row_f64<false>(src, logM, clip, fr, Zw, accw, tws, lane);
+    else if constexpr (V == kFftLds4) wave_unit_row_f64<false, true>(src, logM, clip, fr, Zw, accw, tws, lane);
+    else wave_unit_row_f64<false, false>(src, logM, clip, fr, Zw, accw, tws, lane);
+}
+
+// Which transform a launch carries and what it needs of the LDS.
+struct FftPlan { int variant, tw_count, wave_bytes, fixed_bytes; };
+static FftPlan fft_plan(int W) {
+    // W = 2048: the register transform (62 us per stereo frame alone; REPET_EXACT_FFT=lds: the radix-4 LDS transform, 80 us alone
+    // with a third of the registers -- beside the column sort both take 130 us, so the smaller footprint buys nothing)
+    static const bool want_lds = [] { const char* e = getenv("REPET_EXACT_FFT"); return e && e[0] == 'l'; }();
+    const int Mh = W / 2;
+    FftPlan p{};
+    if (W == 2048 && !want_lds) {
+        p.variant = kFftReg; p.tw_count = 0; p.wave_bytes = f64fft::kExPitch * (int)sizeof(double2);
+        p.fixed_bytes = f64fft::kTwCount * (int)sizeof(double2);
+    } else if (W <= 2048) {
+        p.variant = kFftLds4; p.tw_count = Mh;                          // exp(-2 pi i m / M), m < M: radix-4 reaches 3M/4
+        p.wave_bytes = Mh * (int)sizeof(double2) + (Mh + 8) * (int)sizeof(double);
+        p.fixed_bytes = p.tw_count * (int)sizeof(double2);
+    } else {
+        p.variant = kFftLdsAcc; p.tw_count = Mh / 2;
+        p.wave_bytes = Mh * (int)sizeof(double2) + (Mh + 8) * (int)sizeof(double);
+        p.fixed_bytes = p.tw_count * (int)sizeof(double2);
+        if (p.fixed_bytes + p.wave_bytes > 150 * 1024) { p.tw_count = 0; p.fixed_bytes = 0; }      // W = 8192: twiddles from global memory
+    }
+    return p;
 }
 
 // The float64 unit rows of the frames the first pass queued (PeakArgs::frame_list), one wavefront per frame: the lean kernel
@@ -348,7 +439,7 @@ __device__ __forceinline__ void unit_row_variant(const ExactSource& src, int log
 constexpr int kUnitWaves = 4;      // (four transforms per CU at a time: registers for 16 double2 + 17 sums + the loads in flight)
 struct UnitRowsArgs {
     ExactSource src; const int* frame_list; unsigned int* stats; unsigned int gen;
-    int logM, reg_fft, acc_in_regs, tw_in_lds, wave_bytes, waves;
+    int logM, reg_fft, tw_count, wave_bytes, waves;
 };
 template <int V>
 __global__ __launch_bounds__(64 * kUnitWaves) void unit_rows_f64_kernel(UnitRowsArgs x) {
@@ -360,13 +451,13 @@ __global__ __launch_bounds__(64 * kUnitWaves) void unit_rows_f64_kernel(UnitRows
     unsigned char* work = unit_smem;
     f64fft::Twiddles rtw{nullptr, nullptr};
     if (x.reg_fft) {
-        rtw = f64fft::load_twiddles(reinterpret_cast<double2*>(unit_smem), x.src.twiddle64, tid, 64 * kUnitWaves);
+        rtw = f64fft::load_twiddles(reinterpret_cast<double2*>(unit_smem), x.src.twiddle64, tid, (int)blockDim.x);
         work += (size_t)f64fft::kTwCount * sizeof(double2);
-    } else if (x.tw_in_lds) {
+    } else if (x.tw_count > 0) {
         double2* t = reinterpret_cast<double2*>(unit_smem);
-        for (int k = tid; k < (M >> 1); k += 64 * kUnitWaves) t[k] = x.src.twiddle64[2 * k];
+        for (int k = tid; k < x.tw_count; k += (int)blockDim.x) t[k] = x.src.twiddle64[2 * k];       // exp(-2 pi i k / M)
         tws = t;
-        work += (size_t)(M >> 1) * sizeof(double2);
+        work += (size_t)x.tw_count * sizeof(double2);
     }
     __syncthreads();
     if (wave >= x.waves) return;
@@ -414,11 +505,11 @@ __global__ __launch_bounds__(kExactThreads) void local_maxima_exact_kernel(Exact
     if (x.reg_fft) {
         rtw = f64fft::load_twiddles(reinterpret_cast<double2*>(exact_smem), x.src.twiddle64, tid, kExactThreads);
         work += (size_t)f64fft::kTwCount * sizeof(double2);
-    } else if (x.tw_in_lds) {
+    } else if (x.tw_count > 0) {
         double2* t = reinterpret_cast<double2*>(exact_smem);
-        for (int k = tid; k < (M >> 1); k += kExactThreads) t[k] = x.src.twiddle64[2 * k];
+        for (int k = tid; k < x.tw_count; k += kExactThreads) t[k] = x.src.twiddle64[2 * k];       // exp(-2 pi i k / M)
         tws = t;
-        work += (size_t)(M >> 1) * sizeof(double2);
+        work += (size_t)x.tw_count * sizeof(double2);
     }
 
     for (;;) {
@@ -800,18 +891,13 @@ hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_col
     x.n4 = (int)round_up(n_cols, 4) + 4;
     x.scratch = static_cast<unsigned char*>(scratch);
     x.scratch_per_wg = total / grid;
-    // LDS: the stage twiddles (M/2 complex doubles), then one region that holds up to four transforms side by side (one per
-    // wavefront) and, before them, the two window-maximum buffers of the scan. 76 KB leaves room for two workgroups per CU.
-    const int Mh = src.W / 2;
-    const int tw_bytes = (Mh / 2) * (int)sizeof(double2);
-    x.reg_fft = src.W == 2048 ? 1 : 0;
-    x.acc_in_regs = src.W <= 2048 ? 1 : 0;
-    x.wave_bytes = x.reg_fft ? f64fft::kExPitch * (int)sizeof(double2)
-                             : Mh * (int)sizeof(double2) + (x.acc_in_regs ? 0 : (Mh + 8) * (int)sizeof(double));
+    // LDS: the stage twiddles, then one region that holds up to four transforms side by side (one per wavefront) and, before
+    // them, the two window-maximum buffers of the scan. 76 KB leaves room for two workgroups per CU.
+    const FftPlan plan = fft_plan(src.W);
+    x.reg_fft = plan.variant == kFftReg; x.tw_count = plan.tw_count; x.wave_bytes = plan.wave_bytes;
     const int small = 76 * 1024, large = 150 * 1024;
-    x.tw_in_lds = (x.reg_fft || tw_bytes + x.wave_bytes <= large) ? 1 : 0;
-    const int fixed = x.reg_fft ? f64fft::kTwCount * (int)sizeof(double2) : (x.tw_in_lds ? tw_bytes : 0);
-    int waves = x.reg_fft ? 2 : 4;
+    const int fixed = plan.fixed_bytes;
+    int waves = 4;
     while (waves > 1 && fixed + waves * x.wave_bytes > small) --waves;
     if (waves < 2) { waves = 4; while (waves > 1 && fixed + waves * x.wave_bytes > large) --waves; }
     x.fft_waves = waves;
@@ -826,8 +912,8 @@ hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_col
         hipLaunchKernelGGL(local_maxima_exact_kernel<V>, dim3((unsigned)grid), dim3(kExactThreads), lds, s, x);
         return hipGetLastError();
     };
-    if (x.reg_fft) return go(std::integral_constant<int, kFftReg>{});
-    if (x.acc_in_regs) return go(std::integral_constant<int, kFftLdsRegAcc>{});
+    if (plan.variant == kFftReg) return go(std::integral_constant<int, kFftReg>{});
+    if (plan.variant == kFftLds4) return go(std::integral_constant<int, kFftLds4>{});
     return go(std::integral_constant<int, kFftLdsAcc>{});
 }
 
@@ -838,27 +924,25 @@ hipError_t launch_unit_rows_f64(const ExactSource& src, const PeakRefine* refine
     int logM = 0;
     while ((2 << logM) < src.W) ++logM;
     x.logM = logM;
-    const int Mh = src.W / 2;
-    x.reg_fft = src.W == 2048 ? 1 : 0;
-    x.acc_in_regs = src.W <= 2048 ? 1 : 0;
-    x.wave_bytes = x.reg_fft ? f64fft::kExPitch * (int)sizeof(double2)
-                             : Mh * (int)sizeof(double2) + (x.acc_in_regs ? 0 : (Mh + 8) * (int)sizeof(double));
-    const int tw_bytes = (Mh / 2) * (int)sizeof(double2), large = 150 * 1024;
-    x.tw_in_lds = (x.reg_fft || tw_bytes + x.wave_bytes <= large) ? 1 : 0;
-    const int fixed = x.reg_fft ? f64fft::kTwCount * (int)sizeof(double2) : (x.tw_in_lds ? tw_bytes : 0);
-    int waves = kUnitWaves;
-    while (waves > 1 && fixed + waves * x.wave_bytes > large) --waves;
+    const FftPlan plan = fft_plan(src.W);
+    x.reg_fft = plan.variant == kFftReg; x.tw_count = plan.tw_count; x.wave_bytes = plan.wave_bytes;
+    // the LDS transforms need few registers: two waves per workgroup, two or more workgroups per CU
+    const int budget = plan.variant == kFftReg ? 150 * 1024 : 76 * 1024;
+    int waves = plan.variant == kFftReg ? kUnitWaves : 2;
+    while (waves > 1 && plan.fixed_bytes + waves * x.wave_bytes > budget) --waves;
+    if (plan.fixed_bytes + waves * x.wave_bytes > 150 * 1024) return hipErrorInvalidValue;
     x.waves = waves;
-    const int lds = fixed + waves * x.wave_bytes;
+    const int lds = plan.fixed_bytes + waves * x.wave_bytes;
+    const unsigned grid = plan.variant == kFftReg ? 256u : 1024u;
     auto go = [&](auto tag) -> hipError_t {
         constexpr int V = decltype(tag)::value;
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&unit_rows_f64_kernel<V>), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(unit_rows_f64_kernel<V>, dim3(256), dim3(64 * kUnitWaves), lds, s, x);
+        hipLaunchKernelGGL(unit_rows_f64_kernel<V>, dim3(grid), dim3(64 * waves), lds, s, x);
         return hipGetLastError();
     };
-    if (x.reg_fft) return go(std::integral_constant<int, kFftReg>{});
-    if (x.acc_in_regs) return go(std::integral_constant<int, kFftLdsRegAcc>{});
+    if (plan.variant == kFftReg) return go(std::integral_constant<int, kFftReg>{});
+    if (plan.variant == kFftLds4) return go(std::integral_constant<int, kFftLds4>{});
     return go(std::integral_constant<int, kFftLdsAcc>{});
 }
 
