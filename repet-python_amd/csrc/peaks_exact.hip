@@ -485,6 +485,176 @@ __global__ __launch_bounds__(64 * kUnitWaves) void unit_rows_f64_kernel(UnitRows
     }
 }
 
+// The same rows by ONE WORKGROUP per frame (windows up to 8192): the lean kernel's default. A transform is a chain of
+// dependent steps; one wavefront per frame (above) walks it alone -- 62 us per stereo frame however many frames there are --
+// while 256 threads hold ONE radix-4 butterfly each per pass of a 1024-point transform: loads in one round trip (a stereo
+// frame's samples and remainders as one 16-byte load per thread and point pair, both channels at once), five in-place
+// Stockham passes in LDS with two barriers each, the split pass and the magnitude sums in registers (a thread owns bins
+// tid + 256 q), block-wide norm. LDS: twiddles exp(-2 pi i m / M) [M] and the transform [M]: 32 KB at W = 2048.
+// KQ: radix-4 butterflies per thread and pass = ceil(M / 1024): 1 for W <= 2048 (few registers: four workgroups per CU), 4 up to W = 8192
+template <int KQ>
+__global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
+    constexpr int kWgQ = KQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    __shared__ unsigned int sh_slot;
+    __shared__ double red[4];
+    const ExactSource& s = x.src;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = s.W, M = W >> 1, F = s.F, C = s.n_channels;
+    if (x.stats[11] >= x.stats[10]) return;
+    double2* tw = reinterpret_cast<double2*>(wg_smem);
+    double2* Z = tw + M;
+    for (int k = tid; k < M; k += 256) tw[k] = s.twiddle64[2 * k];
+    const unsigned int n_frames = x.stats[10];
+    const int nq = (M + 255) >> 8;            // point pairs per thread (1 .. 16 for M = 4096: loops below run over q < nq)
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int k = atomicAdd(&x.stats[11], 1u);
+            while (k < n_frames && s.u64_gen[x.frame_list[k]] == x.gen) k = atomicAdd(&x.stats[11], 1u);     // (already there)
+            sh_slot = k;
+        }
+        __syncthreads();
+        const unsigned int slot = sh_slot;
+        if (slot >= n_frames) return;
+        const int64_t lin = x.frame_list[slot];
+        const int clip = (int)(lin / s.gen_clip_stride);
+        const int64_t fr = lin - (int64_t)clip * s.gen_clip_stride;
+        unsigned int* g = s.u64_gen + lin;
+        const int64_t s0 = s.frame_sample0 + fr * (int64_t)s.H;
+        const float* hi = s.hi + (int64_t)clip * s.clip_stride;
+        const float* lo = s.lo ? s.lo + (int64_t)clip * s.clip_stride : hi;
+        const double lo_scale = s.lo ? 1.0 : 0.0;
+        int rel_lo = (int)min(max(-s0, (int64_t)0), (int64_t)W);
+        int rel_hi = (int)min(max(s.n_samples - s0, (int64_t)0), (int64_t)W);
+        const bool none = rel_hi <= rel_lo;
+        if (none) { rel_lo = 0; rel_hi = 1; }
+        const float* frame_hi = hi + (none ? 0 : s0) * C;
+        const float* frame_lo = lo + (none ? 0 : s0) * C;
+        const bool whole = !none && rel_lo == 0 && rel_hi == W;
+        double acc[kWgQ * 4 + 1];
+#pragma unroll
+        for (int q = 0; q < kWgQ * 4 + 1; ++q) acc[q] = 0.0;
+        for (int c = 0; c < C; ++c) {
+            // this channel's windowed points, natural order (no branch around a load; positions frame-relative, 32-bit)
+            for (int q0 = 0; q0 < nq; q0 += 4) {
+                float h0[4], h1[4], l0[4], l1[4];
+                double2 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = min(tid + 256 * (q0 + u), M - 1);
+                    const int a0 = min(max(2 * r, rel_lo), rel_hi - 1), a1 = min(max(2 * r + 1, rel_lo), rel_hi - 1);
+                    h0[u] = frame_hi[a0 * C + c]; h1[u] = frame_hi[a1 * C + c];
+                    l0[u] = frame_lo[a0 * C + c]; l1[u] = frame_lo[a1 * C + c];
+                    w[u] = *reinterpret_cast<const double2*>(s.window64 + 2 * r);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = tid + 256 * (q0 + u);
+                    const int p0 = 2 * r;
+                    const bool in0 = !none && (whole || (p0 >= rel_lo && p0 < rel_hi)), in1 = !none && (whole || (p0 + 1 >= rel_lo && p0 + 1 < rel_hi));
+                    if (r < M) Z[r] = make_double2(in0 ? ((double)h0[u] + lo_scale * (double)l0[u]) * w[u].x : 0.0,
+                                                   in1 ? ((double)h1[u] + lo_scale * (double)l1[u]) * w[u].y : 0.0);
+                }
+            }
+            __syncthreads();
+            for (int p = 1; p < M;) {
+                if (M / p >= 4) {
+                    const int tstep = M / (p * 4), quarter = M >> 2;
+                    double2 u[kWgQ][4];
+#pragma unroll
+                    for (int b = 0; b < kWgQ; ++b) {
+                        const int i = min(tid + 256 * b, quarter - 1);
+                        u[b][0] = Z[i]; u[b][1] = Z[i + quarter]; u[b][2] = Z[i + 2 * quarter]; u[b][3] = Z[i + 3 * quarter];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int b = 0; b < kWgQ; ++b) {
+                        const int i = tid + 256 * b;
+                        if (i < quarter) {
+                            const int k = i & (p - 1);
+                            const int j = ((i - k) << 2) + k;
+                            double2 u0 = u[b][0], u1 = u[b][1], u2 = u[b][2], u3 = u[b][3];
+                            if (p > 1) {
+                                const double2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                                u1 = make_double2(u1.x * w1.x - u1.y * w1.y, u1.x * w1.y + u1.y * w1.x);
+                                u2 = make_double2(u2.x * w2.x - u2.y * w2.y, u2.x * w2.y + u2.y * w2.x);
+                                u3 = make_double2(u3.x * w3.x - u3.y * w3.y, u3.x * w3.y + u3.y * w3.x);
+                            }
+                            const double2 t0 = make_double2(u0.x + u2.x, u0.y + u2.y), t1 = make_double2(u0.x - u2.x, u0.y - u2.y);
+                            const double2 t2 = make_double2(u1.x + u3.x, u1.y + u3.y), d = make_double2(u1.x - u3.x, u1.y - u3.y);
+                            const double2 t3 = make_double2(d.y, -d.x);                       // -i d
+                            Z[j] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                            Z[j + p] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                            Z[j + 2 * p] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                            Z[j + 3 * p] = make_double2(t1.x - t3.x, t1.y - t3.y);
+                        }
+                    }
+                    p *= 4;
+                } else {
+                    const int tstep = M / (p * 2), half = M >> 1;
+                    double2 u[2 * kWgQ][2];
+#pragma unroll
+                    for (int b = 0; b < 2 * kWgQ; ++b) {
+                        const int i = min(tid + 256 * b, half - 1);
+                        u[b][0] = Z[i]; u[b][1] = Z[i + half];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int b = 0; b < 2 * kWgQ; ++b) {
+                        const int i = tid + 256 * b;
+                        if (i < half) {
+                            const int k = i & (p - 1);
+                            const int j = ((i - k) << 1) + k;
+                            const double2 w1 = tw[k * tstep];
+                            const double2 u1 = make_double2(u[b][1].x * w1.x - u[b][1].y * w1.y, u[b][1].x * w1.y + u[b][1].y * w1.x);
+                            Z[j] = make_double2(u[b][0].x + u1.x, u[b][0].y + u1.y);
+                            Z[j + p] = make_double2(u[b][0].x - u1.x, u[b][0].y - u1.y);
+                        }
+                    }
+                    p *= 2;
+                }
+                __syncthreads();
+            }
+            // split: X[k] = (Z[k] + conj Z[M-k]) / 2 + exp(-2 pi i k / W) (Z[k] - conj Z[M-k]) / (2i), k = tid + 256 q <= M
+#pragma unroll
+            for (int q = 0; q < kWgQ * 4 + 1; ++q) {
+                const int kk = tid + 256 * q;
+                if (q <= nq) {                                   // (q == nq: bin M, thread 0)
+                    const int k = min(kk, M);
+                    const double2 wk = s.twiddle64[k];
+                    const double2 a = Z[k & (M - 1)], b = Z[(M - k) & (M - 1)];
+                    const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+                    const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+                    const double orr = di, oi = -dr;
+                    const double xr = er + orr * wk.x - oi * wk.y, xi = ei + orr * wk.y + oi * wk.x;
+                    const double m = sqrt(xr * xr + xi * xi);
+                    acc[q] += (kk <= M) ? m : 0.0;
+                }
+            }
+            __syncthreads();                                     // (the next channel overwrites Z)
+        }
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < kWgQ * 4 + 1; ++q) {
+            const int k = tid + 256 * q;
+            acc[q] = acc[q] / (double)C;
+            if (k < F) part += acc[q] * acc[q];
+        }
+        part = wave_sum_f64(part);
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+        double* out = s.u64 + (int64_t)clip * s.u64_clip_stride + fr * (int64_t)s.FS;
+#pragma unroll
+        for (int q = 0; q < kWgQ * 4 + 1; ++q) {
+            const int k = tid + 256 * q;
+            if (k < s.FS) out[k] = (k < F) ? acc[q] / nrm : 0.0;
+        }
+        if (tid == 0) { *g = x.gen; atomicAdd(&x.stats[9], 1u); }
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(kExactThreads) void local_maxima_exact_kernel(ExactArgs x) {
     extern __shared__ __attribute__((aligned(16))) unsigned char exact_smem[];
@@ -924,6 +1094,19 @@ hipError_t launch_unit_rows_f64(const ExactSource& src, const PeakRefine* refine
     int logM = 0;
     while ((2 << logM) < src.W) ++logM;
     x.logM = logM;
+    static const bool per_wave = [] { const char* e = getenv("REPET_EXACT_FFT"); return e != nullptr; }();      // reg / lds / wave: one wavefront per frame
+    if (!per_wave) {
+        const int Mh = src.W / 2;
+        const int lds = 2 * Mh * (int)sizeof(double2);
+        auto go_wg = [&](auto tag) -> hipError_t {
+            constexpr int KQ = decltype(tag)::value;
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&unit_rows_f64_wg_kernel<KQ>), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(unit_rows_f64_wg_kernel<KQ>, dim3(1024), dim3(256), lds, s, x);
+            return hipGetLastError();
+        };
+        return Mh <= 1024 ? go_wg(std::integral_constant<int, 1>{}) : go_wg(std::integral_constant<int, 4>{});
+    }
     const FftPlan plan = fft_plan(src.W);
     x.reg_fft = plan.variant == kFftReg; x.tw_count = plan.tw_count; x.wave_bytes = plan.wave_bytes;
     // the LDS transforms need few registers: two waves per workgroup, two or more workgroups per CU
