@@ -215,6 +215,45 @@ __device__ __forceinline__ double dot_rows_f64(const double* __restrict__ x, con
     return wave_sum_f64(acc);
 }
 
+// Level-2 values of a LIST of frames against one frame: float64 dot products of float64 unit rows (peaks_exact.hip), the row
+// of `self_frame` kept in registers, the next item's row in flight while the current one is reduced (rows of up to 1 152
+// components; longer ones item by item). All stamps are checked first, in one batch: false when a row is not there.
+// frame_of(i): frame row of item i; store(i, e): every lane calls it with the same e.
+template <class FrameOf, class Store>
+__device__ __forceinline__ bool level2_similarity_list(const double* __restrict__ base, const unsigned int* __restrict__ gens, unsigned int gen,
+                                                       int64_t self_frame, int FS, int lane, int n_items, FrameOf frame_of, Store store) {
+    bool ok = gens[self_frame] == gen;
+    for (int it = lane; it < n_items; it += 64) ok = ok && gens[frame_of(it)] == gen;
+    if (!__all(ok)) return false;
+    const int len2 = FS >> 1;
+    const double* self = base + self_frame * (int64_t)FS;
+    if (len2 > 576) {
+        for (int it = 0; it < n_items; ++it) store(it, dot_rows_f64(self, base + frame_of(it) * (int64_t)FS, FS, lane));
+        return true;
+    }
+    auto fetch = [&](const double* row, double2 (&dst)[9]) {
+        const double2* r2 = reinterpret_cast<const double2*>(row);
+#pragma unroll
+        for (int u = 0; u < 9; ++u) dst[u] = r2[min(64 * u + lane, len2 - 1)];
+    };
+    double2 p[9], q[9];
+    fetch(self, p);
+    if (n_items > 0) fetch(base + frame_of(0) * (int64_t)FS, q);
+#pragma unroll
+    for (int u = 0; u < 9; ++u) if (64 * u + lane >= len2) p[u] = make_double2(0.0, 0.0);
+    for (int it = 0; it < n_items; ++it) {
+        double2 r[9];
+        fetch(base + frame_of(it + 1 < n_items ? it + 1 : it) * (int64_t)FS, r);      // in flight during the sums below
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) acc += p[u].x * q[u].x + p[u].y * q[u].y;
+        store(it, wave_sum_f64(acc));
+#pragma unroll
+        for (int u = 0; u < 9; ++u) q[u] = r[u];
+    }
+    return true;
+}
+
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }

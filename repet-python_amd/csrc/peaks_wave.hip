@@ -160,22 +160,41 @@ __device__ __forceinline__ bool rank_cut_band(const PeakArgs& a, const WaveLds& 
     return settled;
 }
 
-// (lite kernel) the marked members of the band get their level-2 values, then the band is ranked again
-template <class OutIndex, class ElemFrame, class Level2>
+
+// where the lite kernel finds the float64 unit rows (written by launch_unit_rows_f64 earlier on the stream)
+struct LiteSource {
+    const double* u64; const unsigned int* u64_gen; int64_t u64_clip_stride, gen_clip_stride; int FS; unsigned int gen;
+    // (lite kernel) the record's fp32-safe candidates, copied into the wave's lists only when a verdict changes
+    const float* rec_pval; const int* rec_pidx; int rec_np;
+};
+
+// (lite kernel) the marked members of the band get their level-2 values (one pipelined list), then the band is ranked again
+template <class OutIndex, class ElemFrame>
 __device__ __forceinline__ void finish_band_level2(const PeakArgs& a, const WaveLds& L, int lane, int n_band, int n_above, int* out,
-                                                   OutIndex out_index, ElemFrame elem_frame, Level2 level2, bool* missing) {
-    double worst = 0.0;
+                                                   OutIndex out_index, ElemFrame elem_frame, const LiteSource& ls, int clip,
+                                                   int64_t self_frame, bool* missing) {
+    short* items = L.unl_list;
     int n2 = 0;
-    for (int k = 0; k < n_band; ++k) {
-        if (!L.amb_lose[k]) continue;
-        const double e2 = level2(elem_frame(L.amb_idx[k]));
-        worst = fmax(worst, fabs(e2 - L.amb_exact[k]));
-        ++n2;
-        wave_sync();
-        if (lane == 0) L.amb_exact[k] = e2;
+    for (int k0 = 0; k0 < n_band; k0 += 64) {
+        const bool f = k0 + lane < n_band && L.amb_lose[k0 + lane];
+        int next;
+        const int slot = ballot_slot(f, n2, lane, &next);
+        if (f && slot < kRivalCap) items[slot] = (short)(k0 + lane);
+        n2 = next;
     }
     wave_sync();
-    if (*missing) return;
+    double worst = 0.0;
+    const bool have = level2_similarity_list(
+        ls.u64 + (int64_t)clip * ls.u64_clip_stride, ls.u64_gen + (int64_t)clip * ls.gen_clip_stride, ls.gen, self_frame, ls.FS, lane, n2,
+        [&](int it) -> int64_t { return elem_frame(L.amb_idx[items[it]]); },
+        [&](int it, double e2) {
+            const int k = items[it];
+            worst = fmax(worst, fabs(e2 - L.amb_exact[k]));
+            wave_sync();
+            if (lane == 0) L.amb_exact[k] = e2;
+        });
+    wave_sync();
+    if (!have) { *missing = true; return; }
     if (lane == 0 && a.stats) {
         atomicAdd(&a.stats[6], (unsigned)n2);
         if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
@@ -224,8 +243,6 @@ __device__ __forceinline__ LiteRecord carve_record(unsigned char* p, int cap) {
     q.prank = reinterpret_cast<int*>(p);
     return q;
 }
-// where the lite kernel finds the float64 unit rows (written by launch_unit_rows_f64 earlier on the stream)
-struct LiteSource { const double* u64; const unsigned int* u64_gen; int64_t u64_clip_stride, gen_clip_stride; int FS; unsigned int gen; };
 
 // Everything of a row after the sweep: near-tie verdicts, ranking, top-`number` cut, the list. LEVEL2 = false: the first
 // pass (records and queue entries are written where a verdict is closer than delta2). LEVEL2 = true: the lite kernel, whose
@@ -243,16 +260,6 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
     auto elem_row = [&](int i) -> const float* { return a.unit + elem_frame(i) * (int64_t)a.unit_pitch; };
     auto out_index = [&](int i) -> int { return a.mode == 0 ? i : (int)elem_frame(i); };
     const int64_t self_frame = j - a.shift;
-    // level-2 value of the row against frame fr (LEVEL2 only); *missing when the float64 row is not there
-    auto level2 = [&](int64_t fr) -> double {
-        if constexpr (LEVEL2) {
-            const unsigned int* g = ls->u64_gen + (int64_t)clip * ls->gen_clip_stride;
-            if (g[fr] != ls->gen || g[self_frame] != ls->gen) { *missing = true; return 0.0; }    // (written by an earlier kernel)
-            const double* base = ls->u64 + (int64_t)clip * ls->u64_clip_stride;
-            return dot_rows_f64(base + self_frame * (int64_t)ls->FS, base + fr * (int64_t)ls->FS, ls->FS, lane);
-        }
-        return 0.0;
-    };
     int lite_slot = -1;                                       // (first pass) this row's record
 
     if (dlt > 0.0f && n_amb > 0) {
@@ -332,27 +339,39 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                     for (int p = lane; p < np0; p += 64) { q.pval[p] = L.pval[p]; q.pidx[p] = L.pidx[p]; }
                 }
             } else {
-                // level-2 values in place of the level-1 ones, then the verdicts again
-                double worst = 0.0;
+                // level-2 values in place of the level-1 ones (all of the row's in one pipelined list), then the verdicts again
+                short* items = L.unl_list;                     // (free here: the record carries no unlisted-rival map)
                 int n2 = 0;
-                for (int k = 0; k < n_near; ++k) {
-                    if (!amb_n2[k]) continue;
-                    const double e2 = level2(elem_frame(L.amb_idx[k]));
-                    worst = fmax(worst, fabs(e2 - L.amb_exact[k]));
-                    ++n2;
-                    wave_sync();
-                    if (lane == 0) L.amb_exact[k] = e2;
+                for (int k0 = 0; k0 < n_near; k0 += 64) {
+                    const bool f = k0 + lane < n_near && amb_n2[k0 + lane];
+                    int next;
+                    const int slot = ballot_slot(f, n2, lane, &next);
+                    if (f && slot < kRivalCap) items[slot] = (short)(k0 + lane);
+                    n2 = next;
                 }
-                for (int e = 0; e < n_rival; ++e) {
-                    if (!riv_n2[e]) continue;
-                    const double e2 = level2(elem_frame(L.riv_idx[e]));
-                    worst = fmax(worst, fabs(e2 - L.riv_exact[e]));
-                    ++n2;
-                    wave_sync();
-                    if (lane == 0) L.riv_exact[e] = e2;
+                for (int e0 = 0; e0 < n_rival; e0 += 64) {
+                    const bool f = e0 + lane < n_rival && riv_n2[e0 + lane];
+                    int next;
+                    const int slot = ballot_slot(f, n2, lane, &next);
+                    if (f && slot < kRivalCap) items[slot] = (short)(kAmbCap + e0 + lane);
+                    n2 = next;
                 }
                 wave_sync();
-                if (*missing) return;
+                if (n2 > kRivalCap) { *missing = true; return; }       // (more than the list holds: the general path)
+                double worst = 0.0;
+                const bool have = level2_similarity_list(
+                    ls->u64 + (int64_t)clip * ls->u64_clip_stride, ls->u64_gen + (int64_t)clip * ls->gen_clip_stride, ls->gen, self_frame,
+                    ls->FS, lane, n2,
+                    [&](int it) -> int64_t { const int c = items[it]; return elem_frame(c < kAmbCap ? L.amb_idx[c] : L.riv_idx[c - kAmbCap]); },
+                    [&](int it, double e2) {
+                        const int c = items[it];
+                        double* at = c < kAmbCap ? &L.amb_exact[c] : &L.riv_exact[c - kAmbCap];
+                        worst = fmax(worst, fabs(e2 - *at));
+                        wave_sync();
+                        if (lane == 0) *at = e2;
+                    });
+                wave_sync();
+                if (!have) { *missing = true; return; }
                 if (lane == 0 && a.stats) {
                     atomicAdd(&a.stats[6], (unsigned)n2);
                     if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
@@ -363,6 +382,8 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                     differs = differs || (((!L.amb_lose[k] && L.amb_exact[k] >= a.min_value64) ? 1 : 0) != L.amb_ok[k]);
                 if (!__any(differs)) { *unchanged = true; return; }         // the first pass's list stands (up to its cut band)
                 if (lane == 0 && a.stats) atomicAdd(&a.stats[7], 1u);
+                for (int p = lane; p < ls->rec_np; p += 64) { L.pval[p] = ls->rec_pval[p]; L.pidx[p] = ls->rec_pidx[p]; }
+                wave_sync();
             }
         }
         int changed = 0;
@@ -475,7 +496,7 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                             }
                         }
                     } else {
-                        finish_band_level2(a, L, lane, n_band, n_above, out, out_index, elem_frame, level2, missing);
+                        finish_band_level2(a, L, lane, n_band, n_above, out, out_index, elem_frame, *ls, clip, self_frame, missing);
                         if (*missing) return;
                     }
                 }
@@ -826,10 +847,10 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
             for (int e = lane; e < h.n_rival; e += 64) {
                 L.riv_owner[e] = q.riv_owner[e]; L.riv_ref[e] = q.riv_ref[e]; L.riv_idx[e] = q.riv_idx[e]; L.riv_exact[e] = q.riv_exact[e];
             }
-            const int np0 = h.n_peak < a.peak_cap ? h.n_peak : a.peak_cap;
-            for (int p = lane; p < np0; p += 64) { L.pval[p] = q.pval[p]; L.pidx[p] = q.pidx[p]; }
+            LiteSource lr = ls;
+            lr.rec_pval = q.pval; lr.rec_pidx = q.pidx; lr.rec_np = h.n_peak < a.peak_cap ? h.n_peak : a.peak_cap;
             wave_sync();
-            wave_finish_row<true>(a, L, lane, r, j, clip, a.delta, h.n_peak, h.n_near, h.n_rival, h.n_unl, &ls, &missing, &unchanged);
+            wave_finish_row<true>(a, L, lane, r, j, clip, a.delta, h.n_peak, h.n_near, h.n_rival, h.n_unl, &lr, &missing, &unchanged);
         }
         if (h.type == 2 || (unchanged && !missing && h.n_band > 0)) {
             // the recorded band of the cut: its close members get level-2 values, the band is ranked again
@@ -845,15 +866,9 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
             };
             auto out_index = [&](int i) -> int { return a.mode == 0 ? i : (int)elem_frame(i); };
             const int64_t self_frame = j - a.shift;
-            auto level2 = [&](int64_t fr) -> double {
-                const unsigned int* g = ls.u64_gen + (int64_t)clip * ls.gen_clip_stride;
-                if (g[fr] != ls.gen || g[self_frame] != ls.gen) { missing = true; return 0.0; }
-                const double* base = ls.u64 + (int64_t)clip * ls.u64_clip_stride;
-                return dot_rows_f64(base + self_frame * (int64_t)ls.FS, base + fr * (int64_t)ls.FS, ls.FS, lane);
-            };
             int* out = a.idx + r * (int64_t)a.idx_pitch;
             if (!rank_cut_band<true>(a, L, lane, h.n_band, h.n_above, out, out_index, false))
-                finish_band_level2(a, L, lane, h.n_band, h.n_above, out, out_index, elem_frame, level2, &missing);
+                finish_band_level2(a, L, lane, h.n_band, h.n_above, out, out_index, elem_frame, ls, clip, self_frame, &missing);
         }
         if (missing && lane == 0) { atomicAdd(&a.stats[14], 1u); flag_row_for_exact(a, r, clip); }
         wave_sync();
@@ -925,7 +940,7 @@ hipError_t launch_local_maxima_lite(const PeakArgs& a0, const ExactSource& src, 
     if (!a.lite_list || !wave_shape(a.n, a.d, &cap)) return hipSuccess;
     a.dl = (int)round_up(a.d, 4);
     a.peak_cap = cap;
-    LiteSource ls{src.u64, src.u64_gen, src.u64_clip_stride, src.gen_clip_stride, src.FS, a.gen};
+    LiteSource ls{src.u64, src.u64_gen, src.u64_clip_stride, src.gen_clip_stride, src.FS, a.gen, nullptr, nullptr, 0};
     const int bytes = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_lite_kernel), bytes);
     if (e != hipSuccess) return e;
