@@ -15,7 +15,7 @@ for p in (os.path.join(ROOT, "repet-python_amd"), ROOT, os.path.join(ROOT, "test
     sys.path.insert(0, p)
 
 import repet  # noqa: E402
-from repet_synth import synth  # noqa: E402
+from repet_synth import synth, synth_groove  # noqa: E402
 from oracle import repet_oracle as orc  # noqa: E402
 
 DEFAULTS = {k: getattr(repet, k) for k in ("cutoff_frequency", "period_range", "segment_length", "segment_step",
@@ -82,7 +82,8 @@ def edge_case(rs):
 
 def run_case(k, algo, fs, channels, seconds, params):
     from helpers import assert_parity_modulo_near_ties, rms_err
-    x = synth(seconds, fs, channels, 1000 + k)
+    # both clip families: the decaying-note clips and (every third case) the drum clips with a silent bar
+    x = synth_groove(seconds, fs, channels, 1000 + k) if k % 3 == 2 else synth(seconds, fs, channels, 1000 + k)
     for name, value in DEFAULTS.items():
         setattr(repet, name, params.get(name, value))
     rec = {"case": k, "algo": algo, "fs": fs, "channels": channels, "seconds": round(seconds, 2), "params": params}
@@ -116,9 +117,11 @@ def run_case(k, algo, fs, channels, seconds, params):
                 rec["ok"] = True
                 rec["ill_conditioned"] = "similarity_threshold >= 1"
             elif algo in ("sim", "simonline") and same_nan:
+                # (round 2 accepted lists that differed at proven float64 near-ties; with the second level of the peak
+                # picking the lists are the oracle's, so this is a failure -- the analysis only says where)
                 outcome = assert_parity_modulo_near_ties(algo, x, fs, params, require_strict=False)
                 rec["near_tie_rows"], rec["branch"] = int(outcome), outcome.branch
-                rec["ok"] = True
+                rec["ok"] = os.environ.get("FUZZ_ALLOW_TIES") == "1"
             else:
                 rec["ok"] = False
     except AssertionError as e:
