@@ -615,9 +615,11 @@ def test_gram_tile_sizes_give_the_same_matrix():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "repet-python_amd"), root)
     outs = []
-    for tile in ("256", "128", "256+split-in-stft"):            # the third: f16 planes written by the STFT epilogue itself
+    # the third: f16 planes written by the STFT epilogue itself; the fourth: the two-buffer K loop of round 2
+    for tile in ("256", "128", "256+split-in-stft", "256+two-buffers"):
         out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile[:3]}_{len(tile)}_{os.getpid()}.npz")
-        env = dict(os.environ, REPET_GRAM_TILE=tile[:3], REPET_SPLIT_IN_STFT="1" if "split" in tile else "0")
+        env = dict(os.environ, REPET_GRAM_TILE=tile[:3], REPET_SPLIT_IN_STFT="1" if "split" in tile else "0",
+                   REPET_GRAM_PIPE="0" if "two" in tile else "1")
         subprocess.check_call([sys.executable, "-c", code, out], env=env)
         with np.load(out) as z:
             outs.append({k: z[k] for k in z.files})
@@ -626,7 +628,8 @@ def test_gram_tile_sizes_give_the_same_matrix():
     assert np.array_equal(s, outs[1]["s"], equal_nan=True)
     assert np.array_equal(s, s.T, equal_nan=True)
     assert np.all(np.isnan(s[700])) and np.all(np.isnan(s[:, 700])) and np.isnan(s).sum() == 2 * 2300 - 1
-    assert np.array_equal(outs[0]["y"], outs[1]["y"]) and np.array_equal(outs[0]["y"], outs[2]["y"])
+    assert np.array_equal(s, outs[3]["s"], equal_nan=True)
+    assert all(np.array_equal(outs[0]["y"], o["y"]) for o in outs[1:])
 
 
 @pytest.mark.parametrize("seconds,fs,channels,number,distance", [(50, 44100, 2, 100, 1.0), (110, 22050, 1, 100, 0.3),

@@ -1,6 +1,6 @@
 import ctypes, sys, os, numpy as np
 sys.path[:0] = ["repet-python_amd", "."]
-os.environ["REPET_HIP_LIB"] = os.path.abspath("build_diag/lib_stamps.so")
+os.environ["REPET_HIP_LIB"] = os.path.abspath(os.environ.get("STAMPS_LIB", "build_diag/lib_stamps.so"))
 import repet
 from repet_synth import synth
 algo = os.environ.get("PEAK_ALGO", "sim")                     # sim (180 s) or simonline (30 s): the two users of the peak kernel
