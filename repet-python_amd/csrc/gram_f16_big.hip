@@ -238,6 +238,9 @@ __global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __res
 }
 
 // The rescheduled form (see the head of the file). Two waves per SIMD at 250 VGPRs: accumulators 128, two fragment sets 96.
+// MODE bit 0: the DMA pieces ride between the MFMAs (else: in one block behind the first MFMA of the half tile);
+// bit 1: so do the fragment reads (else: in one block behind the eighth MFMA).
+template <int MODE>
 __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
                                                            float* __restrict__ out, int64_t pitch,
                                                            const int2* __restrict__ tiles) {
@@ -315,8 +318,18 @@ __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* 
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(grp == 0 ? f.al[m] : f.ah[m], grp == 1 ? f.bl[n] : f.bh[n],
                                                                 acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (i < 12) load_frag(g_kt, g_ks, g, i);
-            if (i % 3 == 1 && dma) issue_piece(dma_kt, i / 3);           // (wave-uniform)
+            if constexpr (MODE & 2) {
+                if (i < 12) load_frag(g_kt, g_ks, g, i);
+            } else if (i == 7) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) load_frag(g_kt, g_ks, g, q);
+            }
+            if constexpr (MODE & 1) {
+                if (i % 3 == 1 && dma) issue_piece(dma_kt, i / 3);       // (wave-uniform)
+            } else if (i == 0 && dma) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) issue_piece(dma_kt, j);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -466,14 +479,18 @@ hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, f
                                     const int2* tiles, int32_t n_tiles, hipStream_t s) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
     // REPET_GRAM_PIPE=0: the two-buffer kernel with 32-component K-tiles (round 2)
-    static const bool pipe = [] { const char* e = getenv("REPET_GRAM_PIPE"); return !(e && e[0] == '0'); }();
-    if (pipe && (FS % 16) == 0) {
-        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_big_pipe_kernel), kBigLds);
+    static const int pipe = [] { const char* e = getenv("REPET_GRAM_PIPE"); return e ? atoi(e) : 1; }();
+    auto launch_pipe = [&](auto kernel) -> hipError_t {
+        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), kBigLds);
         if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(gram_f16_big_pipe_kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
+        hipLaunchKernelGGL(kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
                            reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles);
         return hipGetLastError();
-    }
+    };
+    if (pipe == 1) return launch_pipe(&gram_f16_big_pipe_kernel<3>);
+    if (pipe == 2) return launch_pipe(&gram_f16_big_pipe_kernel<2>);       // fragments spread, DMA in a block
+    if (pipe == 3) return launch_pipe(&gram_f16_big_pipe_kernel<1>);       // DMA spread, fragments in a block
+    if (pipe == 4) return launch_pipe(&gram_f16_big_pipe_kernel<0>);       // both in blocks (second register set only)
     hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_big_kernel), kBigLds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(gram_f16_big_kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,

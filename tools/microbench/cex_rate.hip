@@ -73,6 +73,41 @@ KERNEL(ds_swizzle, asm volatile(
     "ds_swizzle_b32 %6, %6 offset:swizzle(BITMASK_PERM, \"0000p\")\n ds_swizzle_b32 %7, %7 offset:swizzle(BITMASK_PERM, \"0000p\")\n"
     "s_waitcnt lgkmcnt(0)\n" IO);)
 
+// round 3: is any packed 16-bit integer op in the fast (add / and / mov) class? A comparator as saturating subtract +
+// subtract + add (d = sat(a - b); min = a - d; max = b + d) would take 3 x 2.3 cycles against 2 x 4.3 for min + max.
+#define E8C(OP) OP " %0, %0, %8 clamp\n" OP " %1, %1, %8 clamp\n" OP " %2, %2, %8 clamp\n" OP " %3, %3, %8 clamp\n" OP " %4, %4, %8 clamp\n" OP " %5, %5, %8 clamp\n" OP " %6, %6, %8 clamp\n" OP " %7, %7, %8 clamp\n"
+KERNEL(pk_add_u16, asm volatile(E8("v_pk_add_u16") IO);)
+KERNEL(pk_sub_u16, asm volatile(E8("v_pk_sub_u16") IO);)
+KERNEL(pk_sub_u16_clamp, asm volatile(E8C("v_pk_sub_u16") IO);)
+KERNEL(pk_sub_i16, asm volatile(E8("v_pk_sub_i16") IO);)
+KERNEL(pk_add_f16, asm volatile(E8("v_pk_add_f16") IO);)
+KERNEL(pk_mul_f16, asm volatile(E8("v_pk_mul_f16") IO);)
+KERNEL(pk_fma_f16, asm volatile(E8_3("v_pk_fma_f16") IO);)
+KERNEL(pk_mul_lo_u16, asm volatile(E8("v_pk_mul_lo_u16") IO);)
+KERNEL(pk_mad_u16, asm volatile(E8_3("v_pk_mad_u16") IO);)
+KERNEL(pk_lshlrev_b16, asm volatile(E8("v_pk_lshlrev_b16") IO);)
+KERNEL(add_u16, asm volatile(E8("v_add_u16") IO);)
+KERNEL(sub_u32_clamp, asm volatile(E8C("v_sub_u32") IO);)
+KERNEL(add3_u32, asm volatile(E8_3("v_add3_u32") IO);)
+KERNEL(and_or_b32, asm volatile(E8_3("v_and_or_b32") IO);)
+KERNEL(or3_b32, asm volatile(E8_3("v_or3_b32") IO);)
+KERNEL(xad_u32, asm volatile(E8_3("v_xad_u32") IO);)
+KERNEL(lshl_add_u32, asm volatile(E8_3("v_lshl_add_u32") IO);)
+KERNEL(mad_u32_u24, asm volatile(E8_3("v_mad_u32_u24") IO);)
+KERNEL(mul_u32_u24, asm volatile(E8("v_mul_u32_u24") IO);)
+KERNEL(sad_u32, asm volatile(E8_3("v_sad_u32") IO);)
+KERNEL(sad_u16, asm volatile(E8_3("v_sad_u16") IO);)
+KERNEL(cex_satsub_pk, asm volatile(
+    "v_pk_sub_u16 %8, %0, %1 clamp\n v_pk_sub_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n"
+    "v_pk_sub_u16 %9, %2, %3 clamp\n v_pk_sub_u16 %2, %2, %9\n v_pk_add_u16 %3, %3, %9\n"
+    "v_pk_sub_u16 %8, %4, %5 clamp\n v_pk_sub_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n"
+    "v_pk_sub_u16 %9, %6, %7 clamp\n v_pk_sub_u16 %6, %6, %9\n v_pk_add_u16 %7, %7, %9\n" IO);)
+KERNEL(cex_satsub_u32, asm volatile(
+    "v_sub_u32 %8, %0, %1 clamp\n v_sub_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n"
+    "v_sub_u32 %9, %2, %3 clamp\n v_sub_u32 %2, %2, %9\n v_add_u32 %3, %3, %9\n"
+    "v_sub_u32 %8, %4, %5 clamp\n v_sub_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n"
+    "v_sub_u32 %9, %6, %7 clamp\n v_sub_u32 %6, %6, %9\n v_add_u32 %7, %7, %9\n" IO);)
+
 template <class K> void run(const char* name, K kern, unsigned* d, int per_iter, int units, const char* unit_name) {
     const int iters = 2000, blocks = 256 * 4;   // 512 threads = 8 waves; 4 blocks/CU -> 8 waves/SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -103,5 +138,18 @@ int main() {
     run("v_min_u32 dpp", k_min_u32_dpp, d, 64, 0, ""); run("v_mov_b32 dpp", k_mov_dpp, d, 64, 0, "");
     run("v_permlane32_swap", k_permlane32_swap, d, 64, 0, ""); run("v_permlane16_swap", k_permlane16_swap, d, 64, 0, "");
     run("ds_swizzle_b32", k_ds_swizzle, d, 64 + 8, 0, "");
+    printf("# round 3: packed 16-bit integer classes and the saturating-subtract comparator\n");
+    run("v_pk_add_u16", k_pk_add_u16, d, 64, 0, ""); run("v_pk_sub_u16", k_pk_sub_u16, d, 64, 0, "");
+    run("v_pk_sub_u16 clamp", k_pk_sub_u16_clamp, d, 64, 0, ""); run("v_pk_sub_i16", k_pk_sub_i16, d, 64, 0, "");
+    run("v_pk_add_f16", k_pk_add_f16, d, 64, 0, ""); run("v_pk_mul_f16", k_pk_mul_f16, d, 64, 0, "");
+    run("v_pk_fma_f16", k_pk_fma_f16, d, 64, 0, ""); run("v_pk_mul_lo_u16", k_pk_mul_lo_u16, d, 64, 0, "");
+    run("v_pk_mad_u16", k_pk_mad_u16, d, 64, 0, ""); run("v_pk_lshlrev_b16", k_pk_lshlrev_b16, d, 64, 0, "");
+    run("v_add_u16", k_add_u16, d, 64, 0, ""); run("v_sub_u32 clamp", k_sub_u32_clamp, d, 64, 0, "");
+    run("v_add3_u32", k_add3_u32, d, 64, 0, ""); run("v_and_or_b32", k_and_or_b32, d, 64, 0, "");
+    run("v_or3_b32", k_or3_b32, d, 64, 0, ""); run("v_xad_u32", k_xad_u32, d, 64, 0, "");
+    run("v_lshl_add_u32", k_lshl_add_u32, d, 64, 0, ""); run("v_mad_u32_u24", k_mad_u32_u24, d, 64, 0, "");
+    run("v_mul_u32_u24", k_mul_u32_u24, d, 64, 0, ""); run("v_sad_u32", k_sad_u32, d, 64, 0, ""); run("v_sad_u16", k_sad_u16, d, 64, 0, "");
+    run("cex satsub pk_u16", k_cex_satsub_pk, d, 8 * 12, 8 * 4, "comparator (two 16-bit values)");
+    run("cex satsub u32", k_cex_satsub_u32, d, 8 * 12, 8 * 4, "comparator");
     return 0;
 }

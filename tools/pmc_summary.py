@@ -12,7 +12,7 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"].split("(")[0].replace("void ", "")
         if name.startswith("_ZN5repet"):                      # not demangled (anonymous namespace): keep the readable part
-            for key in ("gram_f16_big_kernel", "gram_f16_kernel", "split_f16_rows_kernel", "split_f16_kernel", "stft_reg_kernel", "istft_ola_reg_kernel"):
+            for key in ("gram_f16_big_pipe_kernel", "gram_f16_big_kernel", "gram_f16_kernel", "split_f16_rows_kernel", "split_f16_kernel", "stft_reg_kernel", "istft_ola_reg_kernel"):
                 if key in name:
                     name = "repet::" + key
                     break

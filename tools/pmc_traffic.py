@@ -19,7 +19,7 @@ KERNELS = [
     ("stft_pair_kernel", "stft", 1, "4-8 B/lane"), ("stft_kernel", "stft", 1, "4-8 B/lane"),
     ("stft_reg_kernel", "stft", 2, "16 B/lane: one float4 per lane and point"),
     ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("split_f16_rows_kernel", "similarity_gemm", 2, "16 B/lane"),
-    ("gram_f16_big_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
+    ("gram_f16_big_pipe_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_big_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("local_maxima_wave_kernel", "local_maxima", 2, "16 B/lane"), ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
     ("columns_from_rows_kernel", "rank_columns", 1, "4 B/lane"), ("rank_columns_kernel", "rank_columns", 2, "16 B/lane"),
@@ -28,7 +28,7 @@ KERNELS = [
     ("mask_sim_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("istft_ola_reg_kernel", "istft_ola", 2, "16 B/lane spectrum loads"), ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
     # the second level of the peak picking (inside the peak-picking stage)
-    ("unit_rows_f64_kernel", "local_maxima", 1, "4-16 B/lane"), ("local_maxima_lite_kernel", "local_maxima", 2, "16 B/lane"),
+    ("unit_rows_f64_wg_kernel", "local_maxima", 1, "4-16 B/lane"), ("unit_rows_f64_kernel", "local_maxima", 1, "4-16 B/lane"), ("local_maxima_lite_kernel", "local_maxima", 2, "16 B/lane"),
     ("local_maxima_exact_kernel", "local_maxima", 1, "4 B/lane"),
 ]
 # compulsory bytes of the streaming stages at cfg 2 (N = 7 938 000, C = 2, T = 7 753, F = 1 025, K = 99.85): a
