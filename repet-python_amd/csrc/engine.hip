@@ -391,12 +391,14 @@ Geo make_geo(int W, int H, int64_t T, int C) {
 }
 
 // B: number of equal-geometry clips handled together (segments of `extended`); buffers are [B][C][rows][FS]
-// REPET_SPLIT_IN_STFT=1: the STFT epilogue writes the f16 planes of the unit rows itself instead of a separate pass over
-// Vn. Measured at cfg 2: the split pass disappears (-0.011 ms) and the STFT grows by as much (+0.012 ms: two 2-byte
-// stores per component from a thread that owns every 256th bin) -- no gain, so the separate pass stays the default.
-bool split_in_stft() {
-    static const bool on = [] { const char* e = getenv("REPET_SPLIT_IN_STFT"); return e && e[0] == '1'; }();
-    return on && gram_f16_enabled();
+// The STFT epilogue can write the f16 planes of the unit rows itself instead of a separate pass over Vn. Measured at cfg 2
+// (one clip): the split pass disappears (-0.011 ms) and the STFT grows by as much (+0.012 ms: two 2-byte stores per
+// component from a thread that owns every 256th bin) -- no gain. Measured at cfg 5 (64 clips of 30 s): the split pass is
+// 0.136 ms there, the STFT grows by 0.065: step 2.54 -> 2.47 ms. So: batches yes, single clips no; REPET_SPLIT_IN_STFT=1 / 0
+// force it either way.
+bool split_in_stft(int B) {
+    static const int forced = [] { const char* e = getenv("REPET_SPLIT_IN_STFT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    return (forced >= 0 ? forced == 1 : B > 1) && gram_f16_enabled();
 }
 
 // The mask kernels read V, read X and write X: 20 bytes per cell, and the inverse STFT reads X again. With the mask as a
@@ -436,7 +438,7 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
                                  (int64_t)(g.Tpad - g.T) * g.FS, B, c->refine_stats.as<unsigned int>()));
     c->refine_stats_cleared = true;
     if (want_vn) {
-        if (split_in_stft()) {
+        if (split_in_stft(B)) {
             // the f16 planes of the unit rows, written by the STFT beside Vn (same bytes per row: 2 planes x 2 bytes);
             // the big-tile Gram kernel reads (and ignores) up to round_up(T, 256) rows of a single clip
             HIP_TRY(c->Vh.ensure((B == 1 ? (size_t)round_up(g.T, 256) * g.FS : B * mean_elems) * sizeof(float)));
@@ -462,7 +464,7 @@ int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64
     a.X = c->X.as<float2>(); a.V = c->V.as<float>(); a.chan_stride = g.chan_stride;
     a.Vm = nullptr; a.Vn = vn ? c->Vn.as<float>() : nullptr; a.P = (p && !p_as_planes) ? c->P.as<float>() : nullptr;
     if (p_as_planes) { a.Ph = c->Vh.p; a.Ph_inv = c->amax.as<float>(); a.batch_inv_stride = g.Tpad; }
-    a.Vh = (vn && split_in_stft()) ? c->Vh.p : nullptr;
+    a.Vh = (vn && split_in_stft(B)) ? c->Vh.p : nullptr;
     a.n_batch = B; a.batch_sample_stride = batch_sample_stride; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
     a.batch_mean_stride = g.Tpad * g.FS;
     HIP_TRY(launch_stft(a, c->stream));
@@ -935,7 +937,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft()));
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft(1)));
     {
         // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
         // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
@@ -1060,7 +1062,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int LP = (int)round_up(B, 64);
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP, spec_stride = (int64_t)g.C * g.chan_stride;
     HIP_TRY(c->band.ensure((size_t)nb * band_stride * sizeof(float)));
-    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride, split_in_stft()));
+    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride, split_in_stft(nb)));
     mark(c, c->band_on_f16 ? "similarity_band_f16x3" : "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;

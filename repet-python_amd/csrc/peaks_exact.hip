@@ -411,13 +411,13 @@ __device__ __forceinline__ void unit_row_variant(const ExactSource& src, int log
 
 // Which transform a launch carries and what it needs of the LDS.
 struct FftPlan { int variant, tw_count, wave_bytes, fixed_bytes; };
-static FftPlan fft_plan(int W) {
+static FftPlan fft_plan(int W, bool allow_reg = true) {
     // W = 2048: the register transform (62 us per stereo frame alone; REPET_EXACT_FFT=lds: the radix-4 LDS transform, 80 us alone
     // with a third of the registers -- beside the column sort both take 130 us, so the smaller footprint buys nothing)
     static const bool want_lds = [] { const char* e = getenv("REPET_EXACT_FFT"); return e && e[0] == 'l'; }();
     const int Mh = W / 2;
     FftPlan p{};
-    if (W == 2048 && !want_lds) {
+    if (W == 2048 && !want_lds && allow_reg) {
         p.variant = kFftReg; p.tw_count = 0; p.wave_bytes = f64fft::kExPitch * (int)sizeof(double2);
         p.fixed_bytes = f64fft::kTwCount * (int)sizeof(double2);
     } else if (W <= 2048) {
@@ -1063,8 +1063,10 @@ hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_col
     x.scratch_per_wg = total / grid;
     // LDS: the stage twiddles, then one region that holds up to four transforms side by side (one per wavefront) and, before
     // them, the two window-maximum buffers of the scan. 76 KB leaves room for two workgroups per CU.
-    const FftPlan plan = fft_plan(src.W);
-    x.reg_fft = plan.variant == kFftReg; x.tw_count = plan.tw_count; x.wave_bytes = plan.wave_bytes;
+    // (never the register transform here: beside the row's own state it needs 31 registers more than a wave can have, and
+    // the transforms of this kernel are the rare ones)
+    const FftPlan plan = fft_plan(src.W, false);
+    x.reg_fft = 0; x.tw_count = plan.tw_count; x.wave_bytes = plan.wave_bytes;
     const int small = 76 * 1024, large = 150 * 1024;
     const int fixed = plan.fixed_bytes;
     int waves = 4;
@@ -1082,7 +1084,6 @@ hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_col
         hipLaunchKernelGGL(local_maxima_exact_kernel<V>, dim3((unsigned)grid), dim3(kExactThreads), lds, s, x);
         return hipGetLastError();
     };
-    if (plan.variant == kFftReg) return go(std::integral_constant<int, kFftReg>{});
     if (plan.variant == kFftLds4) return go(std::integral_constant<int, kFftLds4>{});
     return go(std::integral_constant<int, kFftLdsAcc>{});
 }
