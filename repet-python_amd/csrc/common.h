@@ -133,6 +133,12 @@ struct IstftOlaArgs {
     // (nullable) the soft mask as a plane of its own, laid out like V (element strides of Y): the spectrum is multiplied
     // by it as it is fetched, so the mask kernels write 4 bytes per cell instead of reading and rewriting 8 + 8
     const float* M;
+    // (nullable, original / extended on the register kernels) instead of M: the magnitudes V (laid out like Y), the
+    // repeating-segment model of every clip of the batch, model[clip][channel][q < period][FS], and the clips' periods
+    // (device array, batch-local index): the mask of frame t is soft_mask(V, model[t mod period]) -- what mask_period_kernel
+    // would have written into M, computed where it is used, so that kernel only writes the model (a third of a plane or
+    // less) and never reads V a second time
+    const float* Vmag; const float* model; const int32_t* periods; int64_t model_batch_stride, model_chan_stride; int32_t cutoff;
     // channel groups (launch_istft_ola splits a clip with more channels than one workgroup's LDS holds): this launch writes
     // channels [out_chan0, out_chan0 + n_channels) of an output interleaved over out_channels (0: n_channels, from 0)
     int32_t out_channels, out_chan0;
@@ -142,6 +148,8 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a, hipStream_t s);
 bool reg_fft_supported(int W, int n_channels, bool inverse);
 hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s);
 hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t s);
+// true when launch_istft_ola will take the register kernel for these arguments (the only one that applies a model itself)
+bool istft_reg_takes(const IstftOlaArgs& a);
 
 // Overlap-add of frames[c][t][W] at hop H into out[n][C] (interleaved), out sample n takes padded
 // position n + trim; multiplied by `scale` (1/sum(window[0:W:H])).
@@ -271,9 +279,19 @@ hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_col
 
 // K5/K8/K8b: gather-median masks. V[c][t][FS] -> (optional) mask[c][t][FS]; if X != null it is
 // multiplied in place by the mask after the high-pass override mask[1..cutoff] = 1 (repet.py:185).
+// The soft mask of one bin (repet.py:1446 and the high-pass rule :1449-1451): shared by the mask kernels and by the inverse
+// STFT that applies a repeating-segment model itself, so both give the same bits.
+__device__ __forceinline__ float soft_mask(float v, float model, int f, int cutoff) {
+    const float m = (fminf(v, model) + kMaskEps) / (v + kMaskEps);
+    // fminf drops a NaN model; np.minimum propagates it (empty similarity list -> NaN frame)
+    const float mm = (model != model) ? model : m;
+    return (f >= 1 && f <= cutoff) ? 1.0f : mm;
+}
+
 struct MaskArgs {
     const float* V; int64_t chan_stride; int32_t n_channels; int64_t T; int32_t F, FS;
     float2* X; float* mask; int32_t cutoff;
+    float* model; int64_t model_batch_stride, model_chan_stride;   // mask_period only (nullable): write the medians [clip][channel][q][FS] and nothing else
     int64_t pad_row;   // rows pad_row / pad_row+1 of every channel of V hold -1.0f / +inf (median pads)
     int32_t n_batch; int64_t batch_stride;   // mask_period / mask_sim: blockIdx.z = clip, elements between clips in V and X
     int64_t idx_batch_stride, cnt_batch_stride;   // mask_sim: elements between the clips' index lists / list lengths

@@ -107,6 +107,8 @@ struct repet_ctx {
     int64_t win_total = 0, win_offset = 0;
     bool win_skip_clear = false;  // exec_extended cleared `out` itself (window mode)
     DevBuf Mk;                    // the soft mask as a plane of its own (laid out like V), when the inverse STFT applies it
+    DevBuf Wm;                    // original / extended: the repeating-segment models [clip][channel][q][FS] when the inverse STFT applies THEM
+    bool mask_model = false;      // this pipeline's inverse STFT computes the mask from V and Wm (run_original)
     bool mask_plane = false;      // the pipeline being enqueued keeps the mask apart instead of multiplying X in place
     bool ola_first_batch = false; // run_original: the first batch of equal segments of an `extended` run (class 0 may store)
     int32_t last_fs = 0;          // sampling frequency of the resident clip when it came from a WAVE file (for repet_ctx_result_wav)
@@ -426,7 +428,7 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     if (g.W > 4096) c->mask_plane = false;       // the 8192-sample inverse kernel has no registers to spare for the mask
     HIP_TRY(c->X.ensure((size_t)B * g.C * g.chan_stride * sizeof(float2)));
     HIP_TRY(c->V.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
-    if (c->mask_plane) HIP_TRY(c->Mk.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
+    if (c->mask_plane && !c->mask_model) HIP_TRY(c->Mk.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
     if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
     const size_t mean_elems = (size_t)g.Tpad * g.FS;
     if (want_vn) HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
@@ -483,13 +485,22 @@ MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
 }
 
 // masked spectrum -> inverse FFT + overlap-add (one fused kernel) -> c->out
+// the repeating-segment models of a batch for the inverse STFT (IstftOlaArgs::model)
+struct ModelRef { const float* model; const int32_t* periods; int64_t batch_stride, chan_stride; int32_t cutoff; };
+void apply_model(IstftOlaArgs& a, repet_ctx* c, const ModelRef* mr) {
+    if (!mr) return;
+    a.M = nullptr; a.Vmag = c->V.as<float>(); a.model = mr->model; a.periods = mr->periods;
+    a.model_batch_stride = mr->batch_stride; a.model_chan_stride = mr->chan_stride; a.cutoff = mr->cutoff;
+}
+
 int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_t n_out, int64_t out_offset,
-              bool weighted, int64_t fade_in, int64_t fade_out) {
+              bool weighted, int64_t fade_in, int64_t fade_out, const ModelRef* mr = nullptr) {
     IstftOlaArgs a{};
     a.Y = c->X.as<float2>(); a.M = c->mask_plane ? c->Mk.as<float>() : nullptr; a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.W = g.W;
     a.twiddle = tb->twiddle.as<float2>(); a.trim = trim; a.out = c->out.as<float>(); a.n_out = n_out;
     a.out_offset = c->clip_base + out_offset; a.scale = (float)(1.0 / tb->cola);
     a.accumulate_weighted = weighted ? 1 : 0; a.fade_in = fade_in; a.fade_out = fade_out;
+    apply_model(a, c, mr);
     hipError_t e = launch_istft_ola(a, c->stream);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
     HIP_TRY(e);
@@ -532,7 +543,23 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     // second pass over it (extended 600 s: 0.34 -> 0.24 ms for the Gram stage). REPET_P_PLANES=0: the separate pass.
     const bool p_planes = power_planes_enabled() && gram_f16_enabled() && g.Tpad == round_up(T, kTile) && reg_fft_supported(g.W, g.C, false) &&
                           (band_rows_on_f16(c, T, g.FS, hi, B, mean_stride) || (B == 1 && T >= 2048));   // (a long single clip: as in exec_adaptive)
+    // The mask of a cell is soft_mask(V, W[frame mod period]) with W the medians over the repetitions -- [period][F] per clip
+    // and channel, a third of a plane at most. On the register inverse STFT the mask kernel writes only W and the inverse
+    // computes the mask where it multiplies it in: no mask plane written and read back, no second read of V by the mask
+    // kernel (cfg 3: mask_period 0.24 -> see DESIGN.md section 5). REPET_MASK_MODEL=0: the plane.
+    static const bool model_wanted = [] { const char* e = getenv("REPET_MASK_MODEL"); return !(e && e[0] == '0'); }();
+    const int64_t lim30 = (int64_t)1 << 30;
+    struct ModelScope { repet_ctx* c; ~ModelScope() { c->mask_model = false; } } model_scope{c};
+    c->mask_model = model_wanted && c->mask_plane && reg_fft_supported(g.W, g.C, true) &&
+                    !(weighted && (n >= lim30 || hop >= lim30 || overlap >= lim30));
+    const int model_rows = hi + 1;
+    ModelRef model_ref{};
     RP_TRY(ensure_spectra(c, g, false, !p_planes, B));
+    if (c->mask_model) {
+        HIP_TRY(c->Wm.ensure((size_t)B * g.C * model_rows * g.FS * sizeof(float)));
+        model_ref = ModelRef{c->Wm.as<float>(), period_slots, (int64_t)g.C * model_rows * g.FS, (int64_t)model_rows * g.FS, p->cutoff_bins};
+    }
+    const ModelRef* mr = c->mask_model ? &model_ref : nullptr;
     if (p_planes) RP_TRY(prepare_power_planes(c, g, T, B));
     RP_TRY(run_stft(c, g, tb, offset, n, 1, false, true, B, hop, p_planes));
     HIP_TRY(c->band.ensure((size_t)B * band_stride * sizeof(float)));
@@ -544,15 +571,17 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     mark(c, "beat_period", B * 4.0 * T * hi, 0);
     MaskArgs m = mask_args(c, g, p->cutoff_bins);
     m.n_batch = B;
+    if (mr) { m.X = nullptr; m.mask = nullptr; m.model = c->Wm.as<float>(); m.model_batch_stride = mr->batch_stride; m.model_chan_stride = mr->chan_stride; }
     HIP_TRY(launch_mask_period(m, period_slots, 0, p->period_lo + 1, c->stream));
-    mark(c, "mask_period", B * (4.0 + 4.0 + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);     // V, the gathers, the mask plane or X in place
+    if (mr) mark(c, "mask_period", B * (4.0 + 4.0 / 3) * g.F * T * g.C, 0);                        // the gathers of V, the model (a third of a plane at most)
+    else mark(c, "mask_period", B * (4.0 + 4.0 + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);     // V, the gathers, the mask plane or X in place
     if (c->pre_synthesis) {
         std::function<int()> hook;
         hook.swap(c->pre_synthesis);
         RP_TRY(hook());
     }
     if (!weighted && B == 1) {
-        RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, false, 0, 0));
+        RP_TRY(run_istft(c, g, tb, g.W - g.H, n, offset, false, 0, 0, mr));
     } else if (!weighted) {
         // independent clips of a batch context: clip b is written at offset + b*hop, no cross-fade
         IstftOlaArgs a{};
@@ -561,6 +590,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
         a.out_offset = c->clip_base + offset; a.scale = (float)(1.0 / tb->cola); a.accumulate_weighted = 0;
         a.n_batch = B; a.batch_first = 0; a.batch_step = 1; a.batch_total = B; a.batch_local0 = 0;
         a.batch_spec_stride = (int64_t)g.C * g.chan_stride; a.batch_out_stride = hop; a.overlap = 0;
+        apply_model(a, c, mr);
         hipError_t e = launch_istft_ola(a, c->stream);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
         HIP_TRY(e);
@@ -581,6 +611,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
             a.batch_total = seg_total; a.batch_local0 = k; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
             a.batch_out_stride = hop > 0 ? hop : 0; a.overlap = overlap;
             if (hop == 0) a.out_offset = c->clip_base + offset;   // single (last) segment: explicit offset, j = seg_first
+            apply_model(a, c, mr);
             hipError_t e = launch_istft_ola(a, c->stream);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
             HIP_TRY(e);
@@ -1270,7 +1301,7 @@ int repet_ctx_destroy(repet_ctx* c) {
         for (hipEvent_t e : {c->aux_start, c->aux_main_done, c->aux_done}) if (e) (void)hipEventDestroy(e);
     }
     c->ring.release();
-    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Mk, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
+    for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Mk, &c->Wm, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
                       &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
                       &c->audio_lo, &c->redo_list, &c->redo_flag, &c->u64, &c->u64_gen, &c->exact_scratch,
                       &c->lite_list, &c->lite_flag, &c->lite_records, &c->frame_list, &c->frame_flag,

@@ -119,12 +119,6 @@ __device__ __forceinline__ int pad_offset(int k, int n, int pad_row_bytes, int r
     return pad_row_bytes + ((k - n < low_pads) ? 0 : row_bytes);
 }
 
-__device__ __forceinline__ float soft_mask(float v, float model, int f, int cutoff) {
-    const float m = (fminf(v, model) + kMaskEps) / (v + kMaskEps);
-    // fminf drops a NaN model; np.minimum propagates it (empty similarity list -> NaN frame)
-    const float mm = (model != model) ? model : m;
-    return (f >= 1 && f <= cutoff) ? 1.0f : mm;
-}
 
 __device__ __forceinline__ void emit(const MaskArgs& a, int c, int64_t t, int f, float m) {
     const int64_t o = c * a.chan_stride + t * a.FS + f;
@@ -523,6 +517,7 @@ __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int*
     a.V += bz * a.batch_stride;
     if (a.X) a.X += bz * a.batch_stride;
     if (a.mask) a.mask += bz * a.batch_stride;
+    float* model_row = a.model ? a.model + bz * a.model_batch_stride + c * a.model_chan_stride + (int64_t)q * a.FS : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nfb = (a.F + 63) >> 6;
     const float* Vc = a.V + c * a.chan_stride;
@@ -545,6 +540,10 @@ __global__ __launch_bounds__(256) void mask_period_kernel(MaskArgs a, const int*
         else if (n <= 100) med = period_median<100>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
         else if (n <= 128) med = period_median<128>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
         else med = period_median<0>(n, g, base_bytes, step_bytes, pad_bytes, row_bytes);
+        if (model_row) {                 // the inverse STFT applies the model itself (IstftOlaArgs::model)
+            if (active) model_row[f] = med;
+            continue;
+        }
         // every segment's frame at this position gets the mask of the shared model: four frames per round, all their
         // loads first (a load -> multiply -> store chain per frame would pay the memory latency n times in a row)
         if (active)

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
 constexpr int kInvWaves = 12;
 constexpr int kInvLdsFloat2 = kInvWaves * kExPitch + kTwFloat2 + kRegN + 2 * 8 * 64;    // + split twiddles [N] + carry [2][8][64]
 
-template <int C, bool MASKED>      // C = 1, 2
+template <int C, int MASKED>      // C = 1, 2; MASKED: 0 no mask, 1 a mask plane M, 2 magnitudes + repeating-segment model
 __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaArgs a, int rounds) {
     constexpr int N = kRegN;          // samples per hop = complex FFT length
     extern __shared__ __attribute__((aligned(16))) float2 inv_lds[];
@@ -422,7 +422,13 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
     if (a.n_batch > 0) {
         const int j = a.batch_first + (int)blockIdx.y * a.batch_step;
         a.Y += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
-        if (MASKED) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        if (MASKED == 1) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
+        if (MASKED == 2) {
+            const int local = a.batch_local0 + (int)blockIdx.y * a.batch_step;
+            a.Vmag += (int64_t)local * a.batch_spec_stride;
+            a.model += (int64_t)local * a.model_batch_stride;
+            a.periods += local;
+        }
         a.out_offset += (int64_t)j * a.batch_out_stride;
         a.fade_in = j > 0 ? a.overlap : 0;
         a.fade_out = a.overlap;
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
     const RegTwiddles tw{tw_lds, tw_lds + 16 * 64};
     __syncthreads();
 
+    const int period = MASKED == 2 ? __builtin_amdgcn_readfirstlane(a.periods[0]) : 1;
     const int hops_per_wg = kInvWaves * rounds - 1;
     const int64_t h0 = a.first_hop + (int64_t)blockIdx.x * hops_per_wg;
     const int64_t h_last = (h0 + hops_per_wg - 1 < a.last_hop) ? h0 + hops_per_wg - 1 : a.last_hop;
@@ -460,11 +467,38 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
             float2 v[16];
             if (have) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
-                const float* Mr = MASKED ? a.M + c * a.chan_stride + t * a.FS : nullptr;
+                const float* Mr = MASKED == 1 ? a.M + c * a.chan_stride + t * a.FS
+                                  : MASKED == 2 ? a.Vmag + c * a.chan_stride + t * a.FS : nullptr;
+                // MASKED == 2: the model row of this frame's position inside its period (wave-uniform)
+                const float* Wr = MASKED == 2 ? a.model + c * a.model_chan_stride + (t % period) * a.FS : nullptr;
                 // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D. All loads of a
                 // half (of the whole transform without a mask plane) are issued before the first is consumed: in batches
                 // of four the transform waited for memory four times over
-                constexpr int kHalf = MASKED ? 8 : 16;
+                constexpr int kHalf = MASKED != 0 ? 8 : 16;
+                // MASKED == 2: the masks of the frame's 1 025 bins go through the wave's exchange region (idle until the
+                // transform's first transpose): every lane fetches the magnitude and the model of ITS bins k = lane + 64 s
+                // (and lane 0 the Nyquist bin), the first half of the spectrum is requested behind them, then the masks are
+                // computed and parked as floats in `ex`; the merge below picks mask[k] and mask[N - k] from there. Two memory
+                // round trips per transform as with a mask plane (with model and magnitude of every PAIR in flight beside the
+                // spectrum the kernel either spilled, 58 registers, or took four round trips: 0.47 -> 0.58 ms at cfg 3).
+                float* mask_lds = reinterpret_cast<float*>(ex);
+                float2 xk0[MASKED == 2 ? kHalf : 1], xc0[MASKED == 2 ? kHalf : 1];
+                if constexpr (MASKED == 2) {
+                    float mv[17], mw[17];
+#pragma unroll
+                    for (int s_ = 0; s_ < 16; ++s_) { mv[s_] = Mr[lane + 64 * s_]; mw[s_] = Wr[lane + 64 * s_]; }
+                    mv[16] = Mr[N]; mw[16] = Wr[N];                         // (every lane the same address: one request)
+#pragma unroll
+                    for (int j = 0; j < kHalf; ++j) { xk0[j] = Y[64 * j + lane]; xc0[j] = Y[N - (64 * j + lane)]; }
+#pragma unroll
+                    for (int s_ = 0; s_ < 16; ++s_) {
+                        mask_lds[lane + 64 * s_] = soft_mask(mv[s_], mw[s_], lane + 64 * s_, a.cutoff);
+                        if (s_ & 1) __builtin_amdgcn_sched_barrier(0);             // two divisions' temporaries at a time, not sixteen
+                    }
+                    if (lane == 0) mask_lds[N] = soft_mask(mv[16], mw[16], N, a.cutoff);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the region is wave-private
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int h0_ = 0; h0_ < 16; h0_ += kHalf) {
                     float2 xk[kHalf], xc[kHalf];
@@ -472,15 +506,16 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
 #pragma unroll
                     for (int j = 0; j < kHalf; ++j) {
                         const int k = 64 * (h0_ + j) + lane;
-                        xk[j] = Y[k];
-                        xc[j] = Y[N - k];
-                        if constexpr (MASKED) { mk[j] = Mr[k]; mc[j] = Mr[N - k]; }
+                        if (MASKED == 2 && h0_ == 0) { xk[j] = xk0[j]; xc[j] = xc0[j]; }
+                        else { xk[j] = Y[k]; xc[j] = Y[N - k]; }
+                        if constexpr (MASKED == 1) { mk[j] = Mr[k]; mc[j] = Mr[N - k]; }
+                        if constexpr (MASKED == 2) { mk[j] = mask_lds[k]; mc[j] = mask_lds[N - k]; }
                     }
 #pragma unroll
                     for (int j = 0; j < kHalf; ++j) {
                         const int k = 64 * (h0_ + j) + lane;
                         float2 a_ = xk[j], b_ = xc[j];
-                        if constexpr (MASKED) {
+                        if constexpr (MASKED != 0) {
                             a_ = make_float2(mul_rounded(a_.x, mk[j]), mul_rounded(a_.y, mk[j]));
                             b_ = make_float2(mul_rounded(b_.x, mc[j]), mul_rounded(b_.y, mc[j]));
                         }
@@ -493,6 +528,10 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                         v[h0_ + j] = make_float2(e.x - oy, e.y + ox);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (MASKED == 2) {                                // every lane is done with the parked masks
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 wave_fft1024<true>(v, ex, tw, lane);
@@ -638,7 +677,7 @@ hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t
     const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
     const int64_t lim = (int64_t)1 << 30;
     if (a.accumulate_weighted && (a.n_out >= lim || a.batch_out_stride >= lim || a.overlap >= lim || a.fade_in >= lim || a.fade_out >= lim))
-        return hipErrorNotSupported;                   // cross-fade positions beyond 32 bits: the block kernel
+        return a.model ? hipErrorInvalidValue : hipErrorNotSupported;      // cross-fade positions beyond 32 bits: the block kernel (which takes no model: istft_reg_takes)
     static const int cus = [] {
         int dev = 0;
         hipDeviceProp_t prop{};
@@ -659,9 +698,16 @@ hipError_t launch_istft_ola_reg(const IstftOlaArgs& a, int64_t hops, hipStream_t
         (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)dyn);
         hipLaunchKernelGGL(kernel, dim3(blocks, (unsigned)batches), dim3(64 * kInvWaves), dyn, s, a, rounds);
     };
-    if (a.n_channels == 2) { if (a.M) go(&istft_ola_reg_kernel<2, true>); else go(&istft_ola_reg_kernel<2, false>); }
-    else { if (a.M) go(&istft_ola_reg_kernel<1, true>); else go(&istft_ola_reg_kernel<1, false>); }
+    const int mode = a.model ? 2 : a.M ? 1 : 0;
+    if (a.n_channels == 2) { if (mode == 2) go(&istft_ola_reg_kernel<2, 2>); else if (mode == 1) go(&istft_ola_reg_kernel<2, 1>); else go(&istft_ola_reg_kernel<2, 0>); }
+    else { if (mode == 2) go(&istft_ola_reg_kernel<1, 2>); else if (mode == 1) go(&istft_ola_reg_kernel<1, 1>); else go(&istft_ola_reg_kernel<1, 0>); }
     return hipGetLastError();
+}
+
+bool istft_reg_takes(const IstftOlaArgs& a) {
+    const int64_t lim = (int64_t)1 << 30;
+    if (a.out_channels != 0 || !reg_fft_supported(a.W, a.n_channels, true)) return false;
+    return !(a.accumulate_weighted && (a.n_out >= lim || a.batch_out_stride >= lim || a.overlap >= lim || a.fade_in >= lim || a.fade_out >= lim));
 }
 
 }  // namespace repet

@@ -527,27 +527,32 @@ def test_fft_paths_agree():
 
 
 def test_mask_plane_gives_the_same_bits():
-    """The soft mask kept as a plane of its own and applied by the inverse STFT while it fetches the spectrum
-    (REPET_MASK_PLANE=1; default for original / extended) against the mask multiplied into the spectrum in place (=0):
-    the same rounded products either way, so every variant's output must be IDENTICAL -- batched extended segments,
-    a batch context of simonline clips and the 4-channel block-kernel path included."""
+    """Three ways to apply the soft mask, one result. (a) multiplied into the spectrum in place (REPET_MASK_PLANE=0);
+    (b) kept as a plane of its own and applied by the inverse STFT while it fetches the spectrum (REPET_MASK_PLANE=1 with
+    REPET_MASK_MODEL=0); (c) original / extended on the register inverse STFT (default): the mask kernel writes only the
+    repeating-segment model [period][F] and the inverse STFT computes soft_mask(V, model[t mod period]) itself. The same
+    rounded products every way, so every variant's output must be IDENTICAL -- batched extended segments, a batch
+    context of simonline clips, a batch context of original clips, a mono clip and the 4-channel block-kernel path included."""
     import os
     import subprocess
     import sys
     code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
             "x = synth(31, 44100, 2, 3); outs = [getattr(repet, a)(x, 44100) for a in ('original', 'extended', 'adaptive', 'sim', 'simonline')]; "
+            "m = synth(47, 44100, 1, 8); outs += [repet.original(m, 44100), repet.extended(m, 44100)]; "
             "q = synth(12, 22050, 4, 5); outs += [repet.extended(q, 22050), repet.simonline(q, 22050)]; "
             "c = repet.Context(0); c.upload_batch(np.stack([synth(13, 16000, 2, s) for s in range(3)])); c.execute('simonline', repet.derive_params(16000)); "
-            "outs.append(c.download()); np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))")
+            "outs.append(c.download()); c.execute('original', repet.derive_params(16000)); outs.append(c.download()); "
+            "np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "repet-python_amd"), root)
     outs = []
-    for plane in ("0", "1"):
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_plane_{plane}_{os.getpid()}.npy")
-        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MASK_PLANE=plane))
+    for plane, model in (("0", "1"), ("1", "0"), ("1", "1")):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_plane_{plane}{model}_{os.getpid()}.npy")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MASK_PLANE=plane, REPET_MASK_MODEL=model))
         outs.append(np.load(out))
         os.remove(out)
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    assert np.array_equal(outs[0], outs[2], equal_nan=True)
 
 
 @pytest.mark.slow
