@@ -71,6 +71,9 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
     asm volatile("" : "+v"(p));
     return p;
 }
+// |x| of a spectrum bin, with the roundings pinned (x.y^2 rounded, then one fma): the forward kernels store it as V and the
+// inverse STFT of `original` / `extended` recomputes it from X instead of reading V -- the two must agree to the bit.
+__device__ __forceinline__ float magnitude(float2 x) { return sqrtf(fmaf(x.x, x.x, mul_rounded(x.y, x.y))); }
 
 // w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; den_in / den_ov
 // are (float)(2 fade_in) and (float)(2 overlap). Same values as segment_weight: the conversions are of the same integers.
@@ -133,12 +136,12 @@ struct IstftOlaArgs {
     // (nullable) the soft mask as a plane of its own, laid out like V (element strides of Y): the spectrum is multiplied
     // by it as it is fetched, so the mask kernels write 4 bytes per cell instead of reading and rewriting 8 + 8
     const float* M;
-    // (nullable, original / extended on the register kernels) instead of M: the magnitudes V (laid out like Y), the
+    // (nullable, original / extended on the register kernels) instead of M: the
     // repeating-segment model of every clip of the batch, model[clip][channel][q < period][FS], and the clips' periods
-    // (device array, batch-local index): the mask of frame t is soft_mask(V, model[t mod period]) -- what mask_period_kernel
-    // would have written into M, computed where it is used, so that kernel only writes the model (a third of a plane or
-    // less) and never reads V a second time
-    const float* Vmag; const float* model; const int32_t* periods; int64_t model_batch_stride, model_chan_stride; int32_t cutoff;
+    // (device array, batch-local index): the mask of frame t is soft_mask(|Y|, model[t mod period]) -- what mask_period_kernel
+    // would have written into M, computed where it is used (|Y| by magnitude(), the forward kernels' own V), so that kernel
+    // only writes the model (a third of a plane or less), never reads V a second time, and the inverse reads no plane at all
+    const float* model; const int32_t* periods; int64_t model_batch_stride, model_chan_stride; int32_t cutoff;
     // channel groups (launch_istft_ola splits a clip with more channels than one workgroup's LDS holds): this launch writes
     // channels [out_chan0, out_chan0 + n_channels) of an output interleaved over out_channels (0: n_channels, from 0)
     int32_t out_channels, out_chan0;

@@ -487,9 +487,9 @@ MaskArgs mask_args(repet_ctx* c, const Geo& g, int cutoff) {
 // masked spectrum -> inverse FFT + overlap-add (one fused kernel) -> c->out
 // the repeating-segment models of a batch for the inverse STFT (IstftOlaArgs::model)
 struct ModelRef { const float* model; const int32_t* periods; int64_t batch_stride, chan_stride; int32_t cutoff; };
-void apply_model(IstftOlaArgs& a, repet_ctx* c, const ModelRef* mr) {
+void apply_model(IstftOlaArgs& a, repet_ctx*, const ModelRef* mr) {
     if (!mr) return;
-    a.M = nullptr; a.Vmag = c->V.as<float>(); a.model = mr->model; a.periods = mr->periods;
+    a.M = nullptr; a.model = mr->model; a.periods = mr->periods;
     a.model_batch_stride = mr->batch_stride; a.model_chan_stride = mr->chan_stride; a.cutoff = mr->cutoff;
 }
 
@@ -504,7 +504,7 @@ int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_
     hipError_t e = launch_istft_ola(a, c->stream);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
     HIP_TRY(e);
-    mark(c, "istft_ola", (c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n_out * g.C, 0);
+    mark(c, "istft_ola", (mr ? 8.0 + 4.0 / 3 : c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n_out * g.C, 0);      // (a model: a third of a plane at most)
     return REPET_OK;
 }
 
@@ -545,8 +545,9 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
                           (band_rows_on_f16(c, T, g.FS, hi, B, mean_stride) || (B == 1 && T >= 2048));   // (a long single clip: as in exec_adaptive)
     // The mask of a cell is soft_mask(V, W[frame mod period]) with W the medians over the repetitions -- [period][F] per clip
     // and channel, a third of a plane at most. On the register inverse STFT the mask kernel writes only W and the inverse
-    // computes the mask where it multiplies it in: no mask plane written and read back, no second read of V by the mask
-    // kernel (cfg 3: mask_period 0.24 -> see DESIGN.md section 5). REPET_MASK_MODEL=0: the plane.
+    // computes the mask where it multiplies it in, from |X| (magnitude(): the forward kernel's own V, bit for bit): no mask
+    // plane written and read back, no second read of V by the mask kernel, no read of V by the inverse. cfg 3: mask_period
+    // 0.24 -> 0.11 ms, inverse 0.48 -> 0.51, step 1.53 -> 1.42. REPET_MASK_MODEL=0: the plane.
     static const bool model_wanted = [] { const char* e = getenv("REPET_MASK_MODEL"); return !(e && e[0] == '0'); }();
     const int64_t lim30 = (int64_t)1 << 30;
     struct ModelScope { repet_ctx* c; ~ModelScope() { c->mask_model = false; } } model_scope{c};
@@ -594,7 +595,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
         hipError_t e = launch_istft_ola(a, c->stream);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
         HIP_TRY(e);
-        mark(c, "istft_ola", B * ((c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n * g.C), 0);
+        mark(c, "istft_ola", B * ((mr ? 8.0 + 4.0 / 3 : c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n * g.C), 0);
     } else {
         // segments that overlap in the output must not be accumulated concurrently: one launch per residue
         // class modulo ceil(n / hop) (2 for the default 10 s / 5 s), each class writes disjoint samples
@@ -616,7 +617,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "too many channels for the fused inverse STFT");
             HIP_TRY(e);
         }
-        mark(c, "istft_ola", B * ((c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n * g.C), 0);
+        mark(c, "istft_ola", B * ((mr ? 8.0 + 4.0 / 3 : c->mask_plane ? 12.0 : 8.0) * g.F * g.T * g.C + 4.0 * n * g.C), 0);
     }
     c->last_T = T;
     return REPET_OK;

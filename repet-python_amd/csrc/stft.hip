@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(3, 
                         const float2 d = csub(zk, zc);
                         const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
                         const float2 x = cadd(e, cmul(tw, o));
-                        const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                        const float mag = magnitude(x);
                         a.X[(c + half) * a.chan_stride + row + k] = x;
                         a.V[(c + half) * a.chan_stride + row + k] = mag;
                         acc[i] += mag;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
                     const float2 d = csub(zk, zc);
                     const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);   // (zk - zc) / (2i)
                     const float2 x = cadd(e, cmul(kTables ? tw_lds[k] : a.twiddle[k], o));
-                    const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                    const float mag = magnitude(x);
                     Xrow[k] = x;
                     Vrow[k] = mag;
                     acc[i] += mag;
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(256) void stft_wave_kernel(StftArgs a, int frames_p
                 const float2 d = csub(zk, zc);
                 const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);   // (zk - zc) / (2i)
                 const float2 x = cadd(e, cmul(tw[k], o));
-                const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                const float mag = magnitude(x);
                 Xrow[k] = x;
                 Vrow[k] = mag;
                 vrow[k] = mag;

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
                 const float2 d = csub(zk, zc);
                 const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
                 const float2 x = cadd(e, cmul(split_lds[k], o));
-                const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                const float mag = magnitude(x);
                 Xrow[k] = x;
                 Vrow[k] = mag;
                 acc[s] += mag;
@@ -425,7 +425,6 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
         if (MASKED == 1) a.M += (int64_t)(a.batch_local0 + (int)blockIdx.y * a.batch_step) * a.batch_spec_stride;
         if (MASKED == 2) {
             const int local = a.batch_local0 + (int)blockIdx.y * a.batch_step;
-            a.Vmag += (int64_t)local * a.batch_spec_stride;
             a.model += (int64_t)local * a.model_batch_stride;
             a.periods += local;
         }
@@ -467,8 +466,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
             float2 v[16];
             if (have) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
-                const float* Mr = MASKED == 1 ? a.M + c * a.chan_stride + t * a.FS
-                                  : MASKED == 2 ? a.Vmag + c * a.chan_stride + t * a.FS : nullptr;
+                const float* Mr = MASKED == 1 ? a.M + c * a.chan_stride + t * a.FS : nullptr;
                 // MASKED == 2: the model row of this frame's position inside its period (wave-uniform)
                 const float* Wr = MASKED == 2 ? a.model + c * a.model_chan_stride + (t % period) * a.FS : nullptr;
                 // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D. All loads of a
@@ -476,26 +474,28 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                 // of four the transform waited for memory four times over
                 constexpr int kHalf = MASKED != 0 ? 8 : 16;
                 // MASKED == 2: the masks of the frame's 1 025 bins go through the wave's exchange region (idle until the
-                // transform's first transpose): every lane fetches the magnitude and the model of ITS bins k = lane + 64 s
-                // (and lane 0 the Nyquist bin), the first half of the spectrum is requested behind them, then the masks are
-                // computed and parked as floats in `ex`; the merge below picks mask[k] and mask[N - k] from there. Two memory
-                // round trips per transform as with a mask plane (with model and magnitude of every PAIR in flight beside the
-                // spectrum the kernel either spilled, 58 registers, or took four round trips: 0.47 -> 0.58 ms at cfg 3).
+                // transform's first transpose). Every lane fetches the spectrum and the model of ITS bins k = lane + 64 s
+                // (and the Nyquist bin), the mirrored bins of the first half behind them, computes |X| with the forward
+                // kernel's own roundings (magnitude(): V is not read at all), the masks, and parks them as floats in `ex`;
+                // the merge picks mask[k] and mask[N - k] from there and keeps the lane's own bins in registers. Two memory
+                // round trips per transform as with a mask plane (with model and magnitude of every PAIR in flight beside
+                // the spectrum the kernel either spilled, 58 registers, or took four round trips: 0.47 -> 0.58 ms at cfg 3).
                 float* mask_lds = reinterpret_cast<float*>(ex);
-                float2 xk0[MASKED == 2 ? kHalf : 1], xc0[MASKED == 2 ? kHalf : 1];
+                float2 own[MASKED == 2 ? 16 : 1], xc0[MASKED == 2 ? kHalf : 1];
                 if constexpr (MASKED == 2) {
-                    float mv[17], mw[17];
+                    float mw[17];
 #pragma unroll
-                    for (int s_ = 0; s_ < 16; ++s_) { mv[s_] = Mr[lane + 64 * s_]; mw[s_] = Wr[lane + 64 * s_]; }
-                    mv[16] = Mr[N]; mw[16] = Wr[N];                         // (every lane the same address: one request)
+                    for (int s_ = 0; s_ < 16; ++s_) { own[s_] = Y[lane + 64 * s_]; mw[s_] = Wr[lane + 64 * s_]; }
+                    const float2 xn = Y[N];                                 // (every lane the same address: one request)
+                    mw[16] = Wr[N];
 #pragma unroll
-                    for (int j = 0; j < kHalf; ++j) { xk0[j] = Y[64 * j + lane]; xc0[j] = Y[N - (64 * j + lane)]; }
+                    for (int j = 0; j < kHalf; ++j) xc0[j] = Y[N - (64 * j + lane)];
 #pragma unroll
                     for (int s_ = 0; s_ < 16; ++s_) {
-                        mask_lds[lane + 64 * s_] = soft_mask(mv[s_], mw[s_], lane + 64 * s_, a.cutoff);
+                        mask_lds[lane + 64 * s_] = soft_mask(magnitude(own[s_]), mw[s_], lane + 64 * s_, a.cutoff);
                         if (s_ & 1) __builtin_amdgcn_sched_barrier(0);             // two divisions' temporaries at a time, not sixteen
                     }
-                    if (lane == 0) mask_lds[N] = soft_mask(mv[16], mw[16], N, a.cutoff);
+                    if (lane == 0) mask_lds[N] = soft_mask(magnitude(xn), mw[16], N, a.cutoff);  // (sqrt(x^2 + 0) = |x| exactly: the register forward kernel's fabsf)
                     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the region is wave-private
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -506,10 +506,14 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
 #pragma unroll
                     for (int j = 0; j < kHalf; ++j) {
                         const int k = 64 * (h0_ + j) + lane;
-                        if (MASKED == 2 && h0_ == 0) { xk[j] = xk0[j]; xc[j] = xc0[j]; }
-                        else { xk[j] = Y[k]; xc[j] = Y[N - k]; }
-                        if constexpr (MASKED == 1) { mk[j] = Mr[k]; mc[j] = Mr[N - k]; }
-                        if constexpr (MASKED == 2) { mk[j] = mask_lds[k]; mc[j] = mask_lds[N - k]; }
+                        if constexpr (MASKED == 2) {
+                            xk[j] = own[h0_ + j];
+                            if (h0_ == 0) xc[j] = xc0[j]; else xc[j] = Y[N - k];
+                            mk[j] = mask_lds[k]; mc[j] = mask_lds[N - k];
+                        } else {
+                            xk[j] = Y[k]; xc[j] = Y[N - k];
+                            if constexpr (MASKED == 1) { mk[j] = Mr[k]; mc[j] = Mr[N - k]; }
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < kHalf; ++j) {
