@@ -71,9 +71,16 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
     asm volatile("" : "+v"(p));
     return p;
 }
-// |x| of a spectrum bin, with the roundings pinned (x.y^2 rounded, then one fma): the forward kernels store it as V and the
-// inverse STFT of `original` / `extended` recomputes it from X instead of reading V -- the two must agree to the bit.
+// |x| of a spectrum bin, with the roundings pinned (x.y^2 rounded, one fma, then the hardware square root v_sqrt_f32, 1 ulp):
+// the forward kernels store it as V and the inverse STFT of `original` / `extended` recomputes it from X instead of
+// reading V -- the two must agree to the bit, which one instruction does by construction. sqrtf() is the correctly rounded
+// one: twenty instructions per bin (two trial roundings with compare + select, denormal scaling, class fix-up) in kernels
+// that are VALU-bound -- 340 of the 1 700 instructions of a forward transform. REPET_IEEE_SQRT (build flag): sqrtf().
+#ifdef REPET_IEEE_SQRT
 __device__ __forceinline__ float magnitude(float2 x) { return sqrtf(fmaf(x.x, x.x, mul_rounded(x.y, x.y))); }
+#else
+__device__ __forceinline__ float magnitude(float2 x) { return __builtin_amdgcn_sqrtf(fmaf(x.x, x.x, mul_rounded(x.y, x.y))); }
+#endif
 
 // w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; den_in / den_ov
 // are (float)(2 fade_in) and (float)(2 overlap). Same values as segment_weight: the conversions are of the same integers.

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             {   // k = N (Nyquist): Z[N & (N-1)] = Z[0] on both sides, W_2048^N = -1
                 const float z0x = __shfl(v[0].x, 0), z0y = __shfl(v[0].y, 0);
                 const float2 x = make_float2(z0x - z0y, 0.f);
-                const float mag = fabsf(x.x);
+                const float mag = magnitude(x);           // (not fabsf: the inverse recomputes every bin's magnitude the same way)
                 if (lane == 0) { Xrow[N] = x; Vrow[N] = mag; }
                 acc[16] += mag;
             }
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                         mask_lds[lane + 64 * s_] = soft_mask(magnitude(own[s_]), mw[s_], lane + 64 * s_, a.cutoff);
                         if (s_ & 1) __builtin_amdgcn_sched_barrier(0);             // two divisions' temporaries at a time, not sixteen
                     }
-                    if (lane == 0) mask_lds[N] = soft_mask(magnitude(xn), mw[16], N, a.cutoff);  // (sqrt(x^2 + 0) = |x| exactly: the register forward kernel's fabsf)
+                    if (lane == 0) mask_lds[N] = soft_mask(magnitude(xn), mw[16], N, a.cutoff);  // (the forward kernels' Nyquist magnitude: the same call)
                     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the region is wave-private
                     __builtin_amdgcn_wave_barrier();
                 }
