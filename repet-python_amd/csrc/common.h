@@ -292,7 +292,14 @@ hipError_t launch_local_maxima_exact(const float* M, int64_t row0, int32_t n_col
 // The soft mask of one bin (repet.py:1446 and the high-pass rule :1449-1451): shared by the mask kernels and by the inverse
 // STFT that applies a repeating-segment model itself, so both give the same bits.
 __device__ __forceinline__ float soft_mask(float v, float model, int f, int cutoff) {
+#ifdef REPET_IEEE_SQRT
     const float m = (fminf(v, model) + kMaskEps) / (v + kMaskEps);
+#else
+    // the quotient by the hardware reciprocal (1 ulp) and one product; where the model is not below the magnitude the
+    // quotient is x / x = 1 exactly in the reference, so it is 1 here too (the reciprocal alone could say 1 - 2^-24)
+    const float q = (model + kMaskEps) * __builtin_amdgcn_rcpf(v + kMaskEps);
+    const float m = (model >= v) ? 1.0f : q;
+#endif
     // fminf drops a NaN model; np.minimum propagates it (empty similarity list -> NaN frame)
     const float mm = (model != model) ? model : m;
     return (f >= 1 && f <= cutoff) ? 1.0f : mm;
