@@ -54,11 +54,13 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t s);
 // several when the step is shorter than the overlap.
 __host__ __device__ inline float segment_weight(int64_t n, int64_t fade_in, int64_t overlap, int64_t step, int later) {
     float w = 1.f;
-    if (n < fade_in) w = (float)(2 * n + 1) / (float)(2 * fade_in);
+    // (numerator times the rounded reciprocal of the denominator, as segment_weight32 below: the two agree to the bit)
+    if (n < fade_in) w = (float)(2 * n + 1) * (1.0f / (float)(2 * fade_in));
     if (overlap > 0 && step > 0) {
+        const float inv_ov = 1.0f / (float)(2 * overlap);
         for (int64_t q = 1; q <= later && q * step <= n; ++q) {
             const int64_t r = n - q * step;       // position inside later segment q
-            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) / (float)(2 * overlap);
+            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) * inv_ov;
         }
     }
     return w;
@@ -82,15 +84,17 @@ __device__ __forceinline__ float magnitude(float2 x) { return sqrtf(fmaf(x.x, x.
 __device__ __forceinline__ float magnitude(float2 x) { return __builtin_amdgcn_sqrtf(fmaf(x.x, x.x, mul_rounded(x.y, x.y))); }
 #endif
 
-// w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; den_in / den_ov
-// are (float)(2 fade_in) and (float)(2 overlap). Same values as segment_weight: the conversions are of the same integers.
-__device__ __forceinline__ float segment_weight32(int n, int fade_in, int overlap, int step, int later, float den_in, float den_ov) {
+// w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; inv_in / inv_ov
+// are 1.0f / (float)(2 fade_in) and 1.0f / (float)(2 overlap), computed once per kernel (a division per sample was 64
+// correctly rounded divisions per hop and lane in the register inverse STFT: a third of its instructions on `extended`).
+// Same values as segment_weight: the conversions are of the same integers, the reciprocals of the same floats.
+__device__ __forceinline__ float segment_weight32(int n, int fade_in, int overlap, int step, int later, float inv_in, float inv_ov) {
     float w = 1.f;
-    if (n < fade_in) w = (float)(2 * n + 1) / den_in;
+    if (n < fade_in) w = (float)(2 * n + 1) * inv_in;
     if (overlap > 0 && step > 0) {
         for (int q = 1, base = step; q <= later && base <= n; ++q, base += step) {
             const int r = n - base;
-            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) / den_ov;
+            if (r < overlap) w *= (float)(2 * (overlap - r) - 1) * inv_ov;
         }
     }
     return w;

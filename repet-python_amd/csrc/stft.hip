@@ -820,7 +820,7 @@ __global__ __launch_bounds__(kFftThreads) __attribute__((amdgpu_waves_per_eu(W <
     const int mode = a.accumulate_weighted;
     const bool narrow = a.n_out < (1 << 30) && a.seg_step < (1 << 30) && a.fade_in < (1 << 30) && a.fade_out < (1 << 30);
     const int fade_in = (int)a.fade_in, overlap = (int)a.fade_out, step = (int)a.seg_step;
-    const float den_in = (float)(2 * a.fade_in), den_ov = (float)(2 * a.fade_out);
+    const float den_in = 1.0f / (float)(2 * a.fade_in), den_ov = 1.0f / (float)(2 * a.fade_out);       // (reciprocals: segment_weight32)
     // whole float4 groups of the interleaved hop (positions inside a segment in 32 bits; otherwise element by element)
     const int CT = a.out_channels > 0 ? a.out_channels : C;   // channels the output is interleaved over (a channel group: > C)
     const int cshift = ((mode != 0 && !narrow) || CT != C) ? -1 : C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : -1;

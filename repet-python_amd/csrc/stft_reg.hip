@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
     const int mode = a.accumulate_weighted;
     // (positions inside a segment fit 32 bits here: launch_istft_ola_reg leaves longer segments to the block kernel)
     const int fade_in = (int)a.fade_in, overlap = (int)a.fade_out, step = (int)a.seg_step;
-    const float den_in = (float)(2 * a.fade_in), den_ov = (float)(2 * a.fade_out);
+    const float den_in = 1.0f / (float)(2 * a.fade_in), den_ov = 1.0f / (float)(2 * a.fade_out);       // (reciprocals: segment_weight32)
     auto weight = [&](int64_t n) -> float { return segment_weight32((int)n, fade_in, overlap, step, a.later, den_in, den_ov); };
 
     for (int r = 0; r < rounds; ++r) {
