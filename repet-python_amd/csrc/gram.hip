@@ -323,7 +323,18 @@ __global__ __launch_bounds__(256) void band_chunk_sum_kernel(const float* __rest
         const int64_t t0 = c0 + wave * (kBeatChunk / 4);
         int64_t t1 = t0 + kBeatChunk / 4;
         if (t1 > hi + 1) t1 = hi + 1;
-        for (int64_t t = t0; t < t1; ++t) sum += band[t * LP + l];
+        // sixteen rows in flight, added in row order (the order is part of the result): one load -> add chain per row was
+        // a memory round trip per row, 64 in a row (cfg 4: 22 us for 14 MB)
+        const float* p = band + t0 * LP + l;
+        int64_t t = t0;
+        for (; t + 16 <= t1; t += 16, p += 16 * (int64_t)LP) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[u * (int64_t)LP];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sum += v[u];
+        }
+        for (; t < t1; ++t, p += LP) sum += *p;
     }
     part[wave][lane] = sum;
     __syncthreads();
