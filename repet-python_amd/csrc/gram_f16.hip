@@ -26,6 +26,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace repet {
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void split_f16_rows_kernel(const float* __rest
 
 // BAND: out[t][l] = row t . row t+l for 0 <= l < n_lags (pitch = band pitch), only the tiles that touch those lags;
 // blockIdx.y = clip of a batch (strides in halves / floats).
-template <bool BAND>
+template <bool BAND, bool DMA>
 __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
                                                        float* __restrict__ out, int64_t pitch,
                                                        const int2* __restrict__ tiles, int n_lags,
@@ -122,6 +123,81 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+    if constexpr (DMA) {
+    // Round 3: the K loop of gram_f16_big.hip's rescheduled kernel on this tile. The K-tiles go global -> LDS directly
+    // (global_load_lds_dwordx4, 1-KB pieces of 16 rows x 64 bytes of one plane, the XOR swizzle applied on the per-lane
+    // SOURCE chunk): no staging registers (three sets of 32 were a third of the register file) and no ds_write_b128
+    // traffic (32 KB per K-tile at 79 B/clk was more LDS time than the fragment reads). One barrier per K-tile, in its
+    // middle; the DMA pieces of tile k+2 and the fragment reads of the next half tile ride between the MFMAs, the
+    // fragments into a second register set. Same products in the same order: bit-identical to the loop below.
+    const unsigned grow = (unsigned)(2 * FS);
+    const int prow = lane >> 2;
+    const _Float16* src_lane[8];
+    int dst_piece[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int pc = __builtin_amdgcn_readfirstlane(wave) * 8 + j;                    // 0 .. 31
+        const int operand = pc >> 4, plane = (pc >> 3) & 1, rb = pc & 7;                // 8 blocks of 16 rows
+        const int r = rb * 16 + prow;
+        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+        src_lane[j] = planes + ((operand ? b_row0 : a_row0) + r) * grow + plane * 32 + chunk * 8;
+        dst_piece[j] = operand * kOperandHalves + plane * kPlanePitch + rb * 16 * HBK;  // halves, wave-uniform
+    }
+    auto issue_piece = [&](int kt, int j) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_lane[j] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)(ldsh + (kt & 1) * 2 * kOperandHalves + dst_piece[j]), 16, 0, 0);
+    };
+    struct Frags { halfx8 ah[2], al[2], bh[2], bl[2]; };
+    auto frag = [&](const _Float16* plane_ptr, int w, int blk, int ks) -> halfx8 {
+        return *reinterpret_cast<const halfx8*>(plane_ptr + (w * 64 + blk * 32 + lr) * HBK + (((2 * ks + lh) ^ ((lr >> 2) & 3)) << 3));
+    };
+    // fragment q of 8, in the order the next half uses them
+    auto load_frag = [&](int kt, int ks, Frags& f, int q) {
+        const _Float16* base = ldsh + (kt & 1) * 2 * kOperandHalves;
+        if (q < 2) f.al[q] = frag(base + kPlanePitch, wr, q, ks);
+        else if (q < 4) f.bh[q - 2] = frag(base + kOperandHalves, wc, q - 2, ks);
+        else if (q < 6) f.ah[q - 4] = frag(base, wr, q - 4, ks);
+        else f.bl[q - 6] = frag(base + kOperandHalves + kPlanePitch, wc, q - 6, ks);
+    };
+    auto half_tile = [&](const Frags& f, Frags& g, int g_kt, int g_ks, int dma_kt, bool dma) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int grp = i >> 2, m = (i >> 1) & 1, n = i & 1;          // lo hi', hi lo', hi hi': the order of the loop below
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(grp == 0 ? f.al[m] : f.ah[m], grp == 1 ? f.bl[n] : f.bh[n],
+                                                                acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 8) load_frag(g_kt, g_ks, g, i);
+            if (dma && (i % 3) != 0) issue_piece(dma_kt, (i / 3) * 2 + (i % 3) - 1);     // (wave-uniform) pieces 0 .. 7 behind MFMAs 1, 2, 4, 5, 7, 8, 10, 11
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int nk = FS / HBK;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_piece(0, j);
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_piece(1, j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8): tile 0 has landed, tile 1 may be in flight
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    Frags fa, fb;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) load_frag(0, 0, fa, q);
+    for (int kt = 0; kt < nk; ++kt) {
+        half_tile(fa, fb, kt, 1, 0, false);
+        // every wave has read tile kt out of its buffer (its second half's fragments are in registers: lgkmcnt(0)); tile
+        // kt+1 has landed (vmcnt(0)); tile kt+2 goes into the buffer tile kt has left
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        half_tile(fb, fa, kt + 1 < nk ? kt + 1 : kt, 0, kt + 2, kt + 2 < nk);
+    }
+    __syncthreads();
+    } else {
     // staging: per operand and K-tile 128 rows x (4 hi + 4 lo chunks of 16 bytes) = one cache line per row; a thread
     // takes chunk (tid & 7) of rows (tid >> 3) + 32 j, j < 4: a wave-load covers 8 whole lines
     const int srow = tid >> 3, sch = tid & 7;
@@ -221,6 +297,8 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
 #undef F16_STORE_TILE
 #undef F16_FRAG
 #undef F16_COMPUTE
+
+    }
 
     // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
     const int64_t gi0 = a_row0 + wr * 64;
@@ -323,9 +401,18 @@ hipError_t launch_split_f16_rows(const float* src, void* planes, int64_t n_rows,
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
-    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false>), kGramF16LdsAsk);
+    static const bool dma = [] { const char* e = getenv("REPET_GRAM_DMA"); return !(e && e[0] == '0'); }();
+    if (dma) {
+        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false, true>), kGramF16LdsAsk);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL((gram_f16_kernel<false, true>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
+                           reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
+                           (const float*)nullptr, (int64_t)0);
+        return hipGetLastError();
+    }
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false, false>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gram_f16_kernel<false>, dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
+    hipLaunchKernelGGL((gram_f16_kernel<false, false>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
                        reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
                        (const float*)nullptr, (int64_t)0);
     return hipGetLastError();
@@ -335,9 +422,19 @@ hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
                                 int64_t band_batch_stride, hipStream_t s, const float* row_inv, int64_t inv_batch_stride) {
     if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
-    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true>), kGramF16LdsAsk);
+    // REPET_GRAM_DMA=0: the register-staged K loop of rounds 1-2
+    static const bool dma = [] { const char* e = getenv("REPET_GRAM_DMA"); return !(e && e[0] == '0'); }();
+    if (dma) {
+        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true, true>), kGramF16LdsAsk);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL((gram_f16_kernel<true, true>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
+                           kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
+                           plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride);
+        return hipGetLastError();
+    }
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true, false>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gram_f16_kernel<true>, dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
+    hipLaunchKernelGGL((gram_f16_kernel<true, false>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
                        kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
                        plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride);
     return hipGetLastError();
