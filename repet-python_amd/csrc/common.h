@@ -109,21 +109,25 @@ __device__ __forceinline__ float f16_row_scale(float m) {
     return ldexpf(1.f, 14 - e);
 }
 // one component x of such a row into the two f16 planes (the arithmetic of split4, gram_f16.hip)
-__device__ __forceinline__ void store_split_f16_scaled(void* planes, int64_t e, float x, float sc) {
-    _Float16* p = static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31);
+__device__ __forceinline__ void store_split_f16_scaled_at(_Float16* p, float x, float sc) {      // p: the component's hi half
     const float v = x * sc;
     const _Float16 h = (_Float16)v;
     p[0] = h;
     p[32] = (_Float16)(v - (float)h);
 }
+__device__ __forceinline__ void store_split_f16_scaled(void* planes, int64_t e, float x, float sc) {
+    store_split_f16_scaled_at(static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31), x, sc);
+}
 
 // one component of a unit row into the two f16 planes (the arithmetic of split_f16_kernel, gram_f16.hip)
-__device__ __forceinline__ void store_split_f16(void* planes, int64_t e, float x) {
-    _Float16* p = static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31);
+__device__ __forceinline__ void store_split_f16_at(_Float16* p, float x) {                          // p: the component's hi half
     const float v = x * 128.0f;
     const _Float16 h = (_Float16)v;
     p[0] = h;
     p[32] = (_Float16)(v - (float)h);
+}
+__device__ __forceinline__ void store_split_f16(void* planes, int64_t e, float x) {
+    store_split_f16_at(static_cast<_Float16*>(planes) + ((e >> 5) << 6) + (e & 31), x);
 }
 
 // K9: masked spectrum -> inverse real FFT -> time frames yf[c][t][W] (scaled by 1/W like np.fft.ifft).

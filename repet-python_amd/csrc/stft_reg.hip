@@ -355,12 +355,17 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         float* Vn = a.Vn ? a.Vn + mrow : nullptr;
         float* P = a.P ? a.P + mrow : nullptr;
         void* Vh = a.Vh ? static_cast<void*>(static_cast<_Float16*>(a.Vh) + 2 * b * a.batch_mean_stride) : nullptr;
+        // component k = lane + 64 s of a row that starts on a 32-component boundary sits at 2 row + 64 (k >> 5) + (k & 31)
+        // of the interleaved f16 planes: a per-lane base and 256 bytes per s (as immediates), instead of 64-bit shifts and
+        // masks per store (300 integer instructions per frame)
+        const int64_t plane_lane = 2 * row + ((lane >> 5) << 6) + (lane & 31);
+        _Float16* vh_lane = Vh ? static_cast<_Float16*>(Vh) + plane_lane : nullptr;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k = lane + 64 * s;
             if (Vm) Vm[k] = acc[s];
             if (Vn) Vn[k] = acc[s] / norm;
-            if (Vh) store_split_f16(Vh, row + k, acc[s] / norm);
+            if (Vh) store_split_f16_at(vh_lane + 128 * s, acc[s] / norm);
             if (P) P[k] = acc[s] * acc[s];
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -386,9 +391,10 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             const float sc = f16_row_scale(mx);
             void* Ph = static_cast<void*>(static_cast<_Float16*>(a.Ph) + 2 * b * a.batch_mean_stride);
             if (lane == 0) a.Ph_inv[b * a.batch_inv_stride + t] = 1.0f / sc;
+            _Float16* ph_lane = static_cast<_Float16*>(Ph) + plane_lane;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                store_split_f16_scaled(Ph, row + lane + 64 * s, acc[s] * acc[s], sc);
+                store_split_f16_scaled_at(ph_lane + 128 * s, acc[s] * acc[s], sc);
                 if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             if (lane == 0) store_split_f16_scaled(Ph, row + N, acc[16] * acc[16], sc);
