@@ -202,11 +202,12 @@ int gram_big_tile();
 hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                     const int2* tiles, int32_t n_tiles, hipStream_t s);
 // banded form: band[t][l] = row t . row t+l; plane_batch_stride in halves (2 * Tpad * FS); row_inv (nullable): per-row
-// inverse scales of launch_split_f16_rows, inv_batch_stride floats between clips
+// inverse scales of launch_split_f16_rows, inv_batch_stride floats between clips; lookback: band[j][l] = row j . row j-l
+// instead (the layout the peak picking of simonline reads row by row: PeakArgs::mode 2)
 hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
                                 int64_t band_batch_stride, hipStream_t s, const float* row_inv = nullptr,
-                                int64_t inv_batch_stride = 0);
+                                int64_t inv_batch_stride = 0, bool lookback = false);
 // K6/K3b: band[t][l] = A[t] . A[t+l] for 0 <= l < n_lags (band pitch LP), zero where t+l >= T.
 hipError_t launch_gram_band(const float* A, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                             const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t a_batch_stride,

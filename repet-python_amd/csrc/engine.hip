@@ -109,6 +109,7 @@ struct repet_ctx {
     DevBuf Mk;                    // the soft mask as a plane of its own (laid out like V), when the inverse STFT applies it
     DevBuf Wm;                    // original / extended: the repeating-segment models [clip][channel][q][FS] when the inverse STFT applies THEM
     bool mask_model = false;      // this pipeline's inverse STFT computes the mask from V and Wm (run_original)
+    bool band_lookback = false;   // the last run_gram_band wrote band[j][l] = sim(j, j - l) (simonline on the f16-split kernel)
     bool mask_plane = false;      // the pipeline being enqueued keeps the mask apart instead of multiplying X in place
     bool ola_first_batch = false; // run_original: the first batch of equal segments of an `extended` run (class 0 may store)
     int32_t last_fs = 0;          // sampling frequency of the resident clip when it came from a WAVE file (for repet_ctx_result_wav)
@@ -301,8 +302,10 @@ bool band_rows_on_f16(repet_ctx* c, int64_t T, int FS, int n_lags, int B, int64_
     return scaled && gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS);
 }
 
+// lookback (simonline): ask for band[j][l] = row j . row j - l; granted on the f16-split kernel only (c->band_lookback says so)
 int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, int n_lags, int LP, bool unit_rows = false,
-                  int B = 1, int64_t a_stride = 0, int64_t band_stride = 0, bool planes_ready = false) {
+                  int B = 1, int64_t a_stride = 0, int64_t band_stride = 0, bool planes_ready = false, bool lookback = false) {
+    c->band_lookback = false;
     const int2* tiles; int n;
     RP_TRY(get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n));
     // power spectra (beat spectrum): any range, so the split is scaled by the matrix's largest magnitude. Two extra
@@ -332,7 +335,10 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
             HIP_TRY(c->Vh.ensure((size_t)count * 4));
             HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
         }
-        HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream));
+        static const bool lookback_ok = [] { const char* e = getenv("REPET_BAND_LOOKBACK"); return !(e && e[0] == '0'); }();
+        c->band_lookback = lookback && lookback_ok;
+        HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream, nullptr, 0,
+                                     c->band_lookback));
         return REPET_OK;
     }
     HIP_TRY(launch_gram_band(A, T, FS, band, n_lags, LP, tiles, n, B, a_stride, band_stride, c->stream));
@@ -1094,7 +1100,8 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     const int LP = (int)round_up(B, 64);
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP, spec_stride = (int64_t)g.C * g.chan_stride;
     HIP_TRY(c->band.ensure((size_t)nb * band_stride * sizeof(float)));
-    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride, split_in_stft(nb)));
+    RP_TRY(run_gram_band(c, c->Vn.as<float>(), T, g.FS, c->band.as<float>(), B, LP, true, nb, mean_stride, band_stride, split_in_stft(nb), true));
+    const int peak_mode = c->band_lookback ? 2 : 1;
     mark(c, c->band_on_f16 ? "similarity_band_f16x3" : "similarity_band", nb * (4.0 * g.F * T + 4.0 * T * B), nb * 2.0 * g.F * (double)T * B);
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     const int64_t rows = T >= B ? T - B + 1 : 0;
@@ -1104,13 +1111,13 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
     PeakRefine rf{};
     RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf, rows, nb, B, p->sim_distance_frames, T));
     const PeakBatch pb{nb, band_stride, rows_alloc * KP, rows_alloc, mean_stride};
-    hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, 1, (float)p->sim_threshold,
+    hipError_t e = launch_local_maxima(c->band.as<float>(), rows, B - 1, B, LP, peak_mode, (float)p->sim_threshold,
                                        p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf,
                                        nb > 1 ? &pb : nullptr);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "simonline: buffer too long for the peak-picking kernel");
     HIP_TRY(e);
     if (rows > 0)
-        RP_TRY(run_exact_rows(c, tb, g, c->band.as<float>(), B - 1, B, LP, 1, (float)p->sim_threshold, p->sim_distance_frames, K,
+        RP_TRY(run_exact_rows(c, tb, g, c->band.as<float>(), B - 1, B, LP, peak_mode, (float)p->sim_threshold, p->sim_distance_frames, K,
                               c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, rf, nb > 1 ? &pb : nullptr,
                               c->audio.as<float>() + c->clip_base * g.C, c->has_lo ? c->audio_lo.as<float>() + c->clip_base * g.C : nullptr,
                               N, N * g.C, 0, T, nb));
@@ -2439,12 +2446,13 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
         const int K = o->p.sim_number, KP = std::max(K, kMinIdxPitch);
         if (n_active > 0) {
             HIP_TRY(o->band.ensure((size_t)Tpad * o->LP * sizeof(float)));
-            RP_TRY(run_gram_band(c, Vnb, Tw, o->FS, o->band.as<float>(), o->B, o->LP, true));
+            RP_TRY(run_gram_band(c, Vnb, Tw, o->FS, o->band.as<float>(), o->B, o->LP, true, 1, 0, 0, false, true));
+            const int peak_mode = c->band_lookback ? 2 : 1;
             HIP_TRY(c->idx.ensure((size_t)n_active * KP * sizeof(int32_t)));
             HIP_TRY(c->cnt.ensure((size_t)n_active * sizeof(int32_t)));
             PeakRefine rf{};
             RP_TRY(make_refine(c, Vnb, o->FS, o->p.sim_threshold, &rf, n_active, 1, o->B, o->p.sim_distance_frames, Tpad));
-            hipError_t e = launch_local_maxima(o->band.as<float>(), n_active, first_active, o->B, o->LP, 1, (float)o->p.sim_threshold,
+            hipError_t e = launch_local_maxima(o->band.as<float>(), n_active, first_active, o->B, o->LP, peak_mode, (float)o->p.sim_threshold,
                                                o->p.sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream,
                                                first_global, &rf);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "online: buffer too long for the peak-picking kernel");
@@ -2452,7 +2460,7 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
             // second level: window row fr is global frame first_global + fr, whose first sample sits hist_valid - fr hops
             // before the pending ones in the buffer (zero beyond what has been pushed, as in the offline run's last frame)
             const Geo go = make_geo(o->W, o->H, Tw, o->C);
-            RP_TRY(run_exact_rows(c, tb, go, o->band.as<float>(), first_active, o->B, o->LP, 1, (float)o->p.sim_threshold,
+            RP_TRY(run_exact_rows(c, tb, go, o->band.as<float>(), first_active, o->B, o->LP, peak_mode, (float)o->p.sim_threshold,
                                   o->p.sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), first_global, rf, nullptr,
                                   o->pend[o->pcur].as<float>(), o->pend_lo[o->pcur].as<float>(), o->pend_hist + o->pend_count, 0,
                                   o->pend_hist - o->hist_valid * (int64_t)o->H, Tpad, 1));

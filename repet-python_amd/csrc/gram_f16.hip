@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
                                                        float* __restrict__ out, int64_t pitch,
                                                        const int2* __restrict__ tiles, int n_lags,
                                                        int64_t plane_batch_stride, int64_t out_batch_stride,
-                                                       const float* __restrict__ row_inv, int64_t inv_batch_stride) {
+                                                       const float* __restrict__ row_inv, int64_t inv_batch_stride, int lookback) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     planes += blockIdx.y * plane_batch_stride;
     out += blockIdx.y * out_batch_stride;
@@ -325,6 +325,33 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] *= unscale;
     }
+    if (BAND && lookback) {
+        // LOOK-BACK layout (simonline): out[j][l] = row j . row j - l, the similarities of frame j with the frames BEFORE it
+        // side by side -- the peak picking of frame j reads one contiguous row instead of walking a diagonal of
+        // out[t][l] = row t . row t + l one cache line per element (cfg 5: 55 000 rows of 431 elements, a 64-byte sector
+        // each). The transposed block goes through this wave's LDS patch so that a store instruction covers 64 consecutive
+        // lags of one row.
+        __syncthreads();                                  // the patches alias the tile buffers
+        float* patch = reinterpret_cast<float*>(ldsh) + wave * (64 * 65);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int j = n * 32 + lr;
+                    patch[j * 65 + i] = acc[m][n][r];
+                }
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the patch is wave-private
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 64; ++j) {
+            const int64_t gj = gj0 + j, gi = gi0 + lane;
+            const int64_t lag = gj - gi;
+            if (gj < T && gi < T && lag >= 0 && lag < n_lags) out[gj * pitch + lag] = patch[j * 65 + lane];
+        }
+        return;
+    }
     if (BAND || bi != bj) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -407,20 +434,20 @@ hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL((gram_f16_kernel<false, true>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
                            reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
-                           (const float*)nullptr, (int64_t)0);
+                           (const float*)nullptr, (int64_t)0, 0);
         return hipGetLastError();
     }
     hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false, false>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((gram_f16_kernel<false, false>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
                        reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
-                       (const float*)nullptr, (int64_t)0);
+                       (const float*)nullptr, (int64_t)0, 0);
     return hipGetLastError();
 }
 
 hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float* band, int32_t n_lags, int32_t LP,
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
-                                int64_t band_batch_stride, hipStream_t s, const float* row_inv, int64_t inv_batch_stride) {
+                                int64_t band_batch_stride, hipStream_t s, const float* row_inv, int64_t inv_batch_stride, bool lookback) {
     if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
     // REPET_GRAM_DMA=0: the register-staged K loop of rounds 1-2
     static const bool dma = [] { const char* e = getenv("REPET_GRAM_DMA"); return !(e && e[0] == '0'); }();
@@ -429,14 +456,14 @@ hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL((gram_f16_kernel<true, true>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
                            kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
-                           plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride);
+                           plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride, lookback ? 1 : 0);
         return hipGetLastError();
     }
     hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true, false>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((gram_f16_kernel<true, false>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
                        kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
-                       plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride);
+                       plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride, lookback ? 1 : 0);
     return hipGetLastError();
 }
 

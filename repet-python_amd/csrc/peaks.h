@@ -4,6 +4,8 @@
 
 namespace repet {
 
+// mode: 0 = rows of a full matrix; 1 = simonline on band[t][l] = sim(t, t + l): element i of row j is frame j - ((j - i) mod n),
+// a walk down a diagonal; 2 = the same elements in the look-back band[j][l] = sim(j, j - l): row j is contiguous
 struct PeakArgs {
     const float* M; int64_t row0; int n; int64_t pitch; int mode; float min_value; int d; int number;
     int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap; int64_t shift;

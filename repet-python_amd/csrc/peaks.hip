@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
         // circular-buffer order of the online variant: column c holds frame j - ((j - c) mod B)
         int l = (int)(j - i) % n;
         if (l < 0) l += n;
-        return nan_to_inf(a.M[(j - l - a.shift) * a.pitch + l]);
+        return nan_to_inf(a.M[(a.mode == 2 ? j - a.shift : j - l - a.shift) * a.pitch + l]);     // mode 2: the look-back band
     };
 
     const bool vec_ok = (a.mode == 0) && ((a.pitch & 3) == 0);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
     STAMP(5)
     auto elem_row = [&](int i) -> const float* {               // unit row of the frame behind element i
         int64_t fr = i;
-        if (a.mode == 1) {
+        if (a.mode != 0) {
             int l = (int)(j - i) % n;
             if (l < 0) l += n;
             fr = j - l - a.shift;

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kExactThreads) void local_maxima_exact_kernel(Exact
         auto fetch = [&](int i) -> float {
             if (a.mode == 0) return a.M[j * a.pitch + i];
             const int l = lag_of(i);
-            return a.M[(j - l - a.shift) * a.pitch + l];
+            return a.M[(a.mode == 2 ? j - a.shift : j - l - a.shift) * a.pitch + l];
         };
         auto frame_of = [&](int i) -> int64_t { return a.mode == 0 ? (int64_t)i : j - lag_of(i) - a.shift; };
         auto out_index = [&](int i) -> int { return a.mode == 0 ? i : (int)(j - lag_of(i) - a.shift); };

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
     auto fetch_inside = [&](int i) -> float {
         int l = (int)(j - i) % n;
         l += l < 0 ? n : 0;
-        const int64_t at = a.mode == 0 ? j * a.pitch + i : (j - l - a.shift) * a.pitch + l;
+        const int64_t at = a.mode == 0 ? j * a.pitch + i : (a.mode == 2 ? j - a.shift : j - l - a.shift) * a.pitch + l;    // mode 2: the look-back band, a contiguous row
         return a.M[at];
     };
     const bool vec_ok = (a.mode == 0) && ((a.pitch & 3) == 0);

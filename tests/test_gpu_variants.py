@@ -555,6 +555,33 @@ def test_mask_plane_gives_the_same_bits():
     assert np.array_equal(outs[0], outs[2], equal_nan=True)
 
 
+def test_lookback_band_gives_the_same_bits():
+    """simonline's banded similarity in the look-back layout band[j][l] = sim(j, j - l) (default on the f16-split kernel:
+    the peak picking of a frame reads one contiguous row) against band[t][l] = sim(t, t + l) read down a diagonal
+    (REPET_BAND_LOOKBACK=0): the same numbers in another place, so a single clip, a batch context and a pushed stream
+    must come out IDENTICAL, similar-frame lists included."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth, synth_groove; "
+            "x = synth(31, 44100, 2, 3); y = repet.simonline(x, 44100); g = synth_groove(24, 22050, 1, 2); yg = repet.simonline(g, 22050); "
+            "c = repet.Context(0); c.upload_batch(np.stack([synth(13, 16000, 2, s) for s in range(3)])); p = repet.derive_params(16000); c.execute('simonline', p); "
+            "yb = c.download(); idx, cnt = c.last_sim_indices(c.last_frame_count() - p.buffer_frames + 1, p.sim_number); "
+            "h = repet.online(16000, 2); z = synth(14, 16000, 2, 9); ys = np.concatenate([h.push(z[i:i + 4096]) for i in range(0, len(z), 4096)] + [h.finish()]); "
+            "np.savez(sys.argv[1], y=y, yg=yg, yb=yb, idx=idx, cnt=cnt, ys=ys)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for lookback in ("1", "0"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_lookback_{lookback}_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_BAND_LOOKBACK=lookback))
+        with np.load(out) as z:
+            outs.append({k: z[k] for k in z.files})
+        os.remove(out)
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
 @pytest.mark.slow
 def test_power_planes_from_the_stft_give_the_same_bits():
     """extended with enough segments for the f16-split banded Gram (>= 512 tiles: a 400-s clip): the row-scaled f16 planes
