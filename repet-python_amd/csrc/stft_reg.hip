@@ -460,6 +460,17 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
     const int fade_in = (int)a.fade_in, overlap = (int)a.fade_out, step = (int)a.seg_step;
     const float den_in = 1.0f / (float)(2 * a.fade_in), den_ov = 1.0f / (float)(2 * a.fade_out);       // (reciprocals: segment_weight32)
     auto weight = [&](int64_t n) -> float { return segment_weight32((int)n, fade_in, overlap, step, a.later, den_in, den_ov); };
+    // With a step of at least half a segment only the NEXT segment's fall can reach a sample (the default: 10-s segments
+    // every 5 s): the same two factors without segment_weight32's loop over the later segments, whose trip count differs
+    // from lane to lane (sixteen divergent loops per hop and lane). Wave-uniform choice per hop below.
+    auto weight_one_later = [&](int n) -> float {
+        float w = 1.f;
+        if (n < fade_in) w = (float)(2 * n + 1) * den_in;
+        const int rr = n - step;
+        if (rr >= 0 && rr < overlap) w *= (float)(2 * (overlap - rr) - 1) * den_ov;
+        return w;
+    };
+    const bool later_any = a.later >= 1 && overlap > 0 && step > 0;
 
     for (int r = 0; r < rounds; ++r) {
         const int64_t t = h0 - 1 + (int64_t)kInvWaves * r + wave;       // this wave's frame; it emits hop t
@@ -568,6 +579,8 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
         const bool emit = t >= h0 && t <= h_last;                       // wave-uniform
         if (emit) {
             const int64_t n_base = t * N - a.trim;                       // output sample of the hop's first sample
+            // (no later segment at all: the fall factor must not apply; two steps beyond the hop's last sample: only q = 1 can)
+            const bool one_later = later_any && n_base >= 0 && n_base + 2 * (int64_t)N < 2 * (int64_t)step;
             int lane = lane_id;                                          // opaque: no per-slot addresses kept across rounds
             asm volatile("" : "+v"(lane));
             // an accumulating class of `extended` segments: the eight old values of this lane are fetched together before
@@ -595,7 +608,10 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                 float* dst = a.out + (a.out_offset + n0) * C;
                 if (whole || (n0 >= 0 && n0 + 1 < a.n_out)) {
                     float w0 = 1.f, w1 = 1.f;
-                    if (mode != 0) { w0 = weight(n0); w1 = weight(n0 + 1); }
+                    if (mode != 0) {
+                        if (one_later) { w0 = weight_one_later((int)n0); w1 = weight_one_later((int)n0 + 1); }
+                        else { w0 = weight(n0); w1 = weight(n0 + 1); }
+                    }
                     if constexpr (C == 2) {
                         Float4A* q = reinterpret_cast<Float4A*>(dst);
                         Float4A r{o[0][0], o[1][0], o[0][1], o[1][1]};
