@@ -649,10 +649,12 @@ def test_gram_tile_sizes_give_the_same_matrix():
     outs = []
     # the third: f16 planes written by the STFT epilogue itself; the fourth: the two-buffer K loop of round 2
     # and the intermediate interleaves of the rescheduled K loop (REPET_GRAM_PIPE=2, 3, 4)
-    for tile in ("256", "128", "256+split-in-stft", "256+two-buffers", "256+pipe=2", "256+pipe=3.", "256+pipe=4.."):
+    # and the 128 x 128 kernel with the register-staged K loop of rounds 1-2 (REPET_GRAM_DMA=0)
+    for tile in ("256", "128", "256+split-in-stft", "256+two-buffers", "256+pipe=2", "256+pipe=3.", "256+pipe=4..", "128+register-staged"):
         out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile[:3]}_{len(tile)}_{os.getpid()}.npz")
         pipe = "0" if "two" in tile else tile[9] if "pipe" in tile else "1"
-        env = dict(os.environ, REPET_GRAM_TILE=tile[:3], REPET_SPLIT_IN_STFT="1" if "split" in tile else "0", REPET_GRAM_PIPE=pipe)
+        env = dict(os.environ, REPET_GRAM_TILE=tile[:3], REPET_SPLIT_IN_STFT="1" if "split" in tile else "0", REPET_GRAM_PIPE=pipe,
+                   REPET_GRAM_DMA="0" if "register" in tile else "1")
         subprocess.check_call([sys.executable, "-c", code, out], env=env)
         with np.load(out) as z:
             outs.append({k: z[k] for k in z.files})
