@@ -430,7 +430,9 @@ struct MaskPlaneScope {            // the choice holds for one pipeline; stage e
     ~MaskPlaneScope() { c->mask_plane = false; }
 };
 
-int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B = 1) {
+// p_planes: the forward STFT will write the row-scaled f16 planes of the power spectra (prepare_power_planes): their pad
+// rows [T, Tpad) of every clip are zeroed by the same housekeeping launch (as a 2-D memset they were 61 us at cfg 3)
+int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B = 1, bool p_planes = false) {
     if (g.W > 4096) c->mask_plane = false;       // the 8192-sample inverse kernel has no registers to spare for the mask
     HIP_TRY(c->X.ensure((size_t)B * g.C * g.chan_stride * sizeof(float2)));
     HIP_TRY(c->V.ensure((size_t)B * g.C * g.chan_stride * sizeof(float)));
@@ -441,8 +443,10 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     HIP_TRY(c->refine_stats.ensure(kRefineStats * sizeof(unsigned int)));
     // one launch: the pad rows of V, zeros over the rows [T, Tpad) of every clip's unit spectra (the Gram tiles read
     // them), the counters of the peak refinement (make_refine then skips its own clear)
+    if (p_planes && !want_vn) HIP_TRY(c->Vh.ensure((size_t)B * mean_elems * 4));
+    float* zero_rows = want_vn ? c->Vn.as<float>() + g.T * g.FS : (p_planes && g.Tpad > g.T) ? c->Vh.as<float>() + g.T * g.FS : nullptr;
     HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream,
-                                 want_vn ? c->Vn.as<float>() + g.T * g.FS : nullptr, (int64_t)mean_elems,
+                                 zero_rows, (int64_t)mean_elems,
                                  (int64_t)(g.Tpad - g.T) * g.FS, B, c->refine_stats.as<unsigned int>()));
     c->refine_stats_cleared = true;
     if (want_vn) {
@@ -521,11 +525,8 @@ int run_istft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t trim, int64_
 // pad rows of every clip (zero planes, inverse scale 1: what the separate pass makes of zero rows).
 int prepare_power_planes(repet_ctx* c, const Geo& g, int64_t T, int B) {
     const int64_t mean_stride = g.Tpad * g.FS;
-    HIP_TRY(c->Vh.ensure((size_t)B * mean_stride * 4));
+    HIP_TRY(c->Vh.ensure((size_t)B * mean_stride * 4));            // (pad rows: zeroed by ensure_spectra's housekeeping launch)
     HIP_TRY(c->amax.ensure((size_t)B * g.Tpad * sizeof(float)));
-    if (g.Tpad > T)
-        HIP_TRY(hipMemset2DAsync(static_cast<char*>(c->Vh.p) + (size_t)T * g.FS * 4, (size_t)mean_stride * 4, 0,
-                                 (size_t)(g.Tpad - T) * g.FS * 4, (size_t)B, c->stream));
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->amax.p), 0x3f800000, (size_t)B * g.Tpad, c->stream));
     return REPET_OK;
 }
@@ -561,7 +562,7 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
                     !(weighted && (n >= lim30 || hop >= lim30 || overlap >= lim30));
     const int model_rows = hi + 1;
     ModelRef model_ref{};
-    RP_TRY(ensure_spectra(c, g, false, !p_planes, B));
+    RP_TRY(ensure_spectra(c, g, false, !p_planes, B, p_planes));
     if (c->mask_model) {
         HIP_TRY(c->Wm.ensure((size_t)B * g.C * model_rows * g.FS * sizeof(float)));
         model_ref = ModelRef{c->Wm.as<float>(), period_slots, (int64_t)g.C * model_rows * g.FS, (int64_t)model_rows * g.FS, p->cutoff_bins};
@@ -690,13 +691,30 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
     }
     const int64_t O = L - Hs;
     HIP_TRY(c->periods.ensure((size_t)std::max<int64_t>(n_seg, 1) * sizeof(int32_t)));
-    if (!c->win_skip_clear)
-        HIP_TRY(hipMemsetAsync(c->out.as<float>() + c->clip_base * c->n_channels, 0, (size_t)N * c->n_channels * sizeof(float), c->stream));
     const int64_t last = count - 1;
     const int64_t uniform = std::min(first + n_seg, last) - first;  // equal-length segments in the range
+    constexpr int64_t kMaxSegmentBatch = 256;
+    if (!c->win_skip_clear) {
+        // Class 0 of the first batch STORES its span (run_original: accumulate_weighted = 2 when the segment length is a whole
+        // number of steps) -- with the register inverse STFT, which honours that mode, those samples need no clearing: at
+        // cfg 3 that is all but the last 441 000 of 26 460 000 samples (212 MB of memset, 40 us). Other kernels add onto
+        // the cleared output whatever the mode says, so they get the whole clear.
+        int64_t s0 = 0, s1 = 0;                                     // [s0, s1): stored by class 0 of the first batch
+        const int64_t lim30 = (int64_t)1 << 30;
+        static const bool partial = [] { const char* e = getenv("REPET_EXTENDED_CLEAR"); return !(e && e[0] == 'a'); }();     // =all: the whole output
+        if (partial && uniform > 0 && Hs > 0 && L == ceil_div(L, Hs) * Hs && reg_fft_supported(p->window_length, c->n_channels, true) &&
+            L < lim30 && Hs < lim30 && O < lim30) {
+            const int64_t classes = ceil_div(L, Hs), nb0 = std::min(uniform, kMaxSegmentBatch);
+            const int64_t n_class0 = (nb0 + classes - 1) / classes;
+            s0 = first * Hs;
+            s1 = (first + (n_class0 - 1) * classes) * Hs + L;
+        }
+        float* o = c->out.as<float>() + c->clip_base * c->n_channels;
+        if (s0 > 0) HIP_TRY(hipMemsetAsync(o, 0, (size_t)s0 * c->n_channels * sizeof(float), c->stream));
+        if (s1 < N) HIP_TRY(hipMemsetAsync(o + s1 * c->n_channels, 0, (size_t)(N - s1) * c->n_channels * sizeof(float), c->stream));
+    }
     // the equal-length segments go through every stage as ONE batch -- in bounded batches, so that the workspaces of an
     // hours-long recording stay at a few GB (a segment's spectra are about 15 MB at 44.1 kHz stereo)
-    constexpr int64_t kMaxSegmentBatch = 256;
     auto run_uniform = [&]() -> int {
         for (int64_t done = 0; done < uniform; done += kMaxSegmentBatch) {
             const int64_t nb = std::min(kMaxSegmentBatch, uniform - done);
@@ -777,7 +795,7 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     static const bool adaptive_f16 = [] { const char* e = getenv("REPET_ADAPTIVE_F16"); return !(e && e[0] == '0'); }();
     const bool p_planes = adaptive_f16 && power_planes_enabled() && gram_f16_enabled() && g.Tpad == round_up(T, kTile) &&
                           reg_fft_supported(g.W, g.C, false) && T >= 2048;
-    RP_TRY(ensure_spectra(c, g, false, !p_planes));
+    RP_TRY(ensure_spectra(c, g, false, !p_planes, 1, p_planes));
     if (p_planes) RP_TRY(prepare_power_planes(c, g, T, 1));
     RP_TRY(run_stft(c, g, tb, 0, N, 1, false, true, 1, 0, p_planes));
     const int LP = (int)round_up(hi, 64);
