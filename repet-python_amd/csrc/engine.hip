@@ -750,18 +750,23 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         HIP_TRY(hipEventRecord(c->aux_start, c->stream));              // the clip is resident, `out` is cleared
         HIP_TRY(hipStreamWaitEvent(x->stream, c->aux_start, 0));
         int batch_rc = REPET_OK;
+        hipStream_t aux_stream = x->stream;
         x->pre_synthesis = [&]() -> int {
             batch_rc = run_uniform();
             if (batch_rc != REPET_OK) return batch_rc;
-            if (hipEventRecord(c->aux_main_done, c->stream) != hipSuccess || hipStreamWaitEvent(x->stream, c->aux_main_done, 0) != hipSuccess)
+            // The last segment's inverse STFT goes on the MAIN stream, behind the batch's (it accumulates into samples the
+            // batch also writes): the main stream waits for the analysis on the auxiliary one -- long finished -- and the
+            // launch follows the batch directly. (On the auxiliary stream it was two more stream hops: main -> aux before
+            // it, aux -> main behind it.)
+            if (hipEventRecord(c->aux_main_done, aux_stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->aux_main_done, 0) != hipSuccess)
                 return fail(REPET_ERR_HIP, "extended: stream ordering of the last segment");
+            x->stream = c->stream;
             return REPET_OK;
         };
         const int rc = run_original(x, p, last * Hs, N - last * Hs, 1, 0, c->periods.as<int32_t>() + uniform, true, (int)last, (int)count, O);
         x->pre_synthesis = nullptr;
-        if (rc != REPET_OK) { (void)hipStreamSynchronize(x->stream); return rc; }
-        HIP_TRY(hipEventRecord(c->aux_done, x->stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_done, 0));
+        x->stream = aux_stream;
+        if (rc != REPET_OK) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamSynchronize(c->stream); return rc; }
         mark(c, "last_segment", 0, 0);
     } else {
         if (uniform > 0) RP_TRY(run_uniform());
