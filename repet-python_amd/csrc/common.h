@@ -332,7 +332,7 @@ constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
 hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
                                 hipStream_t s, float* Z = nullptr, int64_t z_stride = 0, int64_t z_count = 0, int32_t n_z = 0,
-                                unsigned int* stats = nullptr);
+                                unsigned int* stats = nullptr, float* Z2 = nullptr);
 // max_count / min_period bound the list length so the launcher can pick the smallest compiled network.
 // side/fork/join (nullable): second stream and two events to run the Nyquist-bin kernel beside the main one.
 // parts: 1 = main kernel only, 2 = Nyquist-bin kernel only, 3 = both (chunked pipelines launch them separately).

@@ -444,21 +444,16 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     // one launch: the pad rows of V, zeros over the rows [T, Tpad) of every clip's unit spectra (the Gram tiles read
     // them), the counters of the peak refinement (make_refine then skips its own clear)
     if (p_planes && !want_vn) HIP_TRY(c->Vh.ensure((size_t)B * mean_elems * 4));
-    float* zero_rows = want_vn ? c->Vn.as<float>() + g.T * g.FS : (p_planes && g.Tpad > g.T) ? c->Vh.as<float>() + g.T * g.FS : nullptr;
+    // the f16 planes of the unit rows, written by the STFT beside Vn (same bytes per row: 2 planes x 2 bytes); the big-tile
+    // Gram kernel reads (and ignores) up to round_up(T, 256) rows of a single clip
+    const bool unit_planes = want_vn && split_in_stft(B);
+    if (unit_planes) HIP_TRY(c->Vh.ensure((B == 1 ? (size_t)round_up(g.T, 256) * g.FS : B * mean_elems) * sizeof(float)));
+    const bool planes_pad = (unit_planes || (p_planes && !want_vn)) && g.Tpad > g.T;
     HIP_TRY(launch_fill_pad_rows(c->V.as<float>(), g.chan_stride, B * g.C, g.Tpad, g.FS, c->stream,
-                                 zero_rows, (int64_t)mean_elems,
-                                 (int64_t)(g.Tpad - g.T) * g.FS, B, c->refine_stats.as<unsigned int>()));
+                                 want_vn ? c->Vn.as<float>() + g.T * g.FS : nullptr, (int64_t)mean_elems,
+                                 (int64_t)(g.Tpad - g.T) * g.FS, B, c->refine_stats.as<unsigned int>(),
+                                 planes_pad ? c->Vh.as<float>() + g.T * g.FS : nullptr));      // (one launch: a 2-D memset of the planes' pad rows was 45-61 us)
     c->refine_stats_cleared = true;
-    if (want_vn) {
-        if (split_in_stft(B)) {
-            // the f16 planes of the unit rows, written by the STFT beside Vn (same bytes per row: 2 planes x 2 bytes);
-            // the big-tile Gram kernel reads (and ignores) up to round_up(T, 256) rows of a single clip
-            HIP_TRY(c->Vh.ensure((B == 1 ? (size_t)round_up(g.T, 256) * g.FS : B * mean_elems) * sizeof(float)));
-            if (g.Tpad > g.T)
-                HIP_TRY(hipMemset2DAsync(c->Vh.as<float>() + g.T * g.FS, mean_elems * sizeof(float), 0,
-                                         (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), (size_t)B, c->stream));
-        }
-    }
     if (want_p) {
         HIP_TRY(c->P.ensure(B * mean_elems * sizeof(float)));
         if (B == 1) HIP_TRY(hipMemsetAsync(c->P.as<float>() + g.T * g.FS, 0, (size_t)(g.Tpad - g.T) * g.FS * sizeof(float), c->stream));

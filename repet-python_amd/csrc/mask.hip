@@ -160,21 +160,25 @@ int median_network_instructions(int max_n, int* net_size) {
 // spectra, which the Gram tiles read), optionally the four counters of the peak refinement. (Three launches before: a
 // fill kernel, a 2-D memset, a 16-byte memset -- 14 us in front of a 68-us STFT.)
 __global__ void fill_pad_rows_kernel(float* V, int64_t chan_stride, int n_channels, int64_t pad_row, int FS,
-                                     float* Z, int64_t z_stride, int64_t z_count, int n_z, unsigned int* stats) {
+                                     float* Z, int64_t z_stride, int64_t z_count, int n_z, unsigned int* stats, float* Z2) {
     const int y = blockIdx.y;
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (y < n_channels && k < 2 * FS) V[y * chan_stride + pad_row * FS + k] = (k < FS) ? -1.0f : INFINITY;
-    if (y < n_z && 4 * k < z_count) *reinterpret_cast<float4*>(Z + y * z_stride + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < n_z && 4 * k < z_count) {
+        *reinterpret_cast<float4*>(Z + y * z_stride + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Z2) *reinterpret_cast<float4*>(Z2 + y * z_stride + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);     // a second array of the same geometry
+    }
     if (stats && y == 0 && k < kRefineStats) stats[k] = 0u;
 }
 
 hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
-                                hipStream_t s, float* Z, int64_t z_stride, int64_t z_count, int32_t n_z, unsigned int* stats) {
-    if (!Z || z_count <= 0) { Z = nullptr; z_count = 0; n_z = 0; }
+                                hipStream_t s, float* Z, int64_t z_stride, int64_t z_count, int32_t n_z, unsigned int* stats, float* Z2) {
+    if (!Z && Z2) { Z = Z2; Z2 = nullptr; }
+    if (!Z || z_count <= 0) { Z = nullptr; Z2 = nullptr; z_count = 0; n_z = 0; }
     if ((z_count & 3) || (z_stride & 3)) return hipErrorInvalidValue;
     const int64_t per_row = std::max<int64_t>(2 * FS, z_count / 4);
     hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)ceil_div(per_row, 256), (unsigned)std::max(n_channels, n_z)), dim3(256), 0, s,
-                       V, chan_stride, n_channels, pad_row, FS, Z, z_stride, z_count, n_z, stats);
+                       V, chan_stride, n_channels, pad_row, FS, Z, z_stride, z_count, n_z, stats, Z2);
     return hipGetLastError();
 }
 
