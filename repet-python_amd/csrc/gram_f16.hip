@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     planes += blockIdx.y * plane_batch_stride;
     out += blockIdx.y * out_batch_stride;
-    const int2 tile = tiles[blockIdx.x];
+    // The list is dealt to the XCDs in groups of eight entries (entry 8 k + x is XCD x's k-th tile: workgroup id modulo 8) and
+    // padded to a multiple of eight: in a batch every clip would put its padding on the same XCDs (a segment of `extended`
+    // has seven tiles + one: XCD 7 idle, 0.203 -> 0.189 ms at cfg 3 without that), so clip b takes the group rotated by b.
+    const int2 tile = tiles[(blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u)];
     const int bi = tile.x, bj = tile.y;
     if (bi < 0) return;
 
