@@ -199,8 +199,9 @@ hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float
 // the same full matrix with 256 x 256 tiles and LDS-DMA staging (gram_f16_big.hip); tiles from gram_tile_list(ceil(T / 256), all);
 // `planes` must be readable up to row round_up(T, 256)
 int gram_big_tile();
+// seg (nullable): the epilogue also writes the segment records of S's rows (peaks.h: PeakArgs::seg), pitch seg_pitch
 hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
-                                    const int2* tiles, int32_t n_tiles, hipStream_t s);
+                                    const int2* tiles, int32_t n_tiles, hipStream_t s, float* seg = nullptr, int32_t seg_pitch = 0);
 // banded form: band[t][l] = row t . row t+l; plane_batch_stride in halves (2 * Tpad * FS); row_inv (nullable): per-row
 // inverse scales of launch_split_f16_rows, inv_batch_stride floats between clips; lookback: band[j][l] = row j . row j-l
 // instead (the layout the peak picking of simonline reads row by row: PeakArgs::mode 2)
@@ -269,10 +270,22 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift = 0,
                                const PeakRefine* refine = nullptr, const PeakBatch* batch = nullptr,
-                               void* scratch = nullptr, const struct ExactSource* lite_src = nullptr);
+                               void* scratch = nullptr, const struct ExactSource* lite_src = nullptr,
+                               const float* seg = nullptr, int32_t seg_pitch = 0);
+//   seg (mode 0, nullable): the rows' segment records (peaks.h: launch_segment_maxima, or the Gram kernel's epilogue), row r
+//           of M at seg + (row0 + r) * 3 * seg_pitch: the wavefront kernel then takes its candidates from them.
 //   lite_src (second level, fast path): instead of the first pass, the rows it left records of (PeakRefine::records)
 //           are taken up again with the float64 unit rows of lite_src (same matrix arguments as the first call).
 bool local_maxima_wave_supported(int n_cols, int d, int* record_bytes);
+// Segment records (peaks.h: PeakArgs::seg): for every row and every aligned run of kSegWidth columns the largest value, the
+// largest of the run's other elements and the position of the largest, as three planes of seg_pitch entries per row.
+// launch_segment_maxima computes them from a matrix (the Gram kernel of the long clips writes them in its epilogue);
+// segment_pitch: the planes' pitch for rows of n_cols elements; local_maxima_segments_apply: whether the peak picking will
+// use them for this shape (mode 0, one clip, 16-byte aligned rows, windows of at least kSegWidth - 1 on either side)
+constexpr int kSegWidth = 32;
+hipError_t launch_segment_maxima(const float* M, int64_t n_rows, int n_cols, int64_t pitch, float* seg, int seg_pitch, hipStream_t s);
+int segment_pitch(int n_cols);
+bool local_maxima_segments_apply(int n_cols, int d, int64_t pitch, int mode, int n_batch);
 hipError_t launch_unit_rows_f64(const struct ExactSource& src, const PeakRefine* refine, hipStream_t s);
 //   scratch (nullable): local_maxima_scratch_bytes(n_rows, n_cols, d) bytes (0 for rows that fit one workgroup). With
 //           it, rows of any length are handled in segments; without it the limit is about 40 000 elements per row.

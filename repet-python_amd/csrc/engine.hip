@@ -123,6 +123,7 @@ struct repet_ctx {
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
     DevBuf peak_scratch;          // per-segment candidates of long similarity rows (launch_local_maxima)
+    DevBuf seg;                   // segment records of the similarity rows (PeakArgs::seg): [row][m1 | m2 | arg][seg_pitch]
     DevBuf beat_partial;          // chunk sums of the beat-spectrum windows (launch_band_window_sum)
     DevBuf amax;                  // inverse scale of every row of the matrix being split (scaled f16-split band Gram)
     DevBuf Vh;                    // f16 hi / lo halves of Vn for the split-precision Gram (gram_f16.hip)
@@ -254,8 +255,12 @@ bool gram_big_enabled() {
     return on;
 }
 
+// seg (nullable): segment records of S's rows for the peak picking (peaks.h), pitch seg_pitch: written by the 256 x 256
+// kernel's epilogue, by a pass over S behind the other kernels
 int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS, bool unit_rows = false,
-                  bool planes_ready = false) {
+                  bool planes_ready = false, float* seg = nullptr, int seg_pitch = 0) {
+    // REPET_GRAM_SEGMENTS=0: the records by the pass over S also behind the 256 x 256 kernel (agreement test of the epilogue's)
+    static const bool seg_in_epilogue = [] { const char* e = getenv("REPET_GRAM_SEGMENTS"); return !(e && e[0] == '0'); }();
     if (unit_rows && gram_f16_enabled() && gram_big_enabled() && T >= 8 * gram_big_tile()) {
         const int bt = gram_big_tile();
         const int nb = (int)ceil_div(T, bt);
@@ -275,7 +280,9 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
             HIP_TRY(c->Vh.ensure((size_t)round_up(T, bt) * FS * 4));
             HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
         }
-        HIP_TRY(launch_gram_full_f16_big(c->Vh.p, T, FS, S, TS, c->tiles_big.as<int2>(), c->tiles_big_count, c->stream));
+        HIP_TRY(launch_gram_full_f16_big(c->Vh.p, T, FS, S, TS, c->tiles_big.as<int2>(), c->tiles_big_count, c->stream,
+                                         seg_in_epilogue ? seg : nullptr, seg_pitch));
+        if (seg && !seg_in_epilogue) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
         return REPET_OK;
     }
     const int2* tiles; int n;
@@ -287,9 +294,11 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
             HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
         }
         HIP_TRY(launch_gram_full_f16(c->Vh.p, T, FS, S, TS, tiles, n, c->stream));
+        if (seg) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
         return REPET_OK;
     }
     HIP_TRY(launch_gram_full(A, T, FS, S, TS, tiles, n, c->stream));
+    if (seg) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
     return REPET_OK;
 }
 // unit_rows: A holds unit vectors (the similarity band of simonline), safe for the f16-split kernel; the beat-spectrum
@@ -993,7 +1002,12 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);
     HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
-    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft(1)));
+    // segment records of S's rows: the peak picking takes its candidates from them instead of scanning S (peaks_wave.hip)
+    const bool with_seg = local_maxima_segments_apply((int)T, p->sim_distance_frames, TS, 0, 1);
+    const int seg_pitch = segment_pitch((int)TS);
+    if (with_seg) HIP_TRY(c->seg.ensure((size_t)T * 3 * seg_pitch * sizeof(float)));
+    float* seg = with_seg ? c->seg.as<float>() : nullptr;
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft(1), seg, seg_pitch));
     {
         // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
         // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
@@ -1040,7 +1054,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         if (scratch > 0) HIP_TRY(c->peak_scratch.ensure(scratch));
         hipError_t e = launch_local_maxima(c->S.as<float>(), T, 0, (int)T, TS, 0, (float)p->sim_threshold,
                                            p->sim_distance_frames, K, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), c->stream, 0, &rf,
-                                           nullptr, scratch > 0 ? c->peak_scratch.p : nullptr);
+                                           nullptr, scratch > 0 ? c->peak_scratch.p : nullptr, nullptr, seg, seg_pitch);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
         // The second level of the peak picking: float64 spectra for the rows the fp32 spectra cannot settle (a few hundred of
@@ -1074,7 +1088,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             if (a0 >= a1) break;
             hipError_t e = launch_local_maxima(c->S.as<float>(), a1 - a0, a0, (int)T, TS, 0, (float)p->sim_threshold,
                                                p->sim_distance_frames, K, c->idx.as<int32_t>() + a0 * KP, KP,
-                                               c->cnt.as<int32_t>() + a0, c->side_stream, 0, &rf);
+                                               c->cnt.as<int32_t>() + a0, c->side_stream, 0, &rf, nullptr, nullptr, nullptr, seg, seg_pitch);
             if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
             HIP_TRY(e);
             HIP_TRY(hipEventRecord(c->chunk_events[k], c->side_stream));
@@ -2204,8 +2218,16 @@ int repet_local_maxima(repet_ctx* c, const float* m, int32_t n_rows, int32_t n_c
     RP_TRY(h2d_pitched(c, c->S.as<float>(), pitch, m, n_rows, n_cols, n_rows));
     HIP_TRY(c->idx.ensure((size_t)n_rows * number * sizeof(int32_t)));
     HIP_TRY(c->cnt.ensure((size_t)n_rows * sizeof(int32_t)));
+    float* seg = nullptr;
+    const int seg_pitch = segment_pitch((int)pitch);
+    if (local_maxima_segments_apply(n_cols, d, pitch, 0, 1)) {
+        HIP_TRY(c->seg.ensure((size_t)n_rows * 3 * seg_pitch * sizeof(float)));
+        seg = c->seg.as<float>();
+        HIP_TRY(launch_segment_maxima(c->S.as<float>(), n_rows, n_cols, pitch, seg, seg_pitch, c->stream));
+    }
     hipError_t e = launch_local_maxima(c->S.as<float>(), n_rows, 0, n_cols, pitch, 0, min_value, d, number,
-                                       c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), c->stream);
+                                       c->idx.as<int32_t>(), number, c->cnt.as<int32_t>(), c->stream, 0, nullptr, nullptr, nullptr,
+                                       nullptr, seg, seg_pitch);
     if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "row too long for the peak-picking kernel");
     HIP_TRY(e);
     HIP_TRY(hipMemcpyAsync(idx_out, c->idx.p, (size_t)n_rows * number * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

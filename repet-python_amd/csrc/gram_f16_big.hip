@@ -60,190 +60,14 @@ constexpr int kPatchPitch = 68;               // floats per patch row: 16-byte a
 constexpr int kPatchLds = 8 * 64 * kPatchPitch * 4;   // bytes: one 64 x 68 float patch per wave = 139 264
 constexpr int kBigLds = kPatchLds > kLoopLds ? kPatchLds : kLoopLds;
 
-__global__ __launch_bounds__(512) void gram_f16_big_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
-                                                           float* __restrict__ out, int64_t pitch,
-                                                           const int2* __restrict__ tiles) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 lds_big[];
-    const int2 tile = tiles[blockIdx.x];
-    const int bi = tile.x, bj = tile.y;
-    if (bi < 0) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;                      // 2 x 4 waves: rows wr*128, columns wc*64
-    const int lr = lane & 31, lh = lane >> 5;
-
-    const int64_t a_row0 = (int64_t)bi * BT, b_row0 = (int64_t)bj * BT;
-    const unsigned grow = (unsigned)(2 * FS);                     // halves per row of the interleaved global image
-
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    // LDS-DMA pieces: 64 per K-tile (2 operands x 2 planes x 16 blocks of 16 rows), 8 per wave. A piece is 1 KiB =
-    // 16 rows x 64 bytes of one plane, written lane-linearly: lane l lands on row l >> 2, 16-byte slot l & 3, which must
-    // hold the row's chunk (l & 3) ^ ((row >> 2) & 3) -- so that is the chunk this lane FETCHES.
-    const int prow = lane >> 2;                                                  // row inside the piece
-    const _Float16* src_lane[8];
-    int dst_piece[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int pc = wave * 8 + j;
-        const int operand = pc >> 5, plane = (pc >> 4) & 1, rb = pc & 15;
-        const int r = rb * 16 + prow;
-        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-        src_lane[j] = planes + ((operand ? b_row0 : a_row0) + r) * grow + plane * 32 + chunk * 8;
-        dst_piece[j] = (operand * 2 + plane) * kPlane + rb * 16 * HBK;           // halves, wave-uniform
-    }
-    auto issue_tile = [&](int kt, int buf) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_lane[j] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(lds_big + buf * kBuffer + dst_piece[j]), 16, 0, 0);
-    };
-    // fragment of lane (lr, lh): 8 halves k = 16 ks + 8 lh .. +7 of plane row `row` -> chunk 2 ks + lh, swizzled by the row
-    auto frag = [&](const _Float16* plane_ptr, int row, int ks) -> halfx8 {
-        return *reinterpret_cast<const halfx8*>(plane_ptr + row * HBK + (((2 * ks + lh) ^ ((row >> 2) & 3)) << 3));
-    };
-
-    const int nk = FS / HBK;
-    GSTAMP(0)
-    GSPAN(0)
-    issue_tile(0, 0);
-    __syncthreads();                                    // (waits vmcnt(0): the tile has landed)
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
-        const _Float16* base = lds_big + (kt & 1) * kBuffer;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            halfx8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int row = wr * 128 + m * 32 + lr;
-                ah[m] = frag(base, row, ks);
-                al[m] = frag(base + kPlane, row, ks);
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int row = wc * 64 + n * 32 + lr;
-                bh[n] = frag(base + 2 * kPlane, row, ks);
-                bl[n] = frag(base + 3 * kPlane, row, ks);
-            }
-            // the order of gram_f16.hip: lo hi', hi lo', hi hi' -- the same sums, bit for bit
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-        }
-        __syncthreads();                                // every wave is done with buffer kt & 1; tile kt+1 has landed
-    }
-
-    GSTAMP(1)
-    // ---- epilogue. acc[m][n][r]: i = wr*128 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr.
-    // Both copies of the block leave through the wave's LDS patch (64 rows x 68 floats) so that every global store is
-    // 16 bytes per lane, four 256-byte rows per instruction (the 4-byte stores of the fragment layout were 256 store
-    // instructions per lane -- the epilogue was store-issue-bound): first the 64 x 64 half as it is, then transposed.
-    // The patches alias the tile buffers, which every wave left at the loop's last barrier. (Measured against it at cfg 2,
-    // 0.197 ms: the natural copy straight from the accumulators as 4-byte stores, 128 contiguous bytes per half-wave --
-    // 0.198; the mirror straight from the accumulators as 16-byte stores, registers 4q..4q+3 being four consecutive i of
-    // row j, 32 bytes per row and instruction -- 0.211. With a quarter of the tiles in flight a workgroup's epilogue is
-    // 15 us instead of 31: half of it is the chip-wide burst of 134 MB at the end of a round, not the store sequence.)
-    const int64_t gi0 = a_row0 + wr * 128;
-    const int64_t gj0 = b_row0 + wc * 64;
-    constexpr float unscale = 1.0f / (128.0f * 128.0f);          // the 2^7 scale of both operands, exact
-    const bool diag = bi == bj;
-    float* patch = reinterpret_cast<float*>(lds_big) + wave * (64 * kPatchPitch);
-    const int srow = lane >> 4, scol = (lane & 15) * 4;          // store role: row srow + 4 k of the patch, floats scol .. scol+3
-    // a tile away from the diagonal and from the matrix's edge stores whole float4s without a test (wave-uniform choice:
-    // with the tests in the loop the compiler splits every float4 into a dword and a dwordx3 store under exec masks)
-    const bool interior = !diag && a_row0 + BT <= T && b_row0 + BT <= T;
-    auto store_rows = [&](int64_t row0, int64_t col0, bool transposed) {
-        // patch row p, float q is S[row0 + p][col0 + q]; on diagonal tiles the natural copy keeps i <= j, the mirror i < j
-        if (interior) {
-            float* dst0 = out + (row0 + srow) * pitch + col0 + scol;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                *reinterpret_cast<float4*>(dst0 + (int64_t)(4 * k) * pitch) = *reinterpret_cast<const float4*>(patch + (srow + 4 * k) * kPatchPitch + scol);
-            return;
-        }
-#pragma unroll 4
-        for (int k = 0; k < 16; ++k) {
-            const int p = srow + 4 * k;
-            const float4 v = *reinterpret_cast<const float4*>(patch + p * kPatchPitch + scol);
-            const int64_t gr = row0 + p, gc = col0 + scol;
-            if (gr >= T) continue;
-            float* dst = out + gr * pitch + gc;
-            const float vals[4] = {v.x, v.y, v.z, v.w};
-            bool all = gc + 3 < T;
-            if (diag) all = all && (transposed ? gr > gc + 3 : gr <= gc);
-            if (all) *reinterpret_cast<float4*>(dst) = v;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool keep = gc + e < T && (!diag || (transposed ? gr > gc + e : gr <= gc + e));
-                    if (keep) dst[e] = vals[e];
-                }
-            }
-        }
-    };
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {
-        // natural: patch[i][j]
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    patch[i * kPatchPitch + n * 32 + lr] = acc[2 * mh + mm][n][r] * unscale;
-                }
-        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the patch is wave-private
-        __builtin_amdgcn_wave_barrier();
-        store_rows(gi0 + mh * 64, gj0, false);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        // mirror: patch[j][i]
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    patch[(n * 32 + lr) * kPatchPitch + i] = acc[2 * mh + mm][n][r] * unscale;
-                }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        store_rows(gj0, gi0 + mh * 64, true);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-    }
-    GSTAMP(2)
-    GSTAMP(3)
-    GSPAN(1)
-}
-
 // The rescheduled form (see the head of the file). Two waves per SIMD at 250 VGPRs: accumulators 128, two fragment sets 96.
-// MODE bit 0: the DMA pieces ride between the MFMAs (else: in one block behind the first MFMA of the half tile);
-// bit 1: so do the fragment reads (else: in one block behind the eighth MFMA).
-template <int MODE>
+// (The forms with the DMA pieces or the fragment reads issued in blocks -- 130 k / 115 k / 137 k cycles of K loop against
+// 114.5 k -- and the round-2 kernel with one barrier per K-tile are in the history: round 3, `REPET_GRAM_PIPE`.)
+// seg (nullable): the segment records of S's rows for the peak picking (peaks.h: PeakArgs::seg), written from the same LDS
+// patches the stores read: lane l takes row l of the 64 x 64 patch, i.e. two segments of 32 columns.
 __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
                                                            float* __restrict__ out, int64_t pitch,
-                                                           const int2* __restrict__ tiles) {
+                                                           const int2* __restrict__ tiles, float* __restrict__ seg, int seg_pitch) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds_big[];
     const int2 tile = tiles[blockIdx.x];
     const int bi = tile.x, bj = tile.y;
@@ -318,18 +142,8 @@ __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* 
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(grp == 0 ? f.al[m] : f.ah[m], grp == 1 ? f.bl[n] : f.bh[n],
                                                                 acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MODE & 2) {
-                if (i < 12) load_frag(g_kt, g_ks, g, i);
-            } else if (i == 7) {
-#pragma unroll
-                for (int q = 0; q < 12; ++q) load_frag(g_kt, g_ks, g, q);
-            }
-            if constexpr (MODE & 1) {
-                if (i % 3 == 1 && dma) issue_piece(dma_kt, i / 3);       // (wave-uniform)
-            } else if (i == 0 && dma) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) issue_piece(dma_kt, j);
-            }
+            if (i < 12) load_frag(g_kt, g_ks, g, i);
+            if (i % 3 == 1 && dma) issue_piece(dma_kt, i / 3);           // (wave-uniform)
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -418,6 +232,52 @@ __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* 
             }
         }
     };
+    // Segment records of the patch's rows (patch row p, float q = S[row0 + p][col0 + q]): lane l owns row l, columns 0 .. 31
+    // are one aligned segment and 32 .. 63 the next. Rows at pitch 68 floats: the sixteen lanes of a ds_read_b128 group
+    // fall on sixteen different bank quads. NaN counts as +inf (v_min_f32 returns the other operand for a quiet NaN).
+    // The patch the diagonal runs through holds one half of a symmetric block in each copy: its records are written from
+    // the natural copy, element (p, q) read at (min, max).
+    struct Top { float m1, m2; int at; };
+    auto top_insert = [](Top& t, float raw, int at) {
+        float val;
+        asm("v_min_f32 %0, 0x7f800000, %1" : "=v"(val) : "v"(raw));
+        t.m2 = __builtin_amdgcn_fmed3f(t.m1, t.m2, val);
+        t.at = val > t.m1 ? at : t.at;
+        asm("v_max_f32 %0, %1, %2" : "=v"(t.m1) : "v"(t.m1), "v"(val));     // (fmaxf: a canonicalising v_max_f32 val, val in front)
+    };
+    auto emit_segments = [&](int64_t row0, int64_t col0, bool transposed, int cls) {
+        if (!seg) return;
+        const bool on_diag = row0 == col0;
+        if (on_diag && transposed) return;
+        Top t0{-INFINITY, -INFINITY, 0}, t1{-INFINITY, -INFINITY, 0};       // (two named triples: an array indexed by the loop
+        if (cls == 1) {                                                      // variable of the slow path went to scratch)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x = *reinterpret_cast<const float4*>(patch + lane * kPatchPitch + 4 * q);
+                top_insert(t0, x.x, 4 * q); top_insert(t0, x.y, 4 * q + 1); top_insert(t0, x.z, 4 * q + 2); top_insert(t0, x.w, 4 * q + 3);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x = *reinterpret_cast<const float4*>(patch + lane * kPatchPitch + 32 + 4 * q);
+                top_insert(t1, x.x, 4 * q); top_insert(t1, x.y, 4 * q + 1); top_insert(t1, x.z, 4 * q + 2); top_insert(t1, x.w, 4 * q + 3);
+            }
+        } else {
+            auto element = [&](int q) {                                      // (p, q) of the symmetric block at (min, max)
+                const int pr = on_diag ? min(lane, q) : lane, pc = on_diag ? max(lane, q) : q;
+                return patch[pr * kPatchPitch + pc];
+            };
+#pragma unroll 1
+            for (int q = 0; q < 32 && col0 + q < T; ++q) top_insert(t0, element(q), q);
+#pragma unroll 1
+            for (int q = 32; q < 64 && col0 + q < T; ++q) top_insert(t1, element(q), q - 32);
+        }
+        if (row0 + lane < T) {
+            float* rec = seg + (row0 + lane) * 3 * (int64_t)seg_pitch + (col0 >> 5);
+            *reinterpret_cast<float2*>(rec) = make_float2(t0.m1, t1.m1);
+            *reinterpret_cast<float2*>(rec + seg_pitch) = make_float2(t0.m2, t1.m2);
+            *reinterpret_cast<int2*>(rec + 2 * seg_pitch) = make_int2(t0.at, t1.at);
+        }
+    };
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
         // natural: patch[i][j]
@@ -435,6 +295,7 @@ __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* 
             __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the patch is wave-private
             __builtin_amdgcn_wave_barrier();
             store_rows(gi0 + mh * 64, gj0, false, cn);
+            emit_segments(gi0 + mh * 64, gj0, false, cn);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
@@ -453,6 +314,7 @@ __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* 
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             store_rows(gj0, gi0 + mh * 64, true, cm);
+            emit_segments(gj0, gi0 + mh * 64, true, cm);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
@@ -476,25 +338,12 @@ extern "C" int repet_debug_gram_stamps(unsigned long long* out) {
 int gram_big_tile() { return BT; }
 
 hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
-                                    const int2* tiles, int32_t n_tiles, hipStream_t s) {
+                                    const int2* tiles, int32_t n_tiles, hipStream_t s, float* seg, int32_t seg_pitch) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
-    // REPET_GRAM_PIPE=0: the two-buffer kernel with 32-component K-tiles (round 2)
-    static const int pipe = [] { const char* e = getenv("REPET_GRAM_PIPE"); return e ? atoi(e) : 1; }();
-    auto launch_pipe = [&](auto kernel) -> hipError_t {
-        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), kBigLds);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
-                           reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles);
-        return hipGetLastError();
-    };
-    if (pipe == 1) return launch_pipe(&gram_f16_big_pipe_kernel<3>);
-    if (pipe == 2) return launch_pipe(&gram_f16_big_pipe_kernel<2>);       // fragments spread, DMA in a block
-    if (pipe == 3) return launch_pipe(&gram_f16_big_pipe_kernel<1>);       // DMA spread, fragments in a block
-    if (pipe == 4) return launch_pipe(&gram_f16_big_pipe_kernel<0>);       // both in blocks (second register set only)
-    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_big_kernel), kBigLds);
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_big_pipe_kernel), kBigLds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gram_f16_big_kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
-                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles);
+    hipLaunchKernelGGL(gram_f16_big_pipe_kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
+                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, seg, seg_pitch);
     return hipGetLastError();
 }
 

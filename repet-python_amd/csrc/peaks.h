@@ -25,6 +25,11 @@ struct PeakArgs {
     double delta2; int* redo_list; unsigned int* redo_flag; unsigned int gen; int64_t flag_stride;
     unsigned char* records; int record_bytes; int* lite_list; unsigned int* lite_flag;
     int* frame_list; unsigned int* frame_flag; int64_t frame_clip_stride;
+    // (mode 0, peaks_wave.hip) segment records of every row: planes m1 | m2 | arg of seg_pitch entries each, row r at
+    // seg + r * 3 * seg_pitch -- the largest value of every aligned run of kSegWidth columns, the largest of its OTHER
+    // elements, the offset of the largest (NaN counted as +inf). With them the first pass looks at raw elements of the row
+    // only where a window's edge cuts a segment whose maximum lies outside it, and around near-ties.
+    const float* seg; int seg_pitch;
 };
 
 __device__ __forceinline__ void flag_row_for_exact(const PeakArgs& a, int64_t r, int clip) {

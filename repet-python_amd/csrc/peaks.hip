@@ -523,13 +523,15 @@ hipError_t launch_local_maxima_lite(const PeakArgs& a, const ExactSource& src, h
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,
                                int32_t mode, float min_value, int32_t d, int32_t number, int32_t* idx,
                                int32_t idx_pitch, int32_t* count, hipStream_t s, int64_t shift, const PeakRefine* refine,
-                               const PeakBatch* batch, void* scratch, const ExactSource* lite_src) {
+                               const PeakBatch* batch, void* scratch, const ExactSource* lite_src, const float* seg,
+                               int32_t seg_pitch) {
     if (n_rows <= 0 && !lite_src) return hipSuccess;
     if (d > n_cols) d = n_cols;                                       // a wider window changes nothing
     PeakArgs a{};
     a.M = M; a.row0 = row0; a.n = n_cols; a.pitch = pitch; a.mode = mode; a.min_value = min_value; a.d = d;
     a.number = number; a.idx = idx; a.idx_pitch = idx_pitch; a.count = count; a.shift = shift;
     a.min_value64 = min_value;
+    a.seg = seg; a.seg_pitch = seg_pitch;
     if (refine && refine->unit_rows && refine->delta > 0.0f && (refine->pitch & 3) == 0) {
         a.unit = refine->unit_rows; a.unit_pitch = refine->pitch; a.delta = refine->delta;
         a.min_value64 = refine->min_value; a.stats = refine->stats;

@@ -18,6 +18,8 @@
 // launcher falls back to the workgroup kernel.
 #include "peaks.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace repet {
@@ -82,15 +84,15 @@ struct WaveLds {
     int* cand_i; float* cand_v; float* cand_m;
 };
 
-__host__ __device__ inline size_t wave_lds_bytes(int cap) {
-    return (size_t)kBufGroups * 16 + (size_t)cap * 8 + kAmbCap * 8 + kRivalCap * 8 + kAmbCap * 4 + kRivalCap * 4 + kAmbCap * 4 +
+__host__ __device__ inline size_t wave_lds_bytes(int cap, int buf_groups = kBufGroups) {
+    return (size_t)buf_groups * 16 + (size_t)cap * 8 + kAmbCap * 8 + kRivalCap * 8 + kAmbCap * 4 + kRivalCap * 4 + kAmbCap * 4 +
            3 * kRivalCap * 2 + 2 * kAmbCap + 16;
 }
 
-__device__ __forceinline__ WaveLds carve(unsigned char* base, int cap) {
+__device__ __forceinline__ WaveLds carve(unsigned char* base, int cap, int buf_groups = kBufGroups) {
     WaveLds w;
     unsigned char* p = base;
-    w.buf = reinterpret_cast<float4*>(p); p += (size_t)kBufGroups * 16;
+    w.buf = reinterpret_cast<float4*>(p); p += (size_t)buf_groups * 16;
     unsigned char* post = p;                                  // 2 496 bytes used only after the sweep
     w.amb_exact = reinterpret_cast<double*>(p); p += kAmbCap * 8;
     w.riv_exact = reinterpret_cast<double*>(p); p += kRivalCap * 8;
@@ -511,7 +513,16 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
 }
 
 // RD = d & 3: the two window reads at run-time offsets (-d and d-w+1) then have compile-time float4 remainders
-template <int RD>
+// SEG (round 4, mode 0 only): the candidates come from the row's SEGMENT RECORDS (PeakArgs::seg) instead of a sweep over its
+// n elements. A strict maximum of a window of +-d >= 31 elements is the maximum of its own aligned 32-element segment (the
+// whole segment lies inside its window), so a row of n elements has n / 32 possible candidates, and a candidate's window
+// maximum is made of its segment's second value, the maxima of the segments that lie whole inside the window, and at most
+// two segments cut by the window's edges -- whose maximum counts as it is when its position lies inside the window, and
+// whose raw elements are looked at only when the position lies outside AND the second value could still matter. The
+// tolerance band of the near-tie refinement widens "maximum" to "within delta of the maximum": a segment whose two largest
+// values are within delta of each other has its 32 elements read. Everything behind the candidates (decide(), rivals,
+// float64 verdicts, ranking, second level) is the sweep kernel's own code: same decisions element for element.
+template <int RD, bool SEG>
 // One wavefront per WORKGROUP: rows take 30 .. 140 us (the refinement of near-ties varies), and a workgroup's LDS and
 // registers are only handed back when its last wave is done (s_memrealtime spans of every row: tools/peak_stamps.py).
 __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64_t n_rows, int lds_per_wave) {
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
     const int lane = threadIdx.x & 63, wave = 0;
     const int64_t r = (int64_t)blockIdx.x;                   // row within this launch
     if (r >= n_rows) return;
-    const WaveLds L = carve(wave_smem + (size_t)wave * lds_per_wave, a.peak_cap);
+    const WaveLds L = carve(wave_smem + (size_t)wave * lds_per_wave, a.peak_cap, a.groups);
     const int n = a.n, d = a.d;
     a.M += blockIdx.y * a.m_stride;
     a.idx += blockIdx.y * a.idx_stride;
@@ -597,8 +608,191 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
 
     int n_riv = 0, n_unl = 0;
     WSTAMP_DECL
+    // ---- SEG: the row's records, staged once (they survive a redo: nothing below touches the buffer before the row ends)
+    const int nseg = (n + kSegWidth - 1) / kSegWidth;
+    float* r1 = reinterpret_cast<float*>(L.buf);
+    float* r2 = r1 + a.seg_pitch;
+    int* ra = reinterpret_cast<int*>(r2 + a.seg_pitch);
+    if constexpr (SEG) {
+        const float* rec = a.seg + j * 3 * (int64_t)a.seg_pitch;
+        for (int s = lane; s < nseg; s += 64) {
+            r1[s] = rec[s];
+            r2[s] = rec[a.seg_pitch + s];
+            ra[s] = reinterpret_cast<const int*>(rec)[2 * a.seg_pitch + s];
+        }
+        wave_sync();
+        WSTAMP(0)
+    }
+    // One candidate per lane: element i of segment s, value v, `own` = the largest of the other elements of its segment.
+    // Wave-uniform call sites only (ballots and shuffles inside).
+    // The cut segments that have to be read are far round trips (S does not fit the caches): the candidates that are their
+    // segment's maximum -- all but a handful -- wait on a list (segment | bits << 28, the window maximum so far) and have
+    // them read side by side behind the last segment (resolve_pending); only the extra candidates of a near-tied segment
+    // read theirs on the spot.
+    int* pend_s = ra + a.seg_pitch;
+    float* pend_m = reinterpret_cast<float*>(pend_s + a.seg_pitch);
+    int n_pend = 0;
+    auto process = [&](bool have, int s, int i, float v, float own, auto deferred_tag) {
+        constexpr bool DEFER = decltype(deferred_tag)::value;
+        const bool valid = have && (v < INFINITY) && !(v < a.min_value - dlt);
+        const float lim = v - dlt;                           // a contribution below this decides nothing
+        const int lo = max(i - d, 0), hi = min(i + d, n - 1);
+        float mx = own;
+        int need = 0;                                        // bit 0 / 1: the cut segment on the left / right must be read
+#pragma unroll
+        for (int dt = -2; dt <= 2; ++dt) {
+            if (dt == 0) continue;
+            const int t = s + dt;
+            const int tc = min(max(t, 0), nseg - 1);
+            const int b0 = tc * kSegWidth, b1 = min(b0 + kSegWidth - 1, n - 1);
+            const bool overlap = valid && t >= 0 && t < nseg && b1 >= lo && b0 <= hi;
+            const float m = r1[tc], m2t = r2[tc];
+            const int at = b0 + ra[tc];
+            const bool counts = (b0 >= lo && b1 <= hi) || (at >= lo && at <= hi);     // whole inside, or its maximum is
+            if (overlap && counts) mx = fmaxf(mx, m);
+            if (overlap && !counts && !(m2t < lim)) need |= dt < 0 ? 1 : 2;
+        }
+        bool open = valid && !(v < mx - dlt);
+        if constexpr (DEFER) {
+            const bool later = open && need != 0;
+            if (__any(later)) {
+                int next;
+                const int slot = ballot_slot(later, n_pend, lane, &next);
+                if (later) { pend_s[slot] = s | (need << 28); pend_m[slot] = mx; }
+                n_pend = next;
+            }
+            open = open && need == 0;
+            need = 0;
+        }
+        const bool waiting = DEFER && valid && !open;        // (on the list, or a safe "no")
+        // the cut segments that must be read: four candidates at a time, sixteen lanes each (eight float4 per side)
+        unsigned long long pend = __ballot(open && need != 0);
+        while (pend) {                                       // (wave-uniform)
+            int from[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                from[g] = pend ? (int)__builtin_ctzll(pend) : -1;
+                if (pend) pend &= pend - 1;
+            }
+            const int g = lane >> 4, side = (lane >> 3) & 1, k = lane & 7;
+            const int mine = g == 0 ? from[0] : (g == 1 ? from[1] : (g == 2 ? from[2] : from[3]));
+            const int ci = __shfl(i, mine < 0 ? 0 : mine), cneed = __shfl(need, mine < 0 ? 0 : mine);
+            const int clo = max(ci - d, 0), chi = min(ci + d, n - 1);
+            const int t = (side ? chi : clo) / kSegWidth;
+            const int e0 = kSegWidth * t + 4 * k;
+            const int r_lo = side ? kSegWidth * t : clo, r_hi = side ? chi : min(kSegWidth * t + kSegWidth - 1, n - 1);
+            const bool act = mine >= 0 && (cneed & (side ? 2 : 1));
+            const float4 x = *reinterpret_cast<const float4*>(src + (act ? e0 : 0));
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            float mm = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (act && e0 + e >= r_lo && e0 + e <= r_hi) mm = fmaxf(mm, nan_to_inf(xs[e]));
+            // the largest of the sixteen lanes, in all of them
+            auto dpp_max = [&](float q, auto ctrl) {
+                const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, q), __builtin_bit_cast(int, q), decltype(ctrl)::value, 0xf, 0xf, false);
+                return fmaxf(q, __builtin_bit_cast(float, o));
+            };
+            mm = dpp_max(mm, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+            mm = dpp_max(mm, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+            mm = dpp_max(mm, std::integral_constant<int, 0x141>{});      // row_half_mirror
+            mm = dpp_max(mm, std::integral_constant<int, 0x140>{});      // row_mirror
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float res = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mm), 16 * q));
+                if (lane == from[q]) mx = fmaxf(mx, res);
+            }
+        }
+        open = valid && !waiting && !(v < mx - dlt);
+        if (__any(open)) {
+            if (n_cand > kCandCap - 64) decide();
+            int next;
+            const int slot = ballot_slot(open, n_cand, lane, &next);
+            if (open) { L.cand_i[slot] = i; L.cand_v[slot] = v; L.cand_m[slot] = mx; }
+            n_cand = next;
+        }
+    };
+    // Eight lanes per waiting candidate (four per side, two float4 each), eight candidates per instruction, four such groups
+    // with their loads in flight together: 32 candidates per round trip.
+    auto resolve_pending = [&]() {
+        wave_sync();
+        const int grp = lane >> 3, side = (lane >> 2) & 1, kk = lane & 3;
+        for (int b0 = 0; b0 < n_pend; b0 += 32) {
+            float4 x0[4], x1[4];
+            int cs[4], r_lo[4], r_hi[4], e0[4];
+            bool act[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = b0 + 8 * u + grp;
+                const int code = pend_s[c < n_pend ? c : 0];
+                cs[u] = code & 0x0fffffff;
+                const int ci = kSegWidth * cs[u] + ra[cs[u]];
+                const int clo = max(ci - d, 0), chi = min(ci + d, n - 1);
+                const int t = (side ? chi : clo) / kSegWidth;
+                e0[u] = kSegWidth * t + 4 * kk;
+                r_lo[u] = side ? kSegWidth * t : clo;
+                r_hi[u] = side ? chi : min(kSegWidth * t + kSegWidth - 1, n - 1);
+                act[u] = c < n_pend && ((code >> 28) & (side ? 2 : 1));
+                x0[u] = *reinterpret_cast<const float4*>(src + (act[u] ? e0[u] : 0));
+                x1[u] = *reinterpret_cast<const float4*>(src + (act[u] ? e0[u] + 16 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xs[8] = {x0[u].x, x0[u].y, x0[u].z, x0[u].w, x1[u].x, x1[u].y, x1[u].z, x1[u].w};
+                float mm = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int at = e0[u] + (e < 4 ? e : e + 12);
+                    if (act[u] && at >= r_lo[u] && at <= r_hi[u]) mm = fmaxf(mm, nan_to_inf(xs[e]));
+                }
+                auto dpp_max = [&](float q, auto ctrl) {
+                    const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, q), __builtin_bit_cast(int, q), decltype(ctrl)::value, 0xf, 0xf, false);
+                    return fmaxf(q, __builtin_bit_cast(float, o));
+                };
+                mm = dpp_max(mm, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+                mm = dpp_max(mm, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+                mm = dpp_max(mm, std::integral_constant<int, 0x141>{});      // row_half_mirror: both sides
+                const int c = b0 + 8 * u + grp;
+                const bool mine = (lane & 7) == 0 && c < n_pend;
+                const float v = r1[cs[u]];
+                const float mx = fmaxf(pend_m[mine ? c : 0], mm);
+                const bool open = mine && !(v < mx - dlt);
+                if (__any(open)) {
+                    if (n_cand > kCandCap - 64) decide();
+                    int next;
+                    const int slot = ballot_slot(open, n_cand, lane, &next);
+                    if (open) { L.cand_i[slot] = kSegWidth * cs[u] + ra[cs[u]]; L.cand_v[slot] = v; L.cand_m[slot] = mx; }
+                    n_cand = next;
+                }
+            }
+        }
+        n_pend = 0;
+    };
+    (void)process; (void)resolve_pending;
     for (;;) {
         n_peak = 0; n_amb = 0; n_cand = 0;
+        if constexpr (SEG) {
+            for (int s0 = 0; s0 < nseg; s0 += 64) {
+                const bool have = s0 + lane < nseg;
+                const int s = have ? s0 + lane : nseg - 1;
+                const float v = r1[s], own = r2[s];
+                process(have, s, kSegWidth * s + ra[s], v, own, std::true_type{});
+                // a segment whose two largest values are within delta of each other may hold more than one open element
+                unsigned long long multi = __ballot(have && dlt > 0.0f && (v < INFINITY) && !(v < a.min_value - dlt) && (v - own <= dlt));
+                while (multi) {                              // (wave-uniform)
+                    const int ss = s0 + (int)__builtin_ctzll(multi);
+                    multi &= multi - 1;
+                    const float top = r1[ss];
+                    const int ai = kSegWidth * ss + ra[ss];
+                    const int e = kSegWidth * ss + (lane & (kSegWidth - 1));
+                    const bool in = lane < kSegWidth && e < n;
+                    const float val = nan_to_inf(src[in ? e : ai]);
+                    process(in && e != ai && val >= top - dlt, ss, e, val, top, std::false_type{});
+                }
+            }
+            resolve_pending();
+            WSTAMP(2)
+        } else {
         // Chunk c + 1 is fetched (into registers) while chunk c is worked on -- the row walk is a chain of dependent steps
         // per wave, and a global load at its head would otherwise be waited for nine times per row. Only chunks that
         // lie wholly inside the row (plain 16-byte loads, no boundary cases: few registers) are fetched ahead.
@@ -737,6 +931,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
             }
             WSTAMP(2)
         }
+        }   // (!SEG)
         decide();
         WSTAMP(3)
         wave_sync();
@@ -750,6 +945,63 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
                 // "no"). The row is read again where it lies (it went through this CU's caches a moment ago).
                 const int n_near = n_amb;
                 for (int k = lane; k < n_near; k += 64) L.amb_lose[k] = 0;
+                if constexpr (SEG) {
+                    // From the records: a segment whose largest value is below the near-tied element's band holds no rival;
+                    // one whose SECOND value is below it holds at most its maximum; only the others -- and the element's
+                    // own segment, unless the element is its maximum and the second value is below the band -- are read.
+                    int* req = L.cand_i;                     // (element, segment) pairs to read: the sweep's buffer is free
+                    int n_req = 0;
+                    const int total = n_near * 5;
+                    for (int e0 = 0; e0 < total && n_riv <= kRivalCap; e0 += 64) {
+                        const int e = e0 + lane;
+                        const bool have = e < total;
+                        const int q = have ? (e * 52429) >> 18 : 0;                   // e / 5 (e < 2^14)
+                        const int dt = e - 5 * q - 2;
+                        const int i = L.amb_idx[q];
+                        const float lim = L.amb_val[q] - dlt;
+                        const int t = i / kSegWidth + dt;
+                        const int tc = min(max(t, 0), nseg - 1);
+                        const int b0 = tc * kSegWidth, b1 = min(b0 + kSegWidth - 1, n - 1);
+                        const int lo = max(i - d, 0), hi = min(i + d, n - 1);
+                        const bool overlap = have && t >= 0 && t < nseg && b1 >= lo && b0 <= hi;
+                        const float m = r1[tc], m2 = r2[tc];
+                        const int at = b0 + ra[tc];
+                        const bool scan = overlap && (dt == 0 ? !(at == i && m2 < lim) : !(m2 < lim));
+                        const bool single = overlap && dt != 0 && !scan && !(m < lim) && at >= lo && at <= hi;
+                        if (__any(single)) {
+                            int next;
+                            const int entry = ballot_slot(single, n_riv, lane, &next);
+                            if (single && entry < kRivalCap) { L.riv_owner[entry] = (short)q; L.riv_idx[entry] = at; }
+                            n_riv = next;
+                        }
+                        if (__any(scan)) {
+                            int next;
+                            const int slot = ballot_slot(scan, n_req, lane, &next);
+                            if (scan && slot < kCandCap) req[slot] = q | (tc << 8);
+                            n_req = next;
+                        }
+                    }
+                    wave_sync();
+                    if (n_req > kCandCap) n_riv = kRivalCap + 1;                      // (more than the buffer holds: a flat row)
+                    for (int rq = 0; rq < n_req && n_riv <= kRivalCap; rq += 2) {      // two requests per step, 32 lanes each
+                        const int mine = rq + (lane >> 5);
+                        const int code = req[mine < n_req ? mine : rq];
+                        const int q = code & 255, t = code >> 8;
+                        const int i = L.amb_idx[q];
+                        const float lim = L.amb_val[q] - dlt;
+                        const int lo = max(i - d, 0), hi = min(i + d, n - 1);
+                        const int k = kSegWidth * t + (lane & 31);
+                        const bool in = mine < n_req && k < n && k >= lo && k <= hi && k != i;
+                        const float val = nan_to_inf(src[in ? k : i]);
+                        const bool rival = in && val >= lim;
+                        if (__any(rival)) {
+                            int next;
+                            const int entry = ballot_slot(rival, n_riv, lane, &next);
+                            if (rival && entry < kRivalCap) { L.riv_owner[entry] = (short)q; L.riv_idx[entry] = k; }
+                            n_riv = next;
+                        }
+                    }
+                } else {
                 // All (near-tied element, window position) pairs are walked lane-parallel, 256 at a time with their
                 // loads in flight together: one near-tie after the other, each behind its own global round trip, was
                 // 7 000 cycles per near-tie and the whole of the slow rows' time. Entries come out in the same order
@@ -784,6 +1036,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
                         }
                     }
                 }
+                }   // (!SEG)
                 wave_sync();
                 // which rivals are near-tied elements themselves (they have a float64 value already), which get one of
                 // their own: one pass over the entries, the near-tie list read as LDS broadcasts
@@ -887,12 +1140,86 @@ extern "C" int repet_debug_wave_spans(unsigned long long* out, int rows) {
 }
 #endif
 
-template <int RD>
+static bool wave_shape(int n_cols, int d, int* cap_out);
+static bool wave_kernel_off();
+
+template <int RD, bool SEG = false>
 static hipError_t launch_wave_rd(const PeakArgs& a, int64_t n_rows, int n_batch, int bytes, int per_wave, hipStream_t s) {
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_wave_kernel<RD>), bytes);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_wave_kernel<RD, SEG>), bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(local_maxima_wave_kernel<RD>, dim3((unsigned)n_rows, (unsigned)n_batch), dim3(64), bytes, s, a, n_rows, per_wave);
+    hipLaunchKernelGGL((local_maxima_wave_kernel<RD, SEG>), dim3((unsigned)n_rows, (unsigned)n_batch), dim3(64), bytes, s, a, n_rows, per_wave);
     return hipGetLastError();
+}
+
+// ---- segment records of a matrix that did not come with them (the Gram kernel of the long clips writes them in its
+// epilogue, gram_f16_big.hip): one wavefront per row, eight lanes per segment (one 128-byte line per segment and step).
+// Merging two (largest, second, position) triples; the lower position wins between equal values.
+struct SegTop { float m1, m2; int at; };
+__device__ __forceinline__ SegTop seg_merge(SegTop x, SegTop y) {
+    SegTop o;
+    const bool take_y = (y.m1 > x.m1) || (y.m1 == x.m1 && y.at < x.at);
+    o.m2 = fmaxf(fminf(x.m1, y.m1), fmaxf(x.m2, y.m2));
+    o.m1 = take_y ? y.m1 : x.m1;
+    o.at = take_y ? y.at : x.at;
+    return o;
+}
+template <int CTRL>
+__device__ __forceinline__ SegTop seg_dpp(SegTop x) {
+    SegTop y;
+    y.m1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x.m1), __builtin_bit_cast(int, x.m1), CTRL, 0xf, 0xf, false));
+    y.m2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x.m2), __builtin_bit_cast(int, x.m2), CTRL, 0xf, 0xf, false));
+    y.at = __builtin_amdgcn_update_dpp(x.at, x.at, CTRL, 0xf, 0xf, false);
+    return seg_merge(x, y);
+}
+__global__ __launch_bounds__(256) void segment_maxima_kernel(const float* __restrict__ M, int64_t n_rows, int n, int64_t pitch,
+                                                             float* __restrict__ seg, int seg_pitch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* src = M + row * pitch;
+    float* rec = seg + row * 3 * (int64_t)seg_pitch;
+    const int nseg = (n + kSegWidth - 1) / kSegWidth;
+    const bool vec_ok = (pitch & 3) == 0;
+    for (int s0 = 0; s0 < nseg; s0 += 8) {
+        const int s = s0 + (lane >> 3), k = lane & 7;
+        const bool have = s < nseg;
+        const int e0 = kSegWidth * s + 4 * k;
+        float xs[4];
+        if (vec_ok) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (have ? e0 : 0));     // (readable up to the pitch)
+            xs[0] = x.x; xs[1] = x.y; xs[2] = x.z; xs[3] = x.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[e] = src[(have && e0 + e < n) ? e0 + e : 0];
+        }
+        SegTop t{-INFINITY, -INFINITY, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float val = (have && e0 + e < n) ? nan_to_inf(xs[e]) : -INFINITY;
+            t = seg_merge(t, SegTop{val, -INFINITY, 4 * k + e});
+        }
+        t = seg_dpp<0xB1>(t);        // quad_perm [1,0,3,2]
+        t = seg_dpp<0x4E>(t);        // quad_perm [2,3,0,1]
+        t = seg_dpp<0x141>(t);       // row_half_mirror: the other quad of the eight
+        if (have && k == 0) {
+            rec[s] = t.m1;
+            rec[seg_pitch + s] = t.m2;
+            reinterpret_cast<int*>(rec)[2 * seg_pitch + s] = t.at;
+        }
+    }
+}
+
+hipError_t launch_segment_maxima(const float* M, int64_t n_rows, int n_cols, int64_t pitch, float* seg, int seg_pitch, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(segment_maxima_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, s, M, n_rows, n_cols, pitch, seg, seg_pitch);
+    return hipGetLastError();
+}
+int segment_pitch(int n_cols) { return (int)round_up(ceil_div(n_cols, kSegWidth), 4); }
+bool local_maxima_segments_apply(int n_cols, int d, int64_t pitch, int mode, int n_batch) {
+    static const bool off = [] { const char* e = getenv("REPET_PEAK_SEGMENTS"); return e && e[0] == '0'; }();   // REPET_PEAK_SEGMENTS=0: the sweep
+    if (d > n_cols) d = n_cols;
+    int cap = 0;
+    return !off && !wave_kernel_off() && mode == 0 && n_batch == 1 && (pitch & 3) == 0 && d >= kSegWidth - 1 && wave_shape(n_cols, d, &cap);
 }
 
 static bool wave_shape(int n_cols, int d, int* cap_out) {
@@ -923,6 +1250,13 @@ hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_ba
     if (!wave_shape(a.n, a.d, &cap)) return hipErrorNotSupported;
     a.dl = (int)round_up(a.d, 4);
     a.peak_cap = cap;
+    a.groups = kBufGroups;
+    if (a.seg && local_maxima_segments_apply(a.n, a.d, a.pitch, a.mode, n_batch)) {
+        a.groups = std::max<int>(kBufGroups, (int)ceil_div(5 * (int64_t)a.seg_pitch * 4, 16));    // three planes + the waiting list
+        const int seg_bytes = (int)round_up((int64_t)wave_lds_bytes(cap, a.groups), 16);
+        return launch_wave_rd<0, true>(a, n_rows, n_batch, seg_bytes, seg_bytes, s);
+    }
+    a.seg = nullptr;
     const int per_wave = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
     const int bytes = per_wave;
     switch (a.d & 3) {
@@ -940,6 +1274,7 @@ hipError_t launch_local_maxima_lite(const PeakArgs& a0, const ExactSource& src, 
     if (!a.lite_list || !wave_shape(a.n, a.d, &cap)) return hipSuccess;
     a.dl = (int)round_up(a.d, 4);
     a.peak_cap = cap;
+    a.groups = kBufGroups;
     LiteSource ls{src.u64, src.u64_gen, src.u64_clip_stride, src.gen_clip_stride, src.FS, a.gen, nullptr, nullptr, 0};
     const int bytes = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&local_maxima_lite_kernel), bytes);

@@ -127,6 +127,36 @@ def test_local_maxima_exact():
                 assert np.array_equal(m[r][idx].astype(np.float64), vals) and len(set(idx)) == len(idx)
 
 
+def test_local_maxima_from_segment_records():
+    """Rows whose window reaches at least 31 elements either way are picked from SEGMENT RECORDS (largest, second largest
+    and position of every aligned 32-element run; peaks_wave.hip) instead of a sweep over the row: smooth rows (the maxima
+    of the neighbouring segments sit at their edges, so the cut segments have to be read), quantised rows (exact ties inside
+    and across segments), NaNs, thresholds in the middle of the values, lengths that end inside a segment."""
+    rs = np.random.RandomState(11)
+    for n, d, k, thr in [(1000, 31, 100, 0.0), (2081, 43, 100, 0.3), (777, 47, 7, 0.0), (4097, 63, 100, 0.55), (96, 40, 5, 0.0),
+                         (33, 31, 3, 0.0), (2500, 32, 100, 0.0)]:
+        t = np.arange(n)
+        rows = [rs.rand(n),
+                0.5 + 0.3 * np.sin(2 * np.pi * t / 73.0) + 0.1 * np.sin(2 * np.pi * t / 517.0) + 1e-3 * rs.rand(n),   # smooth
+                np.round(rs.rand(n) * 16) / 16,                                                                       # many exact ties
+                0.5 + 0.4 * np.sin(2 * np.pi * t / (2.0 * d + 1.0)),                                                  # peaks one window apart
+                np.where(rs.rand(n) < 0.01, np.nan, rs.rand(n)),
+                np.full(n, 0.25)]
+        rows[4][n // 2] = np.nan
+        for r, row in enumerate(rows):
+            m = row.astype(np.float32)
+            vals, idx = repet._localmaxima(m, thr, d, k)
+            wv, wi = orc.localmaxima(m.astype(np.float64), thr, d, k)
+            assert len(idx) == len(wi), (n, d, k, r)
+            if len(np.unique(wv)) == len(wv):
+                assert np.array_equal(idx, wi), (n, d, k, r)
+            else:                                            # exact ties among the survivors: any tied element may sit at the cut
+                assert np.array_equal(np.sort(vals), np.sort(wv)), (n, d, k, r)
+                assert np.array_equal(m[idx].astype(np.float64), vals) and len(set(idx)) == len(idx)
+                if len(wi) < k:
+                    assert set(idx.tolist()) == set(wi.tolist()), (n, d, k, r)
+
+
 def test_indices_on_similarity_matrix(clip):
     x, fs = clip
     w, window, h = orc.stft_geometry(fs)

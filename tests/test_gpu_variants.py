@@ -1031,6 +1031,22 @@ def test_second_level_paths_agree():
         assert off[key]["cnt"] == base[key]["cnt"]
 
 
+def test_segment_record_paths_agree():
+    """Round 4: the first pass of the peak picking takes its candidates from segment records -- written by the epilogue of the
+    256 x 256 Gram kernel (clips from 2 048 frames on) or by a pass over the matrix (shorter clips, the other Gram kernels).
+    REPET_PEAK_SEGMENTS=0 restores the sweep over every element of the row, REPET_GRAM_SEGMENTS=0 takes the records from the
+    pass over the matrix also behind the 256 x 256 kernel: lists, list lengths, second-level statistics and audio must be
+    the default's, bit for bit."""
+    base = _lists_under({})
+    for env in ({"REPET_PEAK_SEGMENTS": "0"}, {"REPET_GRAM_SEGMENTS": "0"}):
+        other = _lists_under(env)
+        for key in base:
+            assert other[key]["cnt"] == base[key]["cnt"], (env, key)
+            assert other[key]["idx"] == base[key]["idx"], (env, key)
+            assert other[key]["sum"] == base[key]["sum"], (env, key)
+            assert other[key]["exact"] == base[key]["exact"], (env, key)
+
+
 def test_remainders_of_float64_input_travel_only_when_needed():
     """A float64 clip whose samples are exact in fp32 (what wavread yields for PCM files, repet.py:929) uploads no remainders;
     the synth clip (float64 noise) does, and dropping them changes nothing audible (same lists on this clip)."""
