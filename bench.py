@@ -122,6 +122,25 @@ def main():
                     help="length of the CPU-baseline clip (default: the whole config-2 clip, ~25 s of host time)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started as plain `python bench.py --gpus N`: this process becomes the launcher. It starts the N ranks as a CHILD
+        # (python -m torch.distributed.run, one rank per GPU over RCCL) before anything here has touched the GPU -- counting
+        # the devices does not -- relays the ranks' output (rank 0 prints the one JSON line) and exits with the child's code.
+        import socket
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s)")
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write(f"[bench] --gpus {args.gpus} without RANK in the environment: launching {' '.join(cmd)}\n")
+        sys.stderr.flush()
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     example_clip = None
     if args.config == 1:
         import scipy.io.wavfile            # the clip is not redistributed with this repository: build container only
@@ -140,8 +159,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE {world}: the two must agree "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}, or plain python bench.py --gpus {args.gpus})")
 
     import ctypes
     import numpy as np
@@ -160,6 +180,8 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")    # ... and its warnings (topology, iommu) on stderr
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL communicator of {dist.get_world_size()} rank(s) for --gpus {args.gpus}")
 
     fs, channels = args.fs, args.channels
     params = repet.derive_params(fs)
@@ -353,7 +375,7 @@ def main():
             "metric": f"audio-seconds/sec (x real-time) for repet.{args.algo}, {fs / 1000:g} kHz {'stereo' if channels == 2 else str(channels) + '-ch'}",
             "value": round(args.duration * args.clips * args.steps * world / elapsed, 2),
             "unit": "audio-seconds/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "series_ms_per_step": [round(e / max(args.steps, 1) * 1e3, 3) for e in all_elapsed],
             "ms_per_step_min": round(min(all_elapsed) / max(args.steps, 1) * 1e3, 3),
@@ -402,7 +424,7 @@ def main():
             import subprocess
             try:
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                        "--series", "3", "--no-cpu-baseline", "--no-scatter", "--no-variants"],
+                                        "--series", "1", "--no-cpu-baseline", "--no-scatter", "--no-variants"],     # (one timed region: a few seconds)
                                        env=dict(os.environ, REPET_GRAM="f32"), capture_output=True, text=True, timeout=600)
                 cj = json.loads(child.stdout.strip().splitlines()[-1])
                 gemm = [st for st in cj["stages"] if st["name"].startswith("similarity_gemm")][0]
@@ -449,7 +471,8 @@ def main():
             bail(f"{type(exc).__name__}: {exc}", traceback.format_exc())
         watchdog.cancel()
         if not once.acquire(blocking=False):         # the watchdog fired while the leg was finishing: it owns the output
-            time.sleep(3600)
+            time.sleep(30)                           # (it ends the process itself; if it has not by then, this does)
+            os._exit(1)
         if rank == 0 and scatter is not None:
             line["scatter_gather"] = scatter
     if dist is not None:

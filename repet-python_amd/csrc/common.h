@@ -256,6 +256,12 @@ constexpr int kRefineStats = 32;   // counters behind PeakRefine::stats: [0] row
                                    // [8] largest |level 1 - level 2| in units of 1e-12, [9] float64 unit rows computed,
                                    // [10] frames queued for float64 spectra, [11] the queue's cursor, [12] rows with a record
                                    // (fast path), [13] their cursor, [14] rows the fast path handed on to the general one
+// The counters that only COUNT (diagnostics: [0]-[3], [6]-[9], [14]) are kept in kStatShards copies, each on a cache line of
+// its own, and added up when they are read (stat_total): thousands of wavefronts adding to ONE word inside a few
+// microseconds are served at about 88 per microsecond, which a short kernel then waits for. The counters the device
+// itself reads (list lengths and cursors: [4], [5], [10]-[13]) live in copy 0 only.
+constexpr int kStatShards = 64;
+constexpr int kStatWords = kRefineStats * (kStatShards + 1);
 struct PeakRefine {
     const float* unit_rows; int32_t pitch; float delta; double min_value; unsigned int* stats;
     double delta2; int32_t* redo_list; unsigned int* redo_flag; unsigned int gen; int64_t flag_stride;

@@ -449,7 +449,7 @@ int ensure_spectra(repet_ctx* c, const Geo& g, bool want_vn, bool want_p, int B 
     if ((size_t)g.chan_stride * 4 >= (size_t)1 << 31) return fail(REPET_ERR_LIMIT, "clip too long: one channel's spectrogram must stay below 2 GiB");
     const size_t mean_elems = (size_t)g.Tpad * g.FS;
     if (want_vn) HIP_TRY(c->Vn.ensure(B * mean_elems * sizeof(float)));
-    HIP_TRY(c->refine_stats.ensure(kRefineStats * sizeof(unsigned int)));
+    HIP_TRY(c->refine_stats.ensure(kStatWords * sizeof(unsigned int)));
     // one launch: the pad rows of V, zeros over the rows [T, Tpad) of every clip's unit spectra (the Gram tiles read
     // them), the counters of the peak refinement (make_refine then skips its own clear)
     if (p_planes && !want_vn) HIP_TRY(c->Vh.ensure((size_t)B * mean_elems * 4));
@@ -884,8 +884,8 @@ int ensure_stamps(repet_ctx* c, DevBuf& buf, size_t count) {
 // rows per clip (the float64 unit-row table)
 int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, PeakRefine* rf, int64_t rows = 0, int clips = 1,
                 int n_cols = 0, int d = 0, int64_t frames = 0) {
-    HIP_TRY(c->refine_stats.ensure(kRefineStats * sizeof(unsigned int)));
-    if (!c->refine_stats_cleared) HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, kRefineStats * sizeof(unsigned int), c->stream));
+    HIP_TRY(c->refine_stats.ensure(kStatWords * sizeof(unsigned int)));
+    if (!c->refine_stats_cleared) HIP_TRY(hipMemsetAsync(c->refine_stats.p, 0, kStatWords * sizeof(unsigned int), c->stream));
     c->refine_stats_cleared = false;
     *rf = PeakRefine{};
     rf->unit_rows = unit_rows; rf->pitch = FS; rf->delta = peak_refine_delta(FS, gram_f16_enabled()); rf->min_value = threshold;
@@ -1345,6 +1345,7 @@ int repet_ctx_destroy(repet_ctx* c) {
                       &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
                       &c->audio_lo, &c->redo_list, &c->redo_flag, &c->u64, &c->u64_gen, &c->exact_scratch,
                       &c->lite_list, &c->lite_flag, &c->lite_records, &c->frame_list, &c->frame_flag,
+                      &c->seg,
                       &c->idx, &c->cnt, &c->periods, &c->win_periods, &c->frames, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tiles})
         b->release();
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); kv.second->window64.release(); kv.second->twiddle64.release(); }
@@ -2340,6 +2341,18 @@ int repet_ctx_last_frame_count(repet_ctx* c, int64_t* n_frames) {
     return REPET_OK;
 }
 
+// the counters of the last run, the copies of every diagnostic counter added up ([8] is a maximum) -- common.h, kStatShards
+static int read_stats(repet_ctx* c, unsigned int (&total)[kRefineStats]) {
+    std::vector<unsigned int> words(kStatWords);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(words.data(), c->refine_stats.p, kStatWords * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < kRefineStats; ++k) total[k] = words[k];
+    for (int sh = 1; sh <= kStatShards; ++sh)
+        for (int k = 0; k < kRefineStats; ++k)
+            total[k] = (k == 8) ? std::max(total[k], words[sh * kRefineStats + k]) : total[k] + words[sh * kRefineStats + k];
+    return REPET_OK;
+}
+
 int repet_ctx_last_exact_stats(repet_ctx* c, int64_t out[8]) {
     if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
     for (int k = 0; k < 8; ++k) out[k] = 0;
@@ -2347,8 +2360,7 @@ int repet_ctx_last_exact_stats(repet_ctx* c, int64_t out[8]) {
     if (!c->refine_stats.p) return REPET_OK;
     DeviceGuard guard(c->device);
     unsigned int host[kRefineStats] = {};
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(host, c->refine_stats.p, sizeof(host), hipMemcpyDeviceToHost));
+    RP_TRY(read_stats(c, host));
     out[0] = host[4] + host[12] - host[14]; out[1] = host[6]; out[2] = host[7]; out[3] = host[8]; out[4] = host[9];
     out[6] = host[12]; out[7] = host[14];
     return REPET_OK;
@@ -2357,8 +2369,7 @@ int repet_ctx_last_exact_stats(repet_ctx* c, int64_t out[8]) {
 #ifdef REPET_EXACT_STAMPS
 int repet_debug_exact_phases(repet_ctx* c, int64_t out[6]) {
     unsigned int host[kRefineStats] = {};
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(host, c->refine_stats.p, sizeof(host), hipMemcpyDeviceToHost));
+    RP_TRY(read_stats(c, host));
     for (int k = 0; k < 6; ++k) out[k] = host[24 + k];
     return REPET_OK;
 }
@@ -2369,9 +2380,8 @@ int repet_ctx_last_refine_stats(repet_ctx* c, int64_t out[4]) {
     for (int k = 0; k < 4; ++k) out[k] = 0;
     if (!c->refine_stats.p) return REPET_OK;
     DeviceGuard guard(c->device);
-    unsigned int host[4] = {0, 0, 0, 0};
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(host, c->refine_stats.p, sizeof(host), hipMemcpyDeviceToHost));
+    unsigned int host[kRefineStats] = {};
+    RP_TRY(read_stats(c, host));
     for (int k = 0; k < 4; ++k) out[k] = host[k];
     return REPET_OK;
 }

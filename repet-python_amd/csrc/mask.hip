@@ -168,7 +168,7 @@ __global__ void fill_pad_rows_kernel(float* V, int64_t chan_stride, int n_channe
         *reinterpret_cast<float4*>(Z + y * z_stride + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Z2) *reinterpret_cast<float4*>(Z2 + y * z_stride + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);     // a second array of the same geometry
     }
-    if (stats && y == 0 && k < kRefineStats) stats[k] = 0u;
+    if (stats && y == 0 && k < kStatWords) stats[k] = 0u;           // (every copy of the counters: common.h, kStatShards)
 }
 
 hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channels, int64_t pad_row, int32_t FS,
@@ -176,7 +176,7 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
     if (!Z && Z2) { Z = Z2; Z2 = nullptr; }
     if (!Z || z_count <= 0) { Z = nullptr; Z2 = nullptr; z_count = 0; n_z = 0; }
     if ((z_count & 3) || (z_stride & 3)) return hipErrorInvalidValue;
-    const int64_t per_row = std::max<int64_t>(2 * FS, z_count / 4);
+    const int64_t per_row = std::max<int64_t>(std::max<int64_t>(2 * FS, z_count / 4), stats ? kStatWords : 0);
     hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)ceil_div(per_row, 256), (unsigned)std::max(n_channels, n_z)), dim3(256), 0, s,
                        V, chan_stride, n_channels, pad_row, FS, Z, z_stride, z_count, n_z, stats, Z2);
     return hipGetLastError();

@@ -32,6 +32,13 @@ struct PeakArgs {
     const float* seg; int seg_pitch;
 };
 
+// diagnostics counters (common.h: kStatShards): the copy of this workgroup
+__device__ __forceinline__ void stat_add(unsigned int* stats, int k, unsigned int v) {
+    atomicAdd(&stats[kRefineStats * (1 + (int)(blockIdx.x & (kStatShards - 1))) + k], v);
+}
+__device__ __forceinline__ void stat_max(unsigned int* stats, int k, unsigned int v) {
+    atomicMax(&stats[kRefineStats * (1 + (int)(blockIdx.x & (kStatShards - 1))) + k], v);
+}
 __device__ __forceinline__ void flag_row_for_exact(const PeakArgs& a, int64_t r, int clip) {
     if (!a.redo_list) return;
     if (atomicExch(a.redo_flag + (int64_t)clip * a.flag_stride + r, a.gen) != a.gen) {

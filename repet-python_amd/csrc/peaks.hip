@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
         __syncthreads();
         if (tid == 0) {
             n_peak = 0; n_amb = 0; n_riv = 0; n_unl = 0;
-            if (a.stats) { atomicAdd(&a.stats[3], 1u); flag_row_for_exact(a, r, blockIdx.y); }    // (the second level decides the row again)
+            if (a.stats) { stat_add(a.stats, 3, 1u); flag_row_for_exact(a, r, blockIdx.y); }    // (the second level decides the row again)
         }
         dlt = 0.0f;
         __syncthreads();
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
             changed += (win != (amb_ok[k] != 0));
         }
         if (a.stats) {
-            if (tid == 0) { atomicAdd(&a.stats[0], 1u); atomicAdd(&a.stats[1], (unsigned)n_near); }
-            if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+            if (tid == 0) { stat_add(a.stats, 0, 1u); stat_add(a.stats, 1, (unsigned)n_near); }
+            if (changed) stat_add(a.stats, 2, (unsigned)changed);
         }
         __syncthreads();
     }
@@ -464,10 +464,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QMAX <= 8 ?
                     changed += (keep != (amb_ok[k] != 0));
                 }
                 if (a.stats) {
-                    if (tid == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
-                    if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+                    if (tid == 0) stat_add(a.stats, 1, (unsigned)n_band);
+                    if (changed) stat_add(a.stats, 2, (unsigned)changed);
                 }
-            } else if (a.stats && tid == 0) { atomicAdd(&a.stats[3], 1u); n_close = 1; }
+            } else if (a.stats && tid == 0) { stat_add(a.stats, 3, 1u); n_close = 1; }
         }
     }
     __syncthreads();

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * kUnitWaves) void unit_rows_f64_kernel(UnitRows
         unit_row_variant<V>(x.src, x.logM, clip, fr, Zw, accw, tws, rtw, lane);
         if (lane == 0) {
             *g = x.gen;
-            atomicAdd(&x.stats[9], 1u);
+            stat_add(x.stats, 9, 1u);
         }
     }
 }
@@ -496,7 +496,6 @@ template <int KQ>
 __global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
     constexpr int kWgQ = KQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
-    __shared__ unsigned int sh_slot;
     __shared__ double red[4];
     const ExactSource& s = x.src;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -507,17 +506,12 @@ __global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
     for (int k = tid; k < M; k += 256) tw[k] = s.twiddle64[2 * k];
     const unsigned int n_frames = x.stats[10];
     const int nq = (M + 255) >> 8;            // point pairs per thread (1 .. 16 for M = 4096: loops below run over q < nq)
-    for (;;) {
+    // (frames dealt by position: a shared cursor hands out about 88 slots per microsecond, and the 1 024 workgroups' first
+    // requests alone took 12 us)
+    for (unsigned int slot = blockIdx.x; slot < n_frames; slot += gridDim.x) {
         __syncthreads();
-        if (tid == 0) {
-            unsigned int k = atomicAdd(&x.stats[11], 1u);
-            while (k < n_frames && s.u64_gen[x.frame_list[k]] == x.gen) k = atomicAdd(&x.stats[11], 1u);     // (already there)
-            sh_slot = k;
-        }
-        __syncthreads();
-        const unsigned int slot = sh_slot;
-        if (slot >= n_frames) return;
         const int64_t lin = x.frame_list[slot];
+        if (s.u64_gen[lin] == x.gen) continue;                 // already there (workgroup-uniform)
         const int clip = (int)(lin / s.gen_clip_stride);
         const int64_t fr = lin - (int64_t)clip * s.gen_clip_stride;
         unsigned int* g = s.u64_gen + lin;
@@ -651,7 +645,7 @@ __global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
             const int k = tid + 256 * q;
             if (k < s.FS) out[k] = (k < F) ? acc[q] / nrm : 0.0;
         }
-        if (tid == 0) { *g = x.gen; atomicAdd(&x.stats[9], 1u); }
+        if (tid == 0) { *g = x.gen; stat_add(x.stats, 9, 1u); }
     }
 }
 
@@ -840,7 +834,7 @@ __global__ __launch_bounds__(kExactThreads) void local_maxima_exact_kernel(Exact
                     __threadfence();
                     if (lane == 0) {
                         __hip_atomic_store(&gens[fr], x.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        atomicAdd(&stats[9], 1u);
+                        stat_add(stats, 9, 1u);
                     }
                 }
             }
@@ -858,8 +852,8 @@ __global__ __launch_bounds__(kExactThreads) void local_maxima_exact_kernel(Exact
                     R.val[i] = e;
                 }
             }
-            if (lane == 0 && worst > 0.0) atomicMax(&stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
-            if (tid == 0) atomicAdd(&stats[6], (unsigned)items);
+            if (lane == 0 && worst > 0.0) stat_max(stats, 8, (unsigned)fmin(worst * 1e12, 4.0e9));
+            if (tid == 0) stat_add(stats, 6, (unsigned)items);
             __syncthreads();
         };
         // best[q] = 1 + the bit pattern of the largest rival value of near-tied element q (0: no rival). Similarities of
@@ -1009,7 +1003,7 @@ __global__ __launch_bounds__(kExactThreads) void local_maxima_exact_kernel(Exact
         const int any = __syncthreads_or(differs);
         if (tid == 0) {
             a.count[r] = kept;
-            if (any) atomicAdd(&stats[7], 1u);
+            if (any) stat_add(stats, 7, 1u);
         }
         XSTAMP(5)
     }

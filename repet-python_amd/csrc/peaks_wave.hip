@@ -147,8 +147,8 @@ __device__ __forceinline__ bool rank_cut_band(const PeakArgs& a, const WaveLds& 
         high_dropped = fmax(high_dropped, __shfl_xor(high_dropped, sh));
     }
     if (count_stats) {
-        if (lane == 0) atomicAdd(&a.stats[1], (unsigned)n_band);
-        if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+        if (lane == 0) stat_add(a.stats, 1, (unsigned)n_band);
+        if (changed) stat_add(a.stats, 2, (unsigned)changed);
     }
     const bool settled = !(low_kept - high_dropped < a.delta2) || !(a.redo_list || LEVEL2);
     wave_sync();
@@ -198,8 +198,8 @@ __device__ __forceinline__ void finish_band_level2(const PeakArgs& a, const Wave
     wave_sync();
     if (!have) { *missing = true; return; }
     if (lane == 0 && a.stats) {
-        atomicAdd(&a.stats[6], (unsigned)n2);
-        if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
+        stat_add(a.stats, 6, (unsigned)n2);
+        if (worst > 0.0) stat_max(a.stats, 8, (unsigned)fmin(worst * 1e12, 4.0e9));
     }
     for (int k = lane; k < n_band; k += 64) {
         const double e = L.amb_exact[k];
@@ -375,15 +375,15 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                 wave_sync();
                 if (!have) { *missing = true; return; }
                 if (lane == 0 && a.stats) {
-                    atomicAdd(&a.stats[6], (unsigned)n2);
-                    if (worst > 0.0) atomicMax(&a.stats[8], (unsigned)fmin(worst * 1e12, 4.0e9));
+                    stat_add(a.stats, 6, (unsigned)n2);
+                    if (worst > 0.0) stat_max(a.stats, 8, (unsigned)fmin(worst * 1e12, 4.0e9));
                 }
                 verdicts();
                 bool differs = false;
                 for (int k = lane; k < n_near; k += 64)
                     differs = differs || (((!L.amb_lose[k] && L.amb_exact[k] >= a.min_value64) ? 1 : 0) != L.amb_ok[k]);
                 if (!__any(differs)) { *unchanged = true; return; }         // the first pass's list stands (up to its cut band)
-                if (lane == 0 && a.stats) atomicAdd(&a.stats[7], 1u);
+                if (lane == 0 && a.stats) stat_add(a.stats, 7, 1u);
                 for (int p = lane; p < ls->rec_np; p += 64) { L.pval[p] = ls->rec_pval[p]; L.pidx[p] = ls->rec_pidx[p]; }
                 wave_sync();
             }
@@ -403,8 +403,8 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
             n_peak = next;
         }
         if (a.stats && !LEVEL2) {
-            if (lane == 0) { atomicAdd(&a.stats[0], 1u); atomicAdd(&a.stats[1], (unsigned)n_near); }
-            if (changed) atomicAdd(&a.stats[2], (unsigned)changed);
+            if (lane == 0) { stat_add(a.stats, 0, 1u); stat_add(a.stats, 1, (unsigned)n_near); }
+            if (changed) stat_add(a.stats, 2, (unsigned)changed);
         }
         wave_sync();
     }
@@ -503,7 +503,7 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
                     }
                 }
             } else if (lane == 0) {
-                if (a.stats && !LEVEL2) atomicAdd(&a.stats[3], 1u);
+                if (a.stats && !LEVEL2) stat_add(a.stats, 3, 1u);
                 flag_row_for_exact(a, r, clip);                // a flat cut: the general second level
             }
         }
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
         }
         WSTAMP(6)                                             // rivals of the near-tied elements
         if (!redo) break;
-        if (a.stats && lane == 0) { atomicAdd(&a.stats[3], 1u); flag_row_for_exact(a, r, blockIdx.y); }   // redo the test with the plain
+        if (a.stats && lane == 0) { stat_add(a.stats, 3, 1u); flag_row_for_exact(a, r, blockIdx.y); }   // redo the test with the plain
         dlt = 0.0f;                                                // fp32 decisions (the second level decides the row again)
     }
     wave_sync();
@@ -1069,7 +1069,6 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
     WSTAMP_OUT
 }
 
-
 // The rows the first pass left records of (see wave_finish_row), one wavefront per row, taken from the list until it is
 // empty (fixed grid). A row whose float64 unit rows are not all there (its band changed with the level-2 verdicts) goes
 // to the general kernel (peaks_exact.hip), which runs next on the stream.
@@ -1078,11 +1077,9 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
     const int lane = threadIdx.x & 63;
     const WaveLds L = carve(lite_smem, a0.peak_cap);
     const unsigned int n_rows = a0.stats[12];
-    for (;;) {
-        unsigned int slot = 0;
-        if (lane == 0) slot = atomicAdd(&a0.stats[13], 1u);
-        slot = __shfl(slot, 0);
-        if (slot >= n_rows) return;
+    // (rows dealt by position, not from a shared cursor: one word hands out about 88 slots per microsecond, and 2 048
+    // wavefronts asking at once -- most of them only to learn that the list is empty -- took 25 of the kernel's 45 us)
+    for (unsigned int slot = blockIdx.x; slot < n_rows; slot += gridDim.x) {
         PeakArgs a = a0;
         const int64_t r = a.lite_list[2 * slot];
         const int clip = a.lite_list[2 * slot + 1];
@@ -1123,7 +1120,7 @@ __global__ __launch_bounds__(64) void local_maxima_lite_kernel(PeakArgs a0, Lite
             if (!rank_cut_band<true>(a, L, lane, h.n_band, h.n_above, out, out_index, false))
                 finish_band_level2(a, L, lane, h.n_band, h.n_above, out, out_index, elem_frame, ls, clip, self_frame, &missing);
         }
-        if (missing && lane == 0) { atomicAdd(&a.stats[14], 1u); flag_row_for_exact(a, r, clip); }
+        if (missing && lane == 0) { stat_add(a.stats, 14, 1u); flag_row_for_exact(a, r, clip); }
         wave_sync();
     }
 }
@@ -1251,20 +1248,23 @@ hipError_t launch_local_maxima_wave(const PeakArgs& a0, int64_t n_rows, int n_ba
     a.dl = (int)round_up(a.d, 4);
     a.peak_cap = cap;
     a.groups = kBufGroups;
+    hipError_t e;
     if (a.seg && local_maxima_segments_apply(a.n, a.d, a.pitch, a.mode, n_batch)) {
         a.groups = std::max<int>(kBufGroups, (int)ceil_div(5 * (int64_t)a.seg_pitch * 4, 16));    // three planes + the waiting list
         const int seg_bytes = (int)round_up((int64_t)wave_lds_bytes(cap, a.groups), 16);
-        return launch_wave_rd<0, true>(a, n_rows, n_batch, seg_bytes, seg_bytes, s);
+        e = launch_wave_rd<0, true>(a, n_rows, n_batch, seg_bytes, seg_bytes, s);
+    } else {
+        a.seg = nullptr;
+        const int per_wave = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
+        const int bytes = per_wave;
+        switch (a.d & 3) {
+            case 0: e = launch_wave_rd<0>(a, n_rows, n_batch, bytes, per_wave, s); break;
+            case 1: e = launch_wave_rd<1>(a, n_rows, n_batch, bytes, per_wave, s); break;
+            case 2: e = launch_wave_rd<2>(a, n_rows, n_batch, bytes, per_wave, s); break;
+            default: e = launch_wave_rd<3>(a, n_rows, n_batch, bytes, per_wave, s); break;
+        }
     }
-    a.seg = nullptr;
-    const int per_wave = (int)round_up((int64_t)wave_lds_bytes(cap), 16);
-    const int bytes = per_wave;
-    switch (a.d & 3) {
-        case 0: return launch_wave_rd<0>(a, n_rows, n_batch, bytes, per_wave, s);
-        case 1: return launch_wave_rd<1>(a, n_rows, n_batch, bytes, per_wave, s);
-        case 2: return launch_wave_rd<2>(a, n_rows, n_batch, bytes, per_wave, s);
-        default: return launch_wave_rd<3>(a, n_rows, n_batch, bytes, per_wave, s);
-    }
+    return e;
 }
 
 // the rows on PeakArgs::lite_list (count on the device): fixed grid of one-wave workgroups

@@ -4,7 +4,7 @@ out="$GRAFT_REPO_ROOT/gpurun_out/r04b"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 900 python3 -m pytest tests/test_gpu_stages.py -x -q -m gpu -k "local_maxima or indices" > "$out/t1.log" 2>&1; echo "t1 rc $?"
 tail -3 "$out/t1.log"
-timeout 900 python3 -m pytest tests/test_gpu_variants.py -x -q -m gpu -k "segment_record or similar_frame" > "$out/t2.log" 2>&1; echo "t2 rc $?"
+timeout 900 python3 -m pytest tests/test_gpu_variants.py -x -q -m gpu -k "segment_record or similar_frame or second_level or online" > "$out/t2.log" 2>&1; echo "t2 rc $?"
 tail -3 "$out/t2.log"
 PEAK_PHASES=1 timeout 600 python3 tools/peak_stamps.py > "$out/stamps.txt" 2>&1; echo "stamps rc $?"
 grep -v "^  t = " "$out/stamps.txt" | grep -A8 "fastest half"
