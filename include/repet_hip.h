@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REPET_ABI_VERSION 1
+#define REPET_ABI_VERSION 2
 
 typedef enum repet_status {
     REPET_OK = 0,
@@ -128,6 +128,12 @@ int repet_ctx_download(repet_ctx* ctx, double* out);
  * fp32 interleaved [n_clips][n_samples][n_channels], device (or peer-accessible) memory, complete on return (the
  * producer of dev_audio must have finished; dev_out may be handed to a collective right away). */
 int repet_ctx_upload_device(repet_ctx* ctx, const float* dev_audio, int64_t n_samples, int32_t n_channels, int32_t n_clips);
+/* (ABI 2) The same with the fp32 REMAINDERS of a float64 waveform beside its fp32 samples: dev_audio_lo[i] = (float)(x[i] -
+ * (double)(float)x[i]) (nullable: none). repet.py computes in float64 throughout (:149, :1223, :1318-1326); the engine takes
+ * the few float64 decisions of its peak picking from sample + remainder = 48 bits of the caller's double, and a waveform
+ * that reaches a device over RCCL must carry them to be separated exactly as the same waveform passed to repet_run is. */
+int repet_ctx_upload_device_split(repet_ctx* ctx, const float* dev_audio, const float* dev_audio_lo, int64_t n_samples,
+                                  int32_t n_channels, int32_t n_clips);
 int repet_ctx_download_device(repet_ctx* ctx, float* dev_out);
 /* Declare the resident samples to be [sample0, sample0 + n_samples) of a clip of n_total samples, for
  * repet_ctx_execute_extended_range: a rank of a multi-GPU `extended` then holds (and returns) only the samples its own
@@ -215,10 +221,16 @@ int repet_run(int algo, const void* audio, int dtype, int64_t n_samples, int32_t
 int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype,
                     const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
                     double* const* out, int32_t n_devices);
-/* The same with the waveforms travelling over xGMI: the clips enter through device 0, go to their devices as
- * ONE group of ncclSend / ncclRecv (fp32, interleaved; ncclCommInitAll over devices 0 .. n_devices-1, librccl opened on
- * first use), are separated from the received device buffers, and the results return the same way. repet_run_batch takes
- * this path when REPET_BATCH_TRANSPORT=rccl. */
+/* The same with the waveforms travelling over xGMI: the clips enter through device 0 and are worked through in
+ * rounds of one clip per device -- a round goes to its devices as ONE group of ncclSend / ncclRecv (fp32, interleaved; a
+ * float64 clip as two planes, samples and remainders; ncclCommInitAll over devices 0 .. n_devices-1, cached; librccl opened
+ * on first use), is separated from the received device buffers while the root stages the next round, and its results
+ * return in a group of their own. repet_run_batch takes this path when REPET_BATCH_TRANSPORT=rccl.
+ * REPET_RCCL_SELF=1 with n_devices == 1 (test switch): every clip is sent by device 0 to itself inside the group.
+ * repet_last_batch_info: what the calling thread's last batch call did -- out[0] transport (0 host, 1 RCCL), out[1] clips that
+ * went through send / receive, out[2] clips whose remainder plane was resident when they were separated, out[3] RCCL groups
+ * completed. */
+int repet_last_batch_info(int64_t out[4]);
 int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype,
                          const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
                          double* const* out, int32_t n_devices);

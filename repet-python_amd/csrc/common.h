@@ -81,7 +81,19 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
 #ifdef REPET_IEEE_SQRT
 __device__ __forceinline__ float magnitude(float2 x) { return sqrtf(fmaf(x.x, x.x, mul_rounded(x.y, x.y))); }
 #else
-__device__ __forceinline__ float magnitude(float2 x) { return __builtin_amdgcn_sqrtf(fmaf(x.x, x.x, mul_rounded(x.y, x.y))); }
+// v_sqrt_f32 takes no denormal input and the squares of a spectrum below 1e-19 underflow: such a bin (a frame that is silent
+// but for noise at the bottom of the fp32 range) goes the long way round, scaled by 2^64 -- a compare and a branch that is
+// practically never taken. (A purely real bin -- DC, Nyquist -- is sqrt(x * x), within
+// one ulp of the |x| np.abs returns; the forward and the inverse kernels share this function, so they agree to the bit.)
+__device__ __forceinline__ float magnitude(float2 x) {
+    const float s = fmaf(x.x, x.x, mul_rounded(x.y, x.y));
+    float r = __builtin_amdgcn_sqrtf(s);
+    if (__builtin_expect(s < 1.0e-30f, 0)) {                    // (an exact zero takes this way too, and comes out as zero)
+        const float a = x.x * 18446744073709551616.0f, b = x.y * 18446744073709551616.0f;
+        r = sqrtf(fmaf(a, a, b * b)) * 5.421010862427522e-20f;
+    }
+    return r;
+}
 #endif
 
 // w(n) of `extended` (segment_weight, common.h) for positions inside ONE segment, in 32-bit arithmetic; inv_in / inv_ov
@@ -325,7 +337,7 @@ __device__ __forceinline__ float soft_mask(float v, float model, int f, int cuto
 #else
     // the quotient by the hardware reciprocal (1 ulp) and one product; where the model is not below the magnitude the
     // quotient is x / x = 1 exactly in the reference, so it is 1 here too (the reciprocal alone could say 1 - 2^-24)
-    const float q = (model + kMaskEps) * __builtin_amdgcn_rcpf(v + kMaskEps);
+    const float q = fminf((model + kMaskEps) * __builtin_amdgcn_rcpf(v + kMaskEps), 1.0f);      // (never 1 + an ulp)
     const float m = (model >= v) ? 1.0f : q;
 #endif
     // fminf drops a NaN model; np.minimum propagates it (empty similarity list -> NaN frame)
@@ -388,16 +400,23 @@ struct StagingRing {
     static constexpr size_t kSlotElems = (size_t)1 << 20;      // 4 MB of fp32 per slot
     float* base = nullptr;
     float* base_lo = nullptr;      // second ring for the fp32 remainders of float64 uploads (ensure_lo)
+    // deferred remainders (staged_upload with a second stream): the whole remainder plane is staged in pinned memory of its
+    // own while the samples travel, and follows them on the other stream
+    float* lo_full = nullptr; size_t lo_full_elems = 0; hipEvent_t hi_done = nullptr, lo_done = nullptr; bool lo_in_flight = false;
     hipEvent_t event[kSlots] = {};
     bool busy[kSlots] = {};
     hipError_t ensure();
     hipError_t ensure_lo();
+    hipError_t ensure_lo_full(size_t elems);
     void release();
     ~StagingRing();
 };
 // dtype: 0 float32, 1 float64, 2 int16 (REPET_F32 / F64 / I16)
+// s_lo (nullable): the remainders follow the samples on this stream, behind the last chunk of samples: what is enqueued on
+// `s` after the call starts as soon as the SAMPLES are there, and whoever reads dst_lo waits for ring.lo_done first
 hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s,
-                         float* dst_lo = nullptr, bool* any_lo = nullptr);
+                         float* dst_lo = nullptr, bool* any_lo = nullptr, hipStream_t s_lo = nullptr, bool* not_finite = nullptr);
+// not_finite (nullable): set when a sample of src is NaN or infinite
 hipError_t staged_download(StagingRing& ring, const float* src, double* dst, size_t count, hipStream_t s);
 hipError_t staged_upload_bytes(StagingRing& ring, const void* src, void* dst, size_t n_bytes, hipStream_t s);
 // WAVE files (wav.hip): header parsing on the host, PCM decode + wavread's normalisation on the device

@@ -93,6 +93,7 @@ struct repet_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // short independent kernels run beside the main stream
+    hipStream_t copy_stream = nullptr;   // the remainder plane of a float64 upload follows the samples here (created on first use)
     std::vector<hipStream_t> ballast_streams;   // candidates that shared the main stream's hardware queue (pick_side_stream)
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     std::vector<hipEvent_t> chunk_events;
@@ -258,7 +259,8 @@ bool gram_big_enabled() {
 // seg (nullable): segment records of S's rows for the peak picking (peaks.h), pitch seg_pitch: written by the 256 x 256
 // kernel's epilogue, by a pass over S behind the other kernels
 int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int64_t TS, bool unit_rows = false,
-                  bool planes_ready = false, float* seg = nullptr, int seg_pitch = 0) {
+                  bool planes_ready = false, float* seg = nullptr, int seg_pitch = 0, bool* seg_written = nullptr) {
+    if (seg_written) *seg_written = false;             // (the caller then runs launch_segment_maxima itself, as a stage of its own)
     // REPET_GRAM_SEGMENTS=0: the records by the pass over S also behind the 256 x 256 kernel (agreement test of the epilogue's)
     static const bool seg_in_epilogue = [] { const char* e = getenv("REPET_GRAM_SEGMENTS"); return !(e && e[0] == '0'); }();
     if (unit_rows && gram_f16_enabled() && gram_big_enabled() && T >= 8 * gram_big_tile()) {
@@ -282,7 +284,8 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
         }
         HIP_TRY(launch_gram_full_f16_big(c->Vh.p, T, FS, S, TS, c->tiles_big.as<int2>(), c->tiles_big_count, c->stream,
                                          seg_in_epilogue ? seg : nullptr, seg_pitch));
-        if (seg && !seg_in_epilogue) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
+        if (seg_written) *seg_written = seg && seg_in_epilogue;
+        else if (seg && !seg_in_epilogue) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
         return REPET_OK;
     }
     const int2* tiles; int n;
@@ -294,11 +297,11 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
             HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
         }
         HIP_TRY(launch_gram_full_f16(c->Vh.p, T, FS, S, TS, tiles, n, c->stream));
-        if (seg) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
+        if (seg && !seg_written) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
         return REPET_OK;
     }
     HIP_TRY(launch_gram_full(A, T, FS, S, TS, tiles, n, c->stream));
-    if (seg) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
+    if (seg && !seg_written) HIP_TRY(launch_segment_maxima(S, T, (int)T, TS, seg, seg_pitch, c->stream));
     return REPET_OK;
 }
 // unit_rows: A holds unit vectors (the similarity band of simonline), safe for the f16-split kernel; the beat-spectrum
@@ -539,6 +542,14 @@ bool power_planes_enabled() {
     return on;
 }
 
+// the arguments of a fused inverse STFT as far as istft_reg_takes() looks at them
+IstftOlaArgs reg_probe(int W, int channels, bool weighted, int64_t n_out, int64_t out_stride, int64_t overlap) {
+    IstftOlaArgs a{};
+    a.W = W; a.n_channels = channels; a.accumulate_weighted = weighted ? 1 : 0; a.n_out = n_out; a.batch_out_stride = out_stride;
+    a.overlap = overlap; a.fade_in = overlap; a.fade_out = overlap;
+    return a;
+}
+
 int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n, int B, int64_t hop,
                  int32_t* period_slots, bool weighted, int seg_first, int seg_total, int64_t overlap) {
     Tables* tb = nullptr;
@@ -560,10 +571,10 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     // plane written and read back, no second read of V by the mask kernel, no read of V by the inverse. cfg 3: mask_period
     // 0.24 -> 0.11 ms, inverse 0.48 -> 0.51, step 1.53 -> 1.42. REPET_MASK_MODEL=0: the plane.
     static const bool model_wanted = [] { const char* e = getenv("REPET_MASK_MODEL"); return !(e && e[0] == '0'); }();
-    const int64_t lim30 = (int64_t)1 << 30;
     struct ModelScope { repet_ctx* c; ~ModelScope() { c->mask_model = false; } } model_scope{c};
-    c->mask_model = model_wanted && c->mask_plane && reg_fft_supported(g.W, g.C, true) &&
-                    !(weighted && (n >= lim30 || hop >= lim30 || overlap >= lim30));
+    // (the launcher's own test, not a copy of it: only the register kernel applies a model, and launch_istft_ola refuses
+    // one on the others)
+    c->mask_model = model_wanted && c->mask_plane && istft_reg_takes(reg_probe(g.W, g.C, weighted, n, hop, overlap));
     const int model_rows = hi + 1;
     ModelRef model_ref{};
     RP_TRY(ensure_spectra(c, g, false, !p_planes, B, p_planes));
@@ -704,10 +715,9 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         // cfg 3 that is all but the last 441 000 of 26 460 000 samples (212 MB of memset, 40 us). Other kernels add onto
         // the cleared output whatever the mode says, so they get the whole clear.
         int64_t s0 = 0, s1 = 0;                                     // [s0, s1): stored by class 0 of the first batch
-        const int64_t lim30 = (int64_t)1 << 30;
         static const bool partial = [] { const char* e = getenv("REPET_EXTENDED_CLEAR"); return !(e && e[0] == 'a'); }();     // =all: the whole output
-        if (partial && uniform > 0 && Hs > 0 && L == ceil_div(L, Hs) * Hs && reg_fft_supported(p->window_length, c->n_channels, true) &&
-            L < lim30 && Hs < lim30 && O < lim30) {
+        if (partial && uniform > 0 && Hs > 0 && L == ceil_div(L, Hs) * Hs &&
+            istft_reg_takes(reg_probe(p->window_length, c->n_channels, true, L, Hs, O))) {
             const int64_t classes = ceil_div(L, Hs), nb0 = std::min(uniform, kMaxSegmentBatch);
             const int64_t n_class0 = (nb0 + classes - 1) / classes;
             s0 = first * Hs;
@@ -921,6 +931,7 @@ int run_exact_rows(repet_ctx* c, const Tables* tb, const Geo& g, const float* M,
                    int64_t clip_stride, int64_t frame_sample0, int64_t n_frames, int clips) {
     if (!rf.redo_list) return REPET_OK;
     hipStream_t stream = c->stream;
+    if (lo && c->ring.lo_in_flight) HIP_TRY(hipStreamWaitEvent(stream, c->ring.lo_done, 0));       // the remainder plane has arrived
     ExactSource src{};
     src.hi = hi; src.lo = lo; src.n_samples = n_samples; src.n_channels = g.C; src.clip_stride = clip_stride;
     src.frame_sample0 = frame_sample0; src.W = g.W; src.H = g.H; src.F = g.F; src.FS = g.FS;
@@ -1007,7 +1018,8 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int seg_pitch = segment_pitch((int)TS);
     if (with_seg) HIP_TRY(c->seg.ensure((size_t)T * 3 * seg_pitch * sizeof(float)));
     float* seg = with_seg ? c->seg.as<float>() : nullptr;
-    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft(1), seg, seg_pitch));
+    bool seg_written = false;
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft(1), seg, seg_pitch, &seg_written));
     {
         // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
         // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
@@ -1017,6 +1029,10 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         const double n_tiles = 0.5 * (double)ceil_div(T, edge) * (double)(ceil_div(T, edge) + 1);
         mark(c, f16 ? "similarity_gemm_f16x3" : "similarity_gemm", 4.0 * g.F * T + 4.0 * T * T,
              (f16 ? 3.0 : 1.0) * 2.0 * g.FS * n_tiles * edge * edge);
+    }
+    if (seg && !seg_written) {                          // (short clips, the other Gram kernels: a pass over S)
+        HIP_TRY(launch_segment_maxima(c->S.as<float>(), T, (int)T, TS, seg, seg_pitch, c->stream));
+        mark(c, "segment_maxima", 4.0 * T * T + 12.0 * T * seg_pitch, 0);
     }
     const int K = p->sim_number, KP = std::max(K, kMinIdxPitch);
     HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
@@ -1351,6 +1367,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     for (auto& kv : c->tables) { kv.second->window.release(); kv.second->twiddle.release(); kv.second->window64.release(); kv.second->twiddle64.release(); }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipStream_t b : c->ballast_streams) (void)hipStreamDestroy(b);
     for (hipEvent_t e : c->chunk_events) (void)hipEventDestroy(e);
     if (c->fork_event) (void)hipEventDestroy(c->fork_event);
@@ -1432,7 +1449,20 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
         HIP_TRY(c->audio_lo.ensure((size_t)count * sizeof(float)));
         lo_dst = c->audio_lo.as<float>();
     }
-    HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream, lo_dst, &c->has_lo));
+    // The remainders are read by the second level of the peak picking only -- behind the STFT, the Gram matrix and the first
+    // pass: they follow the samples on a stream of their own, and what is enqueued next starts when the SAMPLES are there
+    // (run_exact_rows waits for ring.lo_done). Half of a float64 upload's bytes thus cross PCIe beside the computation.
+    if (lo_dst && !c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    bool not_finite = false;
+    HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream, lo_dst, &c->has_lo, lo_dst ? c->copy_stream : nullptr,
+                          &not_finite));
+    if (not_finite) {
+        // repet.py computes on, and NaN spreads from the frames that hold it through whatever is global in the variant (the
+        // beat spectrum of original / extended / adaptive: whole segments or clips of NaN); host arrays with such samples are
+        // refused instead ("Where the drop-in differs on purpose")
+        c->n_channels = 0;
+        return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples");
+    }
     c->n_samples = n;
     c->n_channels = ch;
     c->n_clips = n_clips;
@@ -1441,20 +1471,31 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     return REPET_OK;
 }
 
-int repet_ctx_upload_device(repet_ctx* c, const float* dev_audio, int64_t n, int32_t ch, int32_t n_clips) {
+int repet_ctx_upload_device_split(repet_ctx* c, const float* dev_audio, const float* dev_audio_lo, int64_t n, int32_t ch, int32_t n_clips) {
     if (!c || !dev_audio) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (n < 0 || ch < 1 || n_clips < 1) return fail(REPET_ERR_BAD_ARG, "audio_signal must be (number_samples, number_channels)");
     DeviceGuard guard(c->device);
     const int64_t count = n * ch * n_clips;
     HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
     HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
-    // device -> device (peer memory works as well); the source may be reused when this returns
+    // device -> device (peer memory works as well); the sources may be reused when this returns
     HIP_TRY(hipMemcpyAsync(c->audio.p, dev_audio, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_lo = false;
+    if (dev_audio_lo && count > 0) {
+        // the fp32 remainders of a float64 waveform (x - (double)(float)x): with them the second level of the peak picking
+        // sees the 48 bits the single-GPU call sees
+        HIP_TRY(c->audio_lo.ensure((size_t)count * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(c->audio_lo.p, dev_audio_lo, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        c->has_lo = true;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_samples = n; c->n_channels = ch; c->n_clips = n_clips; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
     return REPET_OK;
+}
+
+int repet_ctx_upload_device(repet_ctx* c, const float* dev_audio, int64_t n, int32_t ch, int32_t n_clips) {
+    return repet_ctx_upload_device_split(c, dev_audio, nullptr, n, ch, n_clips);
 }
 
 int repet_ctx_download_device(repet_ctx* c, float* dev_out) {
@@ -1843,7 +1884,10 @@ int repet_run(int algo, const void* audio, int dtype, int64_t n, int32_t ch, con
     repet_ctx* c = nullptr;
     RP_TRY(thread_ctx(device, &c));
     RP_TRY(repet_ctx_upload(c, audio, dtype, n, ch));
-    RP_TRY(repet_ctx_execute(c, algo, p, timing));
+    // (without a timing request nothing waits between the last kernel and the first copy back: the download is ordered behind
+    // the run on the context's stream, and an error of the run surfaces there)
+    if (timing) RP_TRY(repet_ctx_execute(c, algo, p, timing));
+    else RP_TRY(repet_ctx_execute_async(c, algo, p));
     return repet_ctx_download(c, out);
 }
 
@@ -1852,6 +1896,10 @@ namespace {
 // Logical devices (test switch): REPET_LOGICAL_DEVICES=n lets repet_run_batch deal its clips over n "devices" although
 // fewer GPUs are visible -- logical device d runs on physical device d % visible, in its own thread, context and stream.
 // Dealing, per-device threads and result placement of the multi-GPU path can then be exercised on a one-GPU box.
+// what the last repet_run_batch / repet_run_batch_rccl call of this thread did (repet_last_batch_info)
+struct BatchInfo { int64_t transport = 0, clips_sent = 0, clips_with_remainders = 0, groups = 0; };
+thread_local BatchInfo g_batch_info;
+
 int logical_device_count(int physical) {
     const char* e = getenv("REPET_LOGICAL_DEVICES");
     const int n = e ? atoi(e) : 0;
@@ -1865,6 +1913,7 @@ struct Rccl {
     using comm_t = void*;
     int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
+    int (*CommAbort)(comm_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
@@ -1881,6 +1930,7 @@ struct Rccl {
             auto sym = [&](const char* name) { return dlsym(h, name); };
             x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
             x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+            x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(sym("ncclCommAbort"));
             x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
             x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
             x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
@@ -1932,6 +1982,7 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
     };
 
     if (transport != 1) {
+        g_batch_info = BatchInfo{};
         run_threads([&](int dev) {
             repet_ctx* c = nullptr;
             int rc = repet_ctx_create(dev % physical, &c);
@@ -1948,84 +1999,174 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
         return first_error();
     }
 
+    // ---- transport 1 -------------------------------------------------------------------------------------------------
+    // One call at a time (the communicators are shared, cached per device count and kept until the process ends: creating
+    // them costs hundreds of milliseconds). The clips are worked through in ROUNDS of one clip per device: while the devices
+    // separate round r, the root narrows / uploads round r + 1 and its scatter group is already enqueued; the results of
+    // round r return in their own group and their buffers are freed before round r + 2 is staged -- the root never holds more
+    // than two rounds. A float64 clip travels as TWO fp32 planes, samples and remainders (x - (double)(float)x, only where
+    // one is not zero): the second level of the peak picking then decides on the same 48 bits as the single-GPU call.
+    // REPET_RCCL_SELF=1 with n_devices == 1 (test switch): every clip takes the send / receive path, device 0 to itself
+    // inside the group, so that the transport's lines run on a one-GPU box.
     Rccl& rc = Rccl::get();
     if (!rc.ok) return fail(REPET_ERR_HIP, "librccl could not be loaded (RCCL transport of repet_run_batch)");
-    std::vector<int> devs(n_devices);
-    std::iota(devs.begin(), devs.end(), 0);
-    std::vector<Rccl::comm_t> comms(n_devices, nullptr);
-    NCCL_TRY(rc.CommInitAll(comms.data(), n_devices, devs.data()));
+    static std::mutex call_mu;
+    static std::map<int, std::vector<Rccl::comm_t>> comm_cache;
+    std::lock_guard<std::mutex> call_lock(call_mu);
+    const bool self_test = n_devices == 1 && [] { const char* e = getenv("REPET_RCCL_SELF"); return e && e[0] == '1'; }();
+    g_batch_info = BatchInfo{};
+    g_batch_info.transport = 1;
+    auto it = comm_cache.find(n_devices);
+    if (it == comm_cache.end()) {
+        std::vector<int> devs(n_devices);
+        std::iota(devs.begin(), devs.end(), 0);
+        std::vector<Rccl::comm_t> fresh(n_devices, nullptr);
+        NCCL_TRY(rc.CommInitAll(fresh.data(), n_devices, devs.data()));
+        it = comm_cache.emplace(n_devices, std::move(fresh)).first;
+    }
+    std::vector<Rccl::comm_t>& comms = it->second;
+    bool comms_broken = false;
+
+    struct ClipBufs { float *in_root = nullptr, *lo_root = nullptr, *out_root = nullptr, *in_dev = nullptr, *lo_dev = nullptr, *out_dev = nullptr; bool has_lo = false; };
+    std::vector<ClipBufs> bufs(n_clips);
     std::vector<repet_ctx*> ctx(n_devices, nullptr);
-    std::vector<float*> in_dev(n_clips, nullptr), out_dev(n_clips, nullptr), in_root(n_clips, nullptr), out_root(n_clips, nullptr);
-    int status = REPET_OK;
-    auto cleanup = [&]() {
-        for (int k = 0; k < n_clips; ++k) {
-            for (float* q : {in_dev[k], out_dev[k]}) if (q) { DeviceGuard g(device_of[k]); (void)hipFree(q); }
-            for (float* q : {in_root[k], out_root[k]}) if (q) { DeviceGuard g(0); (void)hipFree(q); }
-        }
-        for (int d = 0; d < n_devices; ++d) { if (ctx[d]) repet_ctx_destroy(ctx[d]); if (comms[d]) (void)rc.CommDestroy(comms[d]); }
+    repet_ctx* io = nullptr;                          // the root's own context for staging and transport (ctx[0] computes)
+    auto travels = [&](int k) { return device_of[k] != 0 || self_test; };
+    auto free_clip = [&](int k) {
+        ClipBufs& q = bufs[k];
+        { DeviceGuard g(0); for (float** ptr : {&q.in_root, &q.lo_root, &q.out_root}) if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; } }
+        { DeviceGuard g(device_of[k]); for (float** ptr : {&q.in_dev, &q.lo_dev, &q.out_dev}) if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; } }
     };
-    auto body = [&]() -> int {
-        for (int d = 0; d < n_devices; ++d) RP_TRY(repet_ctx_create(d, &ctx[d]));
-        // the clips enter through device 0 (fp32, narrowed on their way by the host threads of hostio.hip)
-        for (int k = 0; k < n_clips; ++k) {
-            const size_t count = (size_t)n_samples[k] * n_channels[k];
-            const size_t bytes = std::max<size_t>(count * sizeof(float), 256);
-            { DeviceGuard g(0); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&in_root[k]), bytes)); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_root[k]), bytes)); }
-            if (device_of[k] != 0) { DeviceGuard g(device_of[k]); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&in_dev[k]), bytes)); HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev[k]), bytes)); }
-            DeviceGuard g(0);
-            HIP_TRY(staged_upload(ctx[0]->ring, audio[k], dtype, in_root[k], count, ctx[0]->stream));
+    struct Xfer { const float* src; int src_dev; float* dst; int dst_dev; size_t count; };
+    // One group of sends and receives. The group is CLOSED whatever happens inside it (an error between ncclGroupStart and
+    // ncclGroupEnd used to leave it open under the communicators' destruction); a failed group marks the communicators broken.
+    auto exchange = [&](const std::vector<Xfer>& xs) -> int {
+        if (xs.empty()) return REPET_OK;
+        int err = rc.GroupStart();
+        if (err != 0) { comms_broken = true; return fail(REPET_ERR_HIP, std::string("ncclGroupStart: ") + (rc.GetErrorString ? rc.GetErrorString(err) : "RCCL error")); }
+        const char* what = nullptr;
+        for (const Xfer& x : xs) {
+            hipStream_t send_stream = x.src_dev == 0 ? io->stream : ctx[x.src_dev]->stream;
+            hipStream_t recv_stream = x.dst_dev == 0 ? io->stream : ctx[x.dst_dev]->stream;
+            err = rc.Send(x.src, x.count, Rccl::kFloat, x.dst_dev, comms[x.src_dev], send_stream);
+            if (err != 0) { what = "ncclSend"; break; }
+            err = rc.Recv(x.dst, x.count, Rccl::kFloat, x.src_dev, comms[x.dst_dev], recv_stream);
+            if (err != 0) { what = "ncclRecv"; break; }
         }
-        { DeviceGuard g(0); HIP_TRY(hipStreamSynchronize(ctx[0]->stream)); }
-        // scatter: one group of sends (root) and receives (workers), all links at once
-        NCCL_TRY(rc.GroupStart());
-        for (int k = 0; k < n_clips; ++k) {
-            const int g = device_of[k];
-            if (g == 0) continue;
-            const size_t count = (size_t)n_samples[k] * n_channels[k];
-            NCCL_TRY(rc.Send(in_root[k], count, Rccl::kFloat, g, comms[0], ctx[0]->stream));
-            NCCL_TRY(rc.Recv(in_dev[k], count, Rccl::kFloat, 0, comms[g], ctx[g]->stream));
-        }
-        NCCL_TRY(rc.GroupEnd());
-        for (int d = 0; d < n_devices; ++d) { DeviceGuard g(d); HIP_TRY(hipStreamSynchronize(ctx[d]->stream)); }
-        // every device separates its clips from the received device buffers, results stay on the device
-        run_threads([&](int dev) {
-            int r = REPET_OK;
-            for (int i = dev; r == REPET_OK && i < n_clips; i += n_devices) {
-                const int k = order[i];
-                float* src = dev == 0 ? in_root[k] : in_dev[k];
-                float* dst = dev == 0 ? out_root[k] : out_dev[k];
-                r = repet_ctx_upload_device(ctx[dev], src, n_samples[k], n_channels[k], 1);
-                if (r == REPET_OK) r = repet_ctx_execute(ctx[dev], algo, p, nullptr);
-                if (r == REPET_OK) r = repet_ctx_download_device(ctx[dev], dst);
-            }
-            if (r != REPET_OK) msgs[dev] = g_last_error;
-            rcs[dev] = r;
-        });
-        RP_TRY(first_error());
-        // gather: the mirror image
-        NCCL_TRY(rc.GroupStart());
-        for (int k = 0; k < n_clips; ++k) {
-            const int g = device_of[k];
-            if (g == 0) continue;
-            const size_t count = (size_t)n_samples[k] * n_channels[k];
-            NCCL_TRY(rc.Send(out_dev[k], count, Rccl::kFloat, 0, comms[g], ctx[g]->stream));
-            NCCL_TRY(rc.Recv(out_root[k], count, Rccl::kFloat, g, comms[0], ctx[0]->stream));
-        }
-        NCCL_TRY(rc.GroupEnd());
-        for (int d = 0; d < n_devices; ++d) { DeviceGuard g(d); HIP_TRY(hipStreamSynchronize(ctx[d]->stream)); }
-        DeviceGuard g(0);
-        for (int k = 0; k < n_clips; ++k)
-            HIP_TRY(staged_download(ctx[0]->ring, out_root[k], out[k], (size_t)n_samples[k] * n_channels[k], ctx[0]->stream));
+        const int end = rc.GroupEnd();
+        if (err == 0 && end != 0) { err = end; what = "ncclGroupEnd"; }
+        if (err != 0) { comms_broken = true; return fail(REPET_ERR_HIP, std::string(what) + ": " + (rc.GetErrorString ? rc.GetErrorString(err) : "RCCL error")); }
+        ++g_batch_info.groups;
         return REPET_OK;
     };
-    status = body();
+    const int n_rounds = (n_clips + n_devices - 1) / n_devices;
+    auto round_clips = [&](int r) { std::vector<int> ks; for (int i = r * n_devices; i < std::min(n_clips, (r + 1) * n_devices); ++i) ks.push_back(order[i]); return ks; };
+    // A(r): the round's clips enter through the root (fp32 samples + remainders), the travelling ones leave in one group
+    auto stage_round = [&](int r) -> int {
+        std::vector<Xfer> xs;
+        for (int k : round_clips(r)) {
+            ClipBufs& q = bufs[k];
+            const size_t count = (size_t)n_samples[k] * n_channels[k];
+            const size_t bytes = std::max<size_t>(count * sizeof(float), 256);
+            const bool want_lo = dtype == REPET_F64 && count > 0;
+            {
+                DeviceGuard g(0);
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.in_root), bytes));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.out_root), bytes));
+                if (want_lo) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.lo_root), bytes));
+                bool not_finite = false;
+                HIP_TRY(staged_upload(io->ring, audio[k], dtype, q.in_root, count, io->stream, q.lo_root, &q.has_lo, nullptr, &not_finite));
+                if (not_finite) return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples");
+            }
+            if (q.has_lo) ++g_batch_info.clips_with_remainders;
+            if (!travels(k) || count == 0) continue;
+            const int g = device_of[k];
+            {
+                DeviceGuard gd(g);
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.in_dev), bytes));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.out_dev), bytes));
+                if (q.has_lo) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.lo_dev), bytes));
+            }
+            xs.push_back({q.in_root, 0, q.in_dev, g, count});
+            if (q.has_lo) xs.push_back({q.lo_root, 0, q.lo_dev, g, count});
+            ++g_batch_info.clips_sent;
+        }
+        RP_TRY(exchange(xs));
+        DeviceGuard g(0);
+        HIP_TRY(hipStreamSynchronize(io->stream));          // the root's copies are complete (and the sends have been matched)
+        return REPET_OK;
+    };
+    // B(r): every device separates its clip of the round from device memory; the result stays on the device
+    auto compute_clip = [&](int k) -> int {
+        ClipBufs& q = bufs[k];
+        const int dev = device_of[k];
+        const bool moved = travels(k) && (size_t)n_samples[k] * n_channels[k] > 0;
+        RP_TRY(repet_ctx_upload_device_split(ctx[dev], moved ? q.in_dev : q.in_root, q.has_lo ? (moved ? q.lo_dev : q.lo_root) : nullptr,
+                                             n_samples[k], n_channels[k], 1));
+        RP_TRY(repet_ctx_execute(ctx[dev], algo, p, nullptr));
+        return repet_ctx_download_device(ctx[dev], moved ? q.out_dev : q.out_root);
+    };
+    // C(r): the travelling results return in one group; the root widens them into the caller's arrays; the round is freed
+    auto finish_round = [&](int r) -> int {
+        std::vector<Xfer> xs;
+        for (int k : round_clips(r)) {
+            const size_t count = (size_t)n_samples[k] * n_channels[k];
+            if (travels(k) && count > 0) xs.push_back({bufs[k].out_dev, device_of[k], bufs[k].out_root, 0, count});
+        }
+        RP_TRY(exchange(xs));
+        {
+            DeviceGuard g(0);
+            for (int k : round_clips(r))
+                HIP_TRY(staged_download(io->ring, bufs[k].out_root, out[k], (size_t)n_samples[k] * n_channels[k], io->stream));
+            HIP_TRY(hipStreamSynchronize(io->stream));
+        }
+        for (int d = 1; d < n_devices; ++d) { DeviceGuard g(d); HIP_TRY(hipStreamSynchronize(ctx[d]->stream)); }     // (their sends)
+        for (int k : round_clips(r)) free_clip(k);
+        return REPET_OK;
+    };
+    auto body = [&]() -> int {
+        RP_TRY(repet_ctx_create(0, &io));
+        for (int d = 0; d < n_devices; ++d) RP_TRY(repet_ctx_create(d, &ctx[d]));
+        if (n_rounds > 0) RP_TRY(stage_round(0));
+        for (int r = 0; r < n_rounds; ++r) {
+            // the devices work on round r in their own threads while this one stages round r + 1
+            const std::vector<int> ks = round_clips(r);
+            std::vector<int> round_rc(ks.size(), REPET_OK);
+            std::vector<std::string> round_msg(ks.size());
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < ks.size(); ++i)
+                th.emplace_back([&, i] { round_rc[i] = compute_clip(ks[i]); if (round_rc[i] != REPET_OK) round_msg[i] = g_last_error; });
+            const int staged = r + 1 < n_rounds ? stage_round(r + 1) : REPET_OK;
+            const std::string staged_msg = g_last_error;
+            for (auto& t : th) t.join();
+            for (size_t i = 0; i < ks.size(); ++i) if (round_rc[i] != REPET_OK) return fail(round_rc[i], round_msg[i]);
+            if (staged != REPET_OK) return fail(staged, staged_msg);
+            RP_TRY(finish_round(r));
+        }
+        return REPET_OK;
+    };
+    const int status = body();
     const std::string keep = g_last_error;
-    cleanup();
+    for (int d = 0; d < n_devices; ++d) if (ctx[d]) { DeviceGuard g(d); (void)hipStreamSynchronize(ctx[d]->stream); }
+    if (io) { DeviceGuard g(0); (void)hipStreamSynchronize(io->stream); }
+    for (int k = 0; k < n_clips; ++k) free_clip(k);
+    for (int d = 0; d < n_devices; ++d) if (ctx[d]) repet_ctx_destroy(ctx[d]);
+    if (io) repet_ctx_destroy(io);
+    if (comms_broken) {                               // do not hand a communicator with a failed group to the next call
+        for (Rccl::comm_t cm : comms) if (cm) (void)(rc.CommAbort ? rc.CommAbort(cm) : rc.CommDestroy(cm));
+        comm_cache.erase(n_devices);
+    }
     if (status != REPET_OK) g_last_error = keep;
     return status;
 }
 
 }  // namespace
+
+int repet_last_batch_info(int64_t out[4]) {
+    if (!out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    out[0] = g_batch_info.transport; out[1] = g_batch_info.clips_sent; out[2] = g_batch_info.clips_with_remainders; out[3] = g_batch_info.groups;
+    return REPET_OK;
+}
 
 int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
                     const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {

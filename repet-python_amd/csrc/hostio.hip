@@ -18,10 +18,13 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <functional>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace repet {
@@ -38,21 +41,28 @@ public:
     int size() const { return n_threads_; }
     // fn(part, n_parts) on n_parts = size() parts, the caller running part 0; returns when all are done.
     // One job at a time (callers from different host threads take turns).
+    // A staged copy is thirty-odd such jobs back to back, one per 4-MB chunk: a worker that has just finished a part SPINS
+    // for the next job for a while before it goes back to sleep on the condition variable, and the caller spins for the parts
+    // -- woken through the condition variable every time, the hand-over cost 30 .. 50 us per chunk, a millisecond per clip.
     void run(const std::function<void(int, int)>& fn, size_t work_items = ~(size_t)0) {
         if (n_threads_ <= 1 || work_items < 65536) { fn(0, 1); return; }     // not worth waking anybody up
         std::lock_guard<std::mutex> one_job(job_mutex_);
+        fn_ = &fn;
+        pending_.store(n_threads_ - 1, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn; pending_ = n_threads_ - 1; ++generation_;
+            generation_.fetch_add(1, std::memory_order_release);
         }
-        cv_.notify_all();
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
         fn(0, n_threads_);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return pending_ == 0; });
+        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
+            if (spins < 20000) cpu_relax(); else std::this_thread::yield();
+        }
         fn_ = nullptr;
     }
 
 private:
+    static void cpu_relax() { __builtin_ia32_pause(); }
     HostWorkers() {
         const char* e = getenv("REPET_HOST_THREADS");
         int n = e ? atoi(e) : 0;
@@ -68,45 +78,97 @@ private:
     void loop(int part) {
         unsigned seen = 0;
         for (;;) {
-            const std::function<void(int, int)>* fn;
-            {
+            // the next job: spin for about 200 us (the gaps between the chunks of one copy), then sleep
+            bool have = false;
+            for (int spins = 0; spins < 40000; ++spins) {
+                if (generation_.load(std::memory_order_acquire) != seen) { have = true; break; }
+                cpu_relax();
+            }
+            if (!have) {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return generation_ != seen; });
-                seen = generation_;
-                fn = fn_;
+                sleepers_.fetch_add(1, std::memory_order_release);
+                cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_release);
             }
+            seen = generation_.load(std::memory_order_acquire);
+            const std::function<void(int, int)>* fn = fn_;
             (*fn)(part, n_threads_);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) done_.notify_one();
-            }
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     int n_threads_ = 1;
     std::mutex job_mutex_, m_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(int, int)>* fn_ = nullptr;
-    int pending_ = 0;
-    unsigned generation_ = 0;
+    std::atomic<int> pending_{0}, sleepers_{0};
+    std::atomic<unsigned> generation_{0};
 };
 
-template <typename T>
-void narrow_part(const T* src, float* dst, size_t lo, size_t hi) {
+// The conversion loops are compiled three times (baseline x86-64, AVX2, AVX-512) and picked at load time: at two doubles per
+// instruction the narrowing of a 127-MB clip was instruction-bound on the eight threads (1.7 ms for a copy that takes 1.15).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define REPET_HOST_CLONES
+#else
+#define REPET_HOST_CLONES __attribute__((target_clones("default", "avx2", "avx512f")))
+#endif
+// (every converter also says whether it met a sample that is not finite: the drop-in rejects such input -- INTEGRATION.md)
+REPET_HOST_CLONES bool narrow_f64(const double* src, float* dst, size_t lo, size_t hi) {
+    bool bad = false;
+    for (size_t i = lo; i < hi; ++i) {
+        const double x = src[i];
+        dst[i] = (float)x;
+        bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+    }
+    return bad;
+}
+REPET_HOST_CLONES bool narrow_f32(const float* src, float* dst, size_t lo, size_t hi) {
+    bool bad = false;
+    for (size_t i = lo; i < hi; ++i) {
+        const float x = src[i];
+        dst[i] = x;
+        bad |= !(std::fabs(x) <= std::numeric_limits<float>::max());
+    }
+    return bad;
+}
+REPET_HOST_CLONES void narrow_i16(const int16_t* src, float* dst, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) dst[i] = (float)src[i];
+}
+REPET_HOST_CLONES void widen_f32(const float* src, double* dst, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) dst[i] = (double)src[i];
 }
 
 // float64 -> the fp32 sample and the fp32 remainder (hi + lo carries 48 bits of the double); true when a remainder is not zero
-bool split_part(const double* src, float* dst_hi, float* dst_lo, size_t lo, size_t hi) {
-    bool any = false;
-    for (size_t i = lo; i < hi; ++i) {
-        const double x = src[i];
-        const float h = (float)x;
-        const float l = (float)(x - (double)h);
-        dst_hi[i] = h;
-        dst_lo[i] = l;
-        any = any || (l != 0.0f);       // (a NaN or infinite sample gives a NaN remainder: kept, it is what hi + lo must say)
+// Samples that came from PCM or fp32 data (what wavread returns) have no remainders at all: the part is narrowed in blocks
+// whose remainders are only TESTED (one OR per block, nothing stored), and the remainder plane of the part is written -- zeros
+// up to there, values from there on -- once a block has met one that is not zero.
+REPET_HOST_CLONES bool split_part(const double* src, float* dst_hi, float* dst_lo, size_t lo, size_t hi, bool* not_finite) {
+    constexpr size_t kBlock = 1024;
+    size_t i = lo;
+    bool bad = false;
+    for (; i < hi; i += kBlock) {
+        const size_t end = std::min(hi, i + kBlock);
+        bool any = false;
+        for (size_t k = i; k < end; ++k) {
+            const double x = src[k];
+            const float h = (float)x;
+            dst_hi[k] = h;
+            any |= (x != (double)h);    // (a NaN sample counts: its remainder is NaN, which is what hi + lo must say)
+            bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+        }
+        if (any) break;
     }
-    return any;
+    if (i < hi) {
+        std::memset(dst_lo + lo, 0, (i - lo) * sizeof(float));
+        for (size_t k = i; k < hi; ++k) {
+            const double x = src[k];
+            const float h = (float)x;
+            dst_hi[k] = h;
+            dst_lo[k] = (float)(x - (double)h);
+            bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+        }
+    }
+    if (bad) *not_finite = true;
+    return i < hi;
 }
 
 }  // namespace
@@ -121,6 +183,27 @@ void StagingRing::release() {
     }
     if (base) { (void)hipHostFree(base); base = nullptr; }
     if (base_lo) { (void)hipHostFree(base_lo); base_lo = nullptr; }
+    if (lo_done) { (void)hipEventSynchronize(lo_done); (void)hipEventDestroy(lo_done); lo_done = nullptr; }
+    if (hi_done) { (void)hipEventDestroy(hi_done); hi_done = nullptr; }
+    if (lo_full) { (void)hipHostFree(lo_full); lo_full = nullptr; lo_full_elems = 0; }
+    lo_in_flight = false;
+}
+
+hipError_t StagingRing::ensure_lo_full(size_t elems) {
+    if (!lo_done) {
+        hipError_t e = hipEventCreateWithFlags(&lo_done, hipEventDisableTiming);
+        if (e != hipSuccess) { lo_done = nullptr; return e; }
+        e = hipEventCreateWithFlags(&hi_done, hipEventDisableTiming);
+        if (e != hipSuccess) { hi_done = nullptr; return e; }
+    }
+    if (lo_in_flight) { const hipError_t w = hipEventSynchronize(lo_done); if (w != hipSuccess) return w; lo_in_flight = false; }   // the last plane has left
+    if (lo_full_elems >= elems) return hipSuccess;
+    if (lo_full) { (void)hipHostFree(lo_full); lo_full = nullptr; lo_full_elems = 0; }
+    const size_t want = elems + elems / 8;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&lo_full), want * sizeof(float), hipHostMallocDefault);
+    if (e != hipSuccess) { lo_full = nullptr; return e; }
+    lo_full_elems = want;
+    return hipSuccess;
 }
 
 hipError_t StagingRing::ensure_lo() {
@@ -147,39 +230,80 @@ hipError_t StagingRing::ensure() {
 // whose remainders are all zero (samples that came from PCM or fp32 data) is cleared on the device instead of travelling;
 // *any_lo says whether any chunk travelled.
 hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* dst, size_t count, hipStream_t s,
-                         float* dst_lo, bool* any_lo) {
+                         float* dst_lo, bool* any_lo, hipStream_t s_lo, bool* not_finite) {
     hipError_t e = ring.ensure();
     if (e != hipSuccess) return e;
     const bool split = dst_lo && dtype == 1;
+    const bool deferred = split && s_lo != nullptr;
     if (any_lo) *any_lo = false;
-    if (split) { e = ring.ensure_lo(); if (e != hipSuccess) return e; }
+    if (split && !deferred) { e = ring.ensure_lo(); if (e != hipSuccess) return e; }
+    if (deferred) { e = ring.ensure_lo_full(count); if (e != hipSuccess) return e; }
     HostWorkers& pool = HostWorkers::get();
     const size_t n_chunks = (count + StagingRing::kSlotElems - 1) / StagingRing::kSlotElems;
+    std::vector<char> chunk_has_lo(deferred ? n_chunks : 0, 0);
+    std::atomic<bool> met_not_finite{false};
     for (size_t c = 0; c < n_chunks; ++c) {
         const int slot = (int)(c % StagingRing::kSlots);
         if (ring.busy[slot]) { e = hipEventSynchronize(ring.event[slot]); if (e != hipSuccess) return e; }
         const size_t lo = c * StagingRing::kSlotElems, cnt = std::min(StagingRing::kSlotElems, count - lo);
         float* stage = ring.base + (size_t)slot * StagingRing::kSlotElems;
-        float* stage_lo = split ? ring.base_lo + (size_t)slot * StagingRing::kSlotElems : nullptr;
-        std::atomic<bool> chunk_lo{false};
+        float* stage_lo = !split ? nullptr : (deferred ? ring.lo_full + lo : ring.base_lo + (size_t)slot * StagingRing::kSlotElems);
+        std::atomic<unsigned> parts_with_lo{0};                 // (at most 32 parts)
+        int parts_run = 1;
         pool.run([&](int part, int parts) {
             const size_t a = cnt * part / parts, b = cnt * (part + 1) / parts;
-            if (split) { if (split_part(static_cast<const double*>(src) + lo, stage, stage_lo, a, b)) chunk_lo.store(true, std::memory_order_relaxed); }
-            else if (dtype == 1) narrow_part(static_cast<const double*>(src) + lo, stage, a, b);
-            else if (dtype == 2) narrow_part(static_cast<const int16_t*>(src) + lo, stage, a, b);
-            else std::memcpy(stage + a, static_cast<const float*>(src) + lo + a, (b - a) * sizeof(float));
+            if (part == 0) parts_run = parts;
+            bool bad = false;
+            if (split) {
+                if (split_part(static_cast<const double*>(src) + lo, stage, stage_lo, a, b, &bad)) parts_with_lo.fetch_or(1u << part, std::memory_order_relaxed);
+            }
+            else if (dtype == 1) bad = narrow_f64(static_cast<const double*>(src) + lo, stage, a, b);
+            else if (dtype == 2) narrow_i16(static_cast<const int16_t*>(src) + lo, stage, a, b);
+            else bad = narrow_f32(static_cast<const float*>(src) + lo, stage, a, b);
+            if (bad) met_not_finite.store(true, std::memory_order_relaxed);
         }, cnt);
+        // a chunk's remainders travel whole or not at all: a part that met none wrote nothing, so when another part did, its
+        // share of the staged plane is cleared here (mixed chunks are rare: clips are PCM-exact or they are not)
+        const unsigned with_lo = parts_with_lo.load();
+        const bool chunk_lo = with_lo != 0;
+        if (chunk_lo)
+            for (int part = 0; part < parts_run; ++part)
+                if (!(with_lo >> part & 1u)) {
+                    const size_t a = cnt * part / parts_run, b = cnt * (part + 1) / parts_run;
+                    std::memset(stage_lo + a, 0, (b - a) * sizeof(float));
+                }
         e = hipMemcpyAsync(dst + lo, stage, cnt * sizeof(float), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return e;
-        if (split) {
-            if (chunk_lo.load()) { e = hipMemcpyAsync(dst_lo + lo, stage_lo, cnt * sizeof(float), hipMemcpyHostToDevice, s); if (any_lo) *any_lo = true; }
+        if (split && !deferred) {
+            if (chunk_lo) { e = hipMemcpyAsync(dst_lo + lo, stage_lo, cnt * sizeof(float), hipMemcpyHostToDevice, s); if (any_lo) *any_lo = true; }
             else e = hipMemsetAsync(dst_lo + lo, 0, cnt * sizeof(float), s);
             if (e != hipSuccess) return e;
+        }
+        if (deferred && chunk_lo) {
+            chunk_has_lo[c] = 1;
+            if (any_lo) *any_lo = true;
         }
         e = hipEventRecord(ring.event[slot], s);
         if (e != hipSuccess) return e;
         ring.busy[slot] = true;
     }
+    if (deferred) {
+        // the remainder plane: behind the last chunk of samples, on the other stream
+        e = hipEventRecord(ring.hi_done, s);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(s_lo, ring.hi_done, 0);
+        if (e != hipSuccess) return e;
+        for (size_t c = 0; c < n_chunks; ++c) {
+            const size_t lo = c * StagingRing::kSlotElems, cnt = std::min(StagingRing::kSlotElems, count - lo);
+            if (chunk_has_lo[c]) e = hipMemcpyAsync(dst_lo + lo, ring.lo_full + lo, cnt * sizeof(float), hipMemcpyHostToDevice, s_lo);
+            else e = hipMemsetAsync(dst_lo + lo, 0, cnt * sizeof(float), s_lo);
+            if (e != hipSuccess) return e;
+        }
+        e = hipEventRecord(ring.lo_done, s_lo);
+        if (e != hipSuccess) return e;
+        ring.lo_in_flight = true;
+    }
+    if (not_finite) *not_finite = met_not_finite.load();
     return hipSuccess;
 }
 
@@ -234,8 +358,7 @@ hipError_t staged_download(StagingRing& ring, const float* src, double* dst, siz
         const float* stage = ring.base + (size_t)slot * StagingRing::kSlotElems;
         pool.run([&](int part, int parts) {
             const size_t a = cnt * part / parts, b = cnt * (part + 1) / parts;
-            double* out = dst + lo;
-            for (size_t i = a; i < b; ++i) out[i] = (double)stage[i];
+            widen_f32(stage, dst + lo, a, b);
         }, cnt);
         if (c + StagingRing::kSlots < n_chunks) { e = issue(c + StagingRing::kSlots); if (e != hipSuccess) return e; }
     }

@@ -1295,6 +1295,10 @@ hipError_t launch_istft_ola(const IstftOlaArgs& a0, hipStream_t s) {
         const hipError_t e = launch_istft_ola_reg(a, hops, s);
         if (e != hipErrorNotSupported) return e;
     }
+    // Only the register kernel applies a repeating-segment MODEL itself (IstftOlaArgs::model with M == nullptr); the kernels
+    // below would emit the unmasked mixture without a word. The engine asks istft_reg_takes() before it chooses the model
+    // form; should the two ever disagree, this is an error, not a silent wrong answer.
+    if (a.model) return hipErrorInvalidValue;
     if (a.out_channels == 0 && use_wave_kernels() && a.W <= 4096 && a.n_channels <= 4 && a.n_channels != 3) {
         const int C = a.n_channels;
         const int FI = 4 / C;

@@ -158,6 +158,15 @@ def run_batch(algo, audio_signals, sampling_frequency, n_devices=1, transport="h
     return outs
 
 
+def last_batch_info():
+    """What this thread's last ``run_batch`` did: transport, clips that went through send / receive, clips whose fp32
+    remainder plane was resident when they were separated, RCCL groups completed."""
+    import ctypes as C
+    out = (C.c_int64 * 4)()
+    _native.check(_native.lib().repet_last_batch_info(out))
+    return {"transport": "rccl" if out[0] == 1 else "host", "clips_sent": int(out[1]), "clips_with_remainders": int(out[2]), "rccl_groups": int(out[3])}
+
+
 # ---- private helpers of the reference, kept callable (README.md:79 uses repet._stft) -----------------------
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)

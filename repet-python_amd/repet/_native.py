@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPET_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "librepet_hip.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ORIGINAL, EXTENDED, ADAPTIVE, SIM, SIMONLINE = range(5)
 ALGO_IDS = {"original": ORIGINAL, "extended": EXTENDED, "adaptive": ADAPTIVE, "sim": SIM, "simonline": SIMONLINE}
 F32, F64, I16 = 0, 1, 2
@@ -68,7 +68,9 @@ _SIGNATURES = {
     "repet_ctx_execute": (C.c_int, [_P, C.c_int, C.POINTER(Params), C.POINTER(Timing)]),
     "repet_ctx_download": (C.c_int, [_P, _P]),
     "repet_ctx_upload_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
+    "repet_ctx_upload_device_split": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32]),
     "repet_ctx_download_device": (C.c_int, [_P, _P]),
+    "repet_last_batch_info": (C.c_int, [C.POINTER(C.c_int64)]),
     "repet_ctx_set_window": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "repet_wav_parse": (C.c_int, [_P, C.c_int64, C.POINTER(WavInfo)]),
     "repet_ctx_upload_wav": (C.c_int, [_P, _P, C.c_int64, C.POINTER(WavInfo)]),
@@ -255,10 +257,13 @@ class Context:
         check(lib().repet_ctx_upload_batch(self._h, ptr(a), code, n, c, b))
         self.shape = (b, n, c)
 
-    def upload_device(self, data_ptr, number_samples, number_channels, number_clips=1):
+    def upload_device(self, data_ptr, number_samples, number_channels, number_clips=1, remainder_ptr=None):
         """fp32 interleaved samples already in device memory (e.g. ``tensor.data_ptr()`` of what an RCCL recv filled;
-        its producer must have finished: synchronise that stream first). No host bounce."""
-        check(lib().repet_ctx_upload_device(self._h, C.c_void_p(int(data_ptr)), int(number_samples), int(number_channels), int(number_clips)))
+        its producer must have finished: synchronise that stream first). No host bounce. ``remainder_ptr``: the fp32
+        remainders of a float64 waveform (``x - float64(float32(x))``) in the same layout -- with them the float64 decisions
+        of the peak picking see what a single-GPU call on the float64 array sees."""
+        check(lib().repet_ctx_upload_device_split(self._h, C.c_void_p(int(data_ptr)), C.c_void_p(int(remainder_ptr)) if remainder_ptr else None,
+                                                  int(number_samples), int(number_channels), int(number_clips)))
         self.shape = (number_samples, number_channels) if number_clips == 1 else (number_clips, number_samples, number_channels)
 
     def download_device(self, data_ptr):

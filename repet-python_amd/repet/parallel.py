@@ -4,8 +4,11 @@ the MI355X node, "gloo" in the CPU tests).
 The REPET path shards without any exchange during compute: a batch of clips is a set of independent
 units, and the segments of ``extended`` are independent ``original`` problems whose cross-faded outputs
 add up (repet.py:380-414 is linear in the segments). The only communication is the scatter of
-waveforms from the root and the gather of results back -- point-to-point sends of fp32 samples (the
-engine computes in fp32, so nothing is lost by narrowing on the root; half the bytes travel).
+waveforms from the root and the gather of results back -- point-to-point sends of fp32 samples. The
+engine computes in fp32, but `sim` / `simonline` take the few float64 decisions of their peak picking from
+the 48 bits of sample + remainder (``x - float64(float32(x))``): a float64 clip with such remainders
+therefore travels as TWO fp32 planes (``split_float64``), so that a worker rank separates it exactly as
+``repet.sim`` on the root would (fp32 or PCM-exact clips send one plane: their remainders are zero).
 
 On the RCCL backend the received samples stay on the device: ``dist.recv`` fills a device tensor, the engine
 ingests its pointer (``repet_ctx_upload_device``), the result leaves through ``repet_ctx_download_device``
@@ -56,6 +59,17 @@ def segment_window(segments, first, count):
     return lo, start + length
 
 
+def split_float64(x):
+    """(fp32 samples, fp32 remainders or None) of a float array: what the engine's own upload makes of a float64 array
+    (hostio.hip): ``hi = float32(x)``, ``lo = float32(x - float64(hi))``; None when every remainder is zero."""
+    x = np.asarray(x)
+    hi = np.ascontiguousarray(x, dtype=np.float32)
+    if x.dtype != np.float64:
+        return hi, None
+    lo = (x - hi.astype(np.float64)).astype(np.float32)
+    return hi, (lo if np.any(lo) else None)
+
+
 # ---- the HIP engine on this rank's device ---------------------------------------------------------------------------
 _contexts = {}
 
@@ -73,20 +87,23 @@ def _engine_separate(algo, device):
     device-resident ingest and egress, no host bounce)."""
     import repet
 
-    def run(x, fs):
+    def run(x, fs, remainders=None):
         import torch
         if isinstance(x, torch.Tensor) and x.is_cuda:
             ctx = _context(x.device.index)
             # the engine reads interleaved fp32: a float64 wire (or a strided view) is narrowed / packed first, and the result
             # goes back in the wire's dtype. `x32` stays referenced until upload_device has returned (it copies).
             x32 = x.to(torch.float32).contiguous()
+            lo32 = remainders.to(torch.float32).contiguous() if remainders is not None else None
             torch.cuda.current_stream(x.device).synchronize()          # the recv that filled x (and the cast) have completed
-            ctx.upload_device(x32.data_ptr(), x32.shape[0], x32.shape[1])
+            ctx.upload_device(x32.data_ptr(), x32.shape[0], x32.shape[1], remainder_ptr=lo32.data_ptr() if lo32 is not None else None)
             ctx.execute(algo, repet.derive_params(fs))
             out = torch.empty_like(x32)
             ctx.download_device(out.data_ptr())
             return out.to(x.dtype)
         repet.set_device(device)
+        if remainders is not None:                                     # (host arrays: the float64 waveform, rebuilt exactly)
+            x = np.asarray(x, dtype=np.float64) + np.asarray(remainders, dtype=np.float64)
         return getattr(repet, algo)(x, fs)
     return run
 
@@ -131,7 +148,8 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     """Collective over the default process group. ``clips`` (list of (N_i, C_i) float arrays) is read on
     ``root`` only; every rank separates its share; ``root`` returns the list of background signals (float64) in
     the original order, the other ranks return None. Samples travel as ``wire_dtype`` (fp32: what the engine computes
-    in); on the RCCL backend a worker rank's clips never leave the device."""
+    in; a float64 clip whose fp32 remainders are not all zero sends them as a second plane and ``separate_fn`` is called
+    with them as a third argument); on the RCCL backend a worker rank's clips never leave the device."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -140,19 +158,35 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     fn = separate_fn or _engine_separate(algo, dev.index or 0)
     tdtype = torch.float32 if np.dtype(wire_dtype) == np.float32 else torch.float64
 
+    shares_of = lambda shapes_: deal_clips([s[0] for s in shapes_], world)
+    planes = {}
     meta = [None]
     if rank == root:
-        meta = [[(int(c.shape[0]), int(c.shape[1])) for c in clips]]
+        shapes = [(int(c.shape[0]), int(c.shape[1])) for c in clips]
+        with_lo = [False] * len(shapes)
+        if np.dtype(wire_dtype) == np.float32:                 # (a float64 wire carries everything in one plane)
+            for r, ids in enumerate(shares_of(shapes)):
+                if r != root:
+                    for i in ids:
+                        planes[i] = split_float64(clips[i])
+                        with_lo[i] = planes[i][1] is not None
+        meta = [(shapes, with_lo)]
     dist.broadcast_object_list(meta, src=root)
-    shapes = meta[0]
-    shares = deal_clips([s[0] for s in shapes], world)
+    shapes, with_lo = meta[0]
+    shares = shares_of(shapes)
 
     if rank == root:
         pending = []
         for r, ids in enumerate(shares):                       # the workers' clips leave first, then the root computes
             if r != root:
                 for i in ids:
-                    pending.append(dist.isend(_wire(clips[i], wire_dtype, dev), dst=r))
+                    if i in planes:
+                        hi, lo = planes.pop(i)
+                        pending.append(dist.isend(_wire(hi, wire_dtype, dev), dst=r))
+                        if lo is not None:
+                            pending.append(dist.isend(_wire(lo, wire_dtype, dev), dst=r))
+                    else:
+                        pending.append(dist.isend(_wire(clips[i], wire_dtype, dev), dst=r))
         out = [None] * len(shapes)
         for i in shares[root]:
             out[i] = np.ascontiguousarray(_host(fn(np.asarray(clips[i]), sampling_frequency)), dtype=np.float64)
@@ -170,9 +204,16 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     for i in shares[rank]:
         t = torch.empty(shapes[i], dtype=tdtype, device=dev)
         dist.recv(t, src=root)
-        received.append(t)
-    for t in received:
-        y = fn(t if on_gpu else t.numpy(), sampling_frequency)
+        lo = None
+        if with_lo[i]:
+            lo = torch.empty(shapes[i], dtype=tdtype, device=dev)
+            dist.recv(lo, src=root)
+        received.append((t, lo))
+    for t, lo in received:
+        if lo is None:
+            y = fn(t if on_gpu else t.numpy(), sampling_frequency)
+        else:
+            y = fn(t if on_gpu else t.numpy(), sampling_frequency, lo if on_gpu else lo.numpy())
         if not isinstance(y, torch.Tensor):
             y = _wire(y, wire_dtype, dev)
         dist.send(y.to(tdtype), dst=root)

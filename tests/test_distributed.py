@@ -52,11 +52,35 @@ def _case_clips(rank, world):
     clips = _clips() if rank == 0 else None
     out = {}
     for name, wire in (("f64", np.float64), ("f32", np.float32)):
-        got = parallel.separate_clips("original", clips, FS, separate_fn=lambda x, fs: orc.original(np.asarray(x, dtype=np.float64), fs),
-                                      wire_dtype=wire)
+        got = parallel.separate_clips("original", clips, FS, separate_fn=_original_from_planes, wire_dtype=wire)
         if rank == 0:
             out.update({f"{name}_clip{i}": y for i, y in enumerate(got)})
     return out if rank == 0 else None
+
+
+def _original_from_planes(x, fs, remainders=None):
+    x = np.asarray(x, dtype=np.float64)
+    if remainders is not None:
+        x = x + np.asarray(remainders, dtype=np.float64)
+    return orc.original(x, fs)
+
+
+def _amplified_remainders(x, fs, remainders=None):
+    """Stand-in "separation" that shows which bits of the waveform reached the rank: the part of every sample below its fp32
+    rounding, scaled up so that it survives the fp32 wire back."""
+    x = np.asarray(x, dtype=np.float64)
+    if remainders is not None:
+        x = x + np.asarray(remainders, dtype=np.float64)
+    return (x - x.astype(np.float32).astype(np.float64)) * 2.0 ** 20
+
+
+def _case_remainders(rank, world):
+    clips = None
+    if rank == 0:
+        clips = _clips()
+        clips[3] = clips[3].astype(np.float32).astype(np.float64)      # exact in fp32 (what wavread yields): no second plane
+    got = parallel.separate_clips("sim", clips, FS, separate_fn=_amplified_remainders, wire_dtype=np.float32)
+    return {f"clip{i}": y for i, y in enumerate(got)} if rank == 0 else None
 
 
 def _window_range(window, fs, first, count, n_total, first_sample, p=None):
@@ -136,6 +160,26 @@ def test_scatter_separate_gather_two_ranks(tmp_path):
         assert np.array_equal(got[f"f64_clip{i}"], orc.original(x, FS))
         # fp32 on the wire (what the engine computes in): a worker's clips are narrowed on the way out and back
         assert np.max(np.abs(got[f"f32_clip{i}"] - orc.original(x, FS))) < 1e-5
+
+
+def test_float64_remainders_travel_with_the_clips(tmp_path):
+    """A float64 clip is sent as two fp32 planes (samples and remainders) so that a worker rank separates the 48 bits a
+    single-GPU call sees: every rank's stand-in returns the part of its samples below their fp32 rounding, and that must be
+    the original clip's -- on the root's own clips and on the worker's alike; a clip that is exact in fp32 sends one plane."""
+    got = _run("_case_remainders", tmp_path)
+    clips = _clips()
+    clips[3] = clips[3].astype(np.float32).astype(np.float64)
+    shares = parallel.deal_clips([len(c) for c in clips], 2)
+    assert 3 in shares[1] and len(shares[1]) >= 2                       # the worker rank had a clip of either kind
+    for i, x in enumerate(clips):
+        want = (x - x.astype(np.float32).astype(np.float64)) * 2.0 ** 20
+        assert (np.max(np.abs(want)) == 0) if i == 3 else (np.max(np.abs(want)) > 1e-3)
+        # what crossed the wire twice (fp32 remainder out, fp32 result back): 2^-24 relative on values below 2^-4
+        assert np.max(np.abs(got[f"clip{i}"] - want)) < 1e-8, i
+    hi, lo = parallel.split_float64(clips[0])
+    assert lo is not None and np.array_equal(hi.astype(np.float64) + lo.astype(np.float64), clips[0].astype(np.float32).astype(np.float64) + lo)
+    assert np.max(np.abs(hi.astype(np.float64) + lo.astype(np.float64) - clips[0])) < 2.0 ** -46
+    assert parallel.split_float64(clips[3])[1] is None and parallel.split_float64(clips[0].astype(np.float32))[1] is None
 
 
 def test_extended_segments_sharded_over_two_ranks(tmp_path):

