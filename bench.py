@@ -349,7 +349,7 @@ def main():
                 if name == "peaks+rank_columns":
                     entry["note"] = ("two independent launches side by side on two streams: peak picking (one wavefront per row of S, instruction- and "
                                      "latency-bound) and the column sort of V (transpose, per-column sort + rank search in LDS, transpose back); "
-                                     "bytes = S read once + the sort's passes, time = both (REPET_RANK_OVERLAP=0 lists them apart)")
+                                     "bytes = S read once + the sort's passes, time = both")
             stages.append(entry)
         dom = max(stages, key=lambda s: s["ms"])
         roof = {"kernel": dom["name"]}

@@ -386,7 +386,6 @@ struct RankArgs {
     unsigned short* R; int64_t r_chan_stride;
     float* Vs; int64_t vs_pitch;          // Vs[c * n_cols + f][vs_pitch], vs_pitch = round_up(T, 32)
     unsigned short* codes;                // scratch: the codes column-major, [c * n_cols + f][vs_pitch]
-    int32_t ablate;                       // timing experiments (REPET_RANK_ABLATE): 1 = no merge phases, 2 = no rank search
 };
 bool rank_columns_supported(int64_t T);
 hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s);

@@ -96,7 +96,6 @@ struct repet_ctx {
     hipStream_t copy_stream = nullptr;   // the remainder plane of a float64 upload follows the samples here (created on first use)
     std::vector<hipStream_t> ballast_streams;   // candidates that shared the main stream's hardware queue (pick_side_stream)
     hipEvent_t fork_event = nullptr, join_event = nullptr;
-    std::vector<hipEvent_t> chunk_events;
     // resident clip
     DevBuf staging, audio, out, out64;
     StagingRing ring;             // pinned chunks the waveforms travel through (hostio.hip)
@@ -308,10 +307,9 @@ int run_gram_full(repet_ctx* c, const float* A, int64_t T, int FS, float* S, int
 // bands (power spectra, wide dynamic range) stay on the exact-fp32 one. B clips: a_stride / band_stride in elements.
 // does the banded Gram of power spectra (beat spectrum) run on the f16-split kernel with row-scaled planes?
 bool band_rows_on_f16(repet_ctx* c, int64_t T, int FS, int n_lags, int B, int64_t a_stride) {
-    static const bool scaled = [] { const char* e = getenv("REPET_GRAM_BAND"); return !(e && e[0] == 'f' && e[1] == '3'); }();
     const int2* tiles; int n;
     if (get_tiles(c, T, gram_band_diagonals(n_lags), &tiles, &n) != REPET_OK) return false;
-    return scaled && gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS);
+    return gram_f16_enabled() && (int64_t)n * B >= 512 && (B == 1 || a_stride == round_up(T, kTile) * FS);
 }
 
 // lookback (simonline): ask for band[j][l] = row j . row j - l; granted on the f16-split kernel only (c->band_lookback says so)
@@ -347,8 +345,7 @@ int run_gram_band(repet_ctx* c, const float* A, int64_t T, int FS, float* band, 
             HIP_TRY(c->Vh.ensure((size_t)count * 4));
             HIP_TRY(launch_split_f16(A, c->Vh.p, count, c->stream));
         }
-        static const bool lookback_ok = [] { const char* e = getenv("REPET_BAND_LOOKBACK"); return !(e && e[0] == '0'); }();
-        c->band_lookback = lookback && lookback_ok;
+        c->band_lookback = lookback;
         HIP_TRY(launch_gram_band_f16(c->Vh.p, T, FS, band, n_lags, LP, tiles, n, B, 2 * per_clip, band_stride, c->stream, nullptr, 0,
                                      c->band_lookback));
         return REPET_OK;
@@ -414,12 +411,8 @@ Geo make_geo(int W, int H, int64_t T, int C) {
 // The STFT epilogue can write the f16 planes of the unit rows itself instead of a separate pass over Vn. Measured at cfg 2
 // (one clip): the split pass disappears (-0.011 ms) and the STFT grows by as much (+0.012 ms: two 2-byte stores per
 // component from a thread that owns every 256th bin) -- no gain. Measured at cfg 5 (64 clips of 30 s): the split pass is
-// 0.136 ms there, the STFT grows by 0.065: step 2.54 -> 2.47 ms. So: batches yes, single clips no; REPET_SPLIT_IN_STFT=1 / 0
-// force it either way.
-bool split_in_stft(int B) {
-    static const int forced = [] { const char* e = getenv("REPET_SPLIT_IN_STFT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    return (forced >= 0 ? forced == 1 : B > 1) && gram_f16_enabled();
-}
+// 0.136 ms there, the STFT grows by 0.065: step 2.54 -> 2.47 ms. So: batches yes, single clips no.
+bool split_in_stft(int B) { return B > 1 && gram_f16_enabled(); }
 
 // The mask kernels read V, read X and write X: 20 bytes per cell, and the inverse STFT reads X again. With the mask as a
 // plane of its own they write 4 bytes and the inverse STFT multiplies while it fetches (8 + 4): 20 instead of 28 bytes per
@@ -429,11 +422,15 @@ bool split_in_stft(int B) {
 //   simonline cfg 5 (ten similar frames: HBM)    0.763 + 0.544 -> 0.603 + 0.608   default: plane
 //   adaptive cfg 4                                0.077 + 0.055 -> 0.060 + 0.068   default: in place
 //   sim cfg 2 (selection-bound mask)              0.50 + 0.072 -> 0.50 + 0.091     default: in place
-// REPET_MASK_PLANE=0 / 1: never / in every variant.
+// REPET_MASK_PLANE=0 / 1 / p: never / in every variant (with the repeating-segment model where a variant has one) / the same
+// as a plain plane, without the model.
 enum class MaskKind { period, adaptive, sim_float, sim_ranks };
+int mask_plane_forced() {
+    static const int forced = [] { const char* e = getenv("REPET_MASK_PLANE"); return e ? (e[0] == '0' ? 0 : (e[0] == 'p' ? 2 : 1)) : -1; }();
+    return forced;
+}
 bool mask_plane_wanted(MaskKind kind) {
-    static const int forced = [] { const char* e = getenv("REPET_MASK_PLANE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced != 0 : (kind == MaskKind::period || kind == MaskKind::sim_float);
+    return mask_plane_forced() >= 0 ? mask_plane_forced() != 0 : (kind == MaskKind::period || kind == MaskKind::sim_float);
 }
 
 struct MaskPlaneScope {            // the choice holds for one pipeline; stage exports and the streaming handle never see it
@@ -537,10 +534,6 @@ int prepare_power_planes(repet_ctx* c, const Geo& g, int64_t T, int B) {
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->amax.p), 0x3f800000, (size_t)B * g.Tpad, c->stream));
     return REPET_OK;
 }
-bool power_planes_enabled() {
-    static const bool on = [] { const char* e = getenv("REPET_P_PLANES"); return !(e && e[0] == '0'); }();
-    return on;
-}
 
 // the arguments of a fused inverse STFT as far as istft_reg_takes() looks at them
 IstftOlaArgs reg_probe(int W, int channels, bool weighted, int64_t n_out, int64_t out_stride, int64_t overlap) {
@@ -562,15 +555,15 @@ int run_original(repet_ctx* c, const repet_params* p, int64_t offset, int64_t n,
     const int64_t mean_stride = g.Tpad * g.FS, band_stride = g.Tpad * LP;
     // When the beat spectrum's Gram runs on the f16-split kernel (many segments) and the forward STFT is the
     // wave-per-frame kernel, the wave that owns a frame writes the row-scaled f16 planes of P itself: no fp32 P, no
-    // second pass over it (extended 600 s: 0.34 -> 0.24 ms for the Gram stage). REPET_P_PLANES=0: the separate pass.
-    const bool p_planes = power_planes_enabled() && gram_f16_enabled() && g.Tpad == round_up(T, kTile) && reg_fft_supported(g.W, g.C, false) &&
+    // second pass over it (extended 600 s: 0.34 -> 0.24 ms for the Gram stage).
+    const bool p_planes = gram_f16_enabled() && g.Tpad == round_up(T, kTile) && reg_fft_supported(g.W, g.C, false) &&
                           (band_rows_on_f16(c, T, g.FS, hi, B, mean_stride) || (B == 1 && T >= 2048));   // (a long single clip: as in exec_adaptive)
     // The mask of a cell is soft_mask(V, W[frame mod period]) with W the medians over the repetitions -- [period][F] per clip
     // and channel, a third of a plane at most. On the register inverse STFT the mask kernel writes only W and the inverse
     // computes the mask where it multiplies it in, from |X| (magnitude(): the forward kernel's own V, bit for bit): no mask
     // plane written and read back, no second read of V by the mask kernel, no read of V by the inverse. cfg 3: mask_period
-    // 0.24 -> 0.11 ms, inverse 0.48 -> 0.51, step 1.53 -> 1.42. REPET_MASK_MODEL=0: the plane.
-    static const bool model_wanted = [] { const char* e = getenv("REPET_MASK_MODEL"); return !(e && e[0] == '0'); }();
+    // 0.24 -> 0.11 ms, inverse 0.48 -> 0.51, step 1.53 -> 1.42. REPET_MASK_PLANE=p: the plane.
+    const bool model_wanted = mask_plane_forced() != 2;
     struct ModelScope { repet_ctx* c; ~ModelScope() { c->mask_model = false; } } model_scope{c};
     // (the launcher's own test, not a copy of it: only the register kernel applies a model, and launch_istft_ola refuses
     // one on the others)
@@ -715,8 +708,7 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         // cfg 3 that is all but the last 441 000 of 26 460 000 samples (212 MB of memset, 40 us). Other kernels add onto
         // the cleared output whatever the mode says, so they get the whole clear.
         int64_t s0 = 0, s1 = 0;                                     // [s0, s1): stored by class 0 of the first batch
-        static const bool partial = [] { const char* e = getenv("REPET_EXTENDED_CLEAR"); return !(e && e[0] == 'a'); }();     // =all: the whole output
-        if (partial && uniform > 0 && Hs > 0 && L == ceil_div(L, Hs) * Hs &&
+        if (uniform > 0 && Hs > 0 && L == ceil_div(L, Hs) * Hs &&
             istft_reg_takes(reg_probe(p->window_length, c->n_channels, true, L, Hs, O))) {
             const int64_t classes = ceil_div(L, Hs), nb0 = std::min(uniform, kMaxSegmentBatch);
             const int64_t n_class0 = (nb0 + classes - 1) / classes;
@@ -744,8 +736,7 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         return REPET_OK;
     };
     const bool with_last = first + n_seg == count;                  // the longer last segment, repet.py:320-322
-    static const bool overlap_last = [] { const char* e = getenv("REPET_EXTENDED_OVERLAP"); return !(e && e[0] == '0'); }();
-    if (with_last && uniform > 0 && overlap_last) {
+    if (with_last && uniform > 0) {
         // One small clip through eight kernels is a chain of launch latencies (0.22 ms at cfg 3) -- beside the batch it
         // is free: its analysis is enqueued on the auxiliary stream FIRST, the batch follows on the main stream, and
         // only the last segment's inverse STFT (it accumulates into samples the batch also writes) waits for the batch.
@@ -810,9 +801,8 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     if (hi <= p->period_lo) return fail(REPET_ERR_TOO_SHORT, "attempt to get argmax of an empty sequence (segment too short for the period range)");
     if (p->filter_order < 1) return fail(REPET_ERR_BAD_ARG, "adaptive: filter_order must be >= 1");
     // One long clip's narrow band did not pay for the two extra passes of the f16 split (0.16 -> 0.17 ms at cfg 4); with the
-    // planes written by the forward STFT's own waves there are no extra passes. REPET_ADAPTIVE_F16=0: the fp32 MFMA kernel.
-    static const bool adaptive_f16 = [] { const char* e = getenv("REPET_ADAPTIVE_F16"); return !(e && e[0] == '0'); }();
-    const bool p_planes = adaptive_f16 && power_planes_enabled() && gram_f16_enabled() && g.Tpad == round_up(T, kTile) &&
+    // planes written by the forward STFT's own waves there are no extra passes.
+    const bool p_planes = gram_f16_enabled() && g.Tpad == round_up(T, kTile) &&
                           reg_fft_supported(g.W, g.C, false) && T >= 2048;
     RP_TRY(ensure_spectra(c, g, false, !p_planes, 1, p_planes));
     if (p_planes) RP_TRY(prepare_power_planes(c, g, T, 1));
@@ -838,15 +828,6 @@ int exec_adaptive(repet_ctx* c, const repet_params* p) {
     return REPET_OK;
 }
 
-int ensure_chunk_events(repet_ctx* c, int n) {
-    while ((int)c->chunk_events.size() < n) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->chunk_events.push_back(e);
-    }
-    return REPET_OK;
-}
-
 // Near-tie refinement of the peak picking (peaks.hip): the tolerance inside which an fp32 similarity is not
 // trusted, delta = scale * sqrt(FS) * 2^-24 (an error random walk over the FS products of unit-vector components).
 // Measured against float64 on MI355X at FS = 1056 (tools/refine_probe.py --ambiguity):
@@ -855,27 +836,15 @@ int ensure_chunk_events(repet_ctx* c, int n) {
 //                           2x loses one more row
 //   f16-split Gram kernel : rms 1.3e-7, max 1.1e-6  -> scale 2 (3.9e-6); 1x, 2x and 4x give identical lists
 // The cost grows with delta (cfg 2, f16 Gram: peaks 0.28 / 0.30 / 0.34 ms at 1x / 2x / 4x).
-// REPET_PEAK_REFINE=0 turns the refinement off (plain fp32 decisions); REPET_PEAK_DELTA_SCALE overrides the scale.
-float peak_refine_delta(int FS, bool f16_gram) {
-    static const int on = [] { const char* e = getenv("REPET_PEAK_REFINE"); return e ? atoi(e) : 1; }();
-    if (!on) return 0.0f;
-    static const float forced = [] { const char* e = getenv("REPET_PEAK_DELTA_SCALE"); return e ? (float)atof(e) : 0.0f; }();
-    const float scale = forced > 0.0f ? forced : (f16_gram ? 2.0f : 4.0f);
-    return scale * sqrtf((float)FS) * 5.9604645e-8f;
-}
+float peak_refine_delta(int FS, bool f16_gram) { return (f16_gram ? 2.0f : 4.0f) * sqrtf((float)FS) * 5.9604645e-8f; }
 
 // Second level (peaks_exact.hip): a float64 comparison of the fp32 spectra closer than this is decided again from float64
 // spectra. The level-1 values are off by up to 9.3e-8 against the float64 reference (rms 1.2e-8: fp32 FFT, magnitudes and
 // unit rows; tools/level_error_probe.py; on the device `level2_max_diff` of repet_ctx_last_exact_stats reports the largest
-// difference met), a comparison of two of them by up to twice that. REPET_PEAK_EXACT=0 turns the second level off,
-// REPET_PEAK_DELTA2 overrides the band.
+// difference met), a comparison of two of them by up to twice that; DESIGN.md 1 derives the band from the error of the fp32
+// spectra. REPET_PEAK_EXACT=0 turns the second level off.
 double peak_exact_delta2() {
-    static const double v = [] {
-        const char* off = getenv("REPET_PEAK_EXACT");
-        if (off && off[0] == '0') return 0.0;
-        const char* e = getenv("REPET_PEAK_DELTA2");
-        return e ? atof(e) : 2.5e-7;
-    }();
+    static const double v = [] { const char* off = getenv("REPET_PEAK_EXACT"); return (off && off[0] == '0') ? 0.0 : 2.5e-7; }();
     return v;
 }
 
@@ -906,9 +875,8 @@ int make_refine(repet_ctx* c, const float* unit_rows, int FS, double threshold, 
         RP_TRY(ensure_stamps(c, c->redo_flag, total));
         rf->delta2 = peak_exact_delta2(); rf->redo_list = c->redo_list.as<int32_t>(); rf->redo_flag = c->redo_flag.as<unsigned int>();
         rf->gen = ++c->exact_gen; rf->flag_stride = rows;
-        static const bool lite_on = [] { const char* e = getenv("REPET_PEAK_LITE"); return !(e && e[0] == '0'); }();
         int record_bytes = 0;
-        if (lite_on && frames > 0 && local_maxima_wave_supported(n_cols, d, &record_bytes)) {
+        if (frames > 0 && local_maxima_wave_supported(n_cols, d, &record_bytes)) {
             HIP_TRY(c->lite_list.ensure(total * 2 * sizeof(int32_t)));
             RP_TRY(ensure_stamps(c, c->lite_flag, total));
             HIP_TRY(c->lite_records.ensure(total * (size_t)record_bytes));
@@ -958,14 +926,6 @@ int run_exact_rows(repet_ctx* c, const Tables* tb, const Geo& g, const float* M,
     return REPET_OK;
 }
 
-// Row chunks of the experimental peaks -> mask two-stream pipeline (REPET_SIM_CHUNKS=n enables it). Measured on
-// MI355X at cfg 2 it LOSES: 1.09 ms unchunked vs 1.17 / 1.24 / 1.43 ms at 4 / 8 / 16 chunks -- four mask waves per
-// SIMD leave no registers for a co-resident peak-picking wave and every chunk adds a partial-occupancy tail.
-int sim_chunks(int64_t) {
-    static const int forced = [] { const char* e = getenv("REPET_SIM_CHUNKS"); return e ? atoi(e) : 0; }();
-    return forced > 1 ? forced : 1;
-}
-
 // REPET_MEDIAN=f32 keeps the selection of `sim` on the float magnitudes; default: the rank-domain form (rank.hip) when
 // the clip is long enough for it to pay (the column sort is a fixed cost, the saving grows with the list length).
 bool rank_median_enabled() {
@@ -1005,7 +965,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const Geo g = make_geo(p->window_length, p->step_length, T, c->n_channels);
     if (p->sim_number < 1) return fail(REPET_ERR_BAD_ARG, "similarity_number must be >= 1");
     // (the same test as below: the median on rank codes multiplies X in place, the float path keeps the mask apart)
-    const bool ranks_ahead = sim_chunks(T) <= 1 && rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
+    const bool ranks_ahead = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
                              std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1)) >= kRankMinList &&
                              std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1)) <= 128;
     MaskPlaneScope plane(c, mask_plane_wanted(ranks_ahead ? MaskKind::sim_ranks : MaskKind::sim_float));
@@ -1039,10 +999,9 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
     // peaks are more than d frames apart: at most ceil(T/(d+1)) of them, whatever similarity_number says
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
-    const int n_chunks = sim_chunks(T);
     PeakRefine rf{};
-    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf, n_chunks <= 1 ? T : 0, 1, (int)T, p->sim_distance_frames, T));
-    if (n_chunks <= 1) {
+    RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf, T, 1, (int)T, p->sim_distance_frames, T));
+    {
         MaskArgs m = mask_args(c, g, p->cutoff_bins);
         const bool use_rank = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
                               max_peaks >= kRankMinList && max_peaks <= 128;
@@ -1051,9 +1010,8 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         // row: tools/peak_stamps.py), which the sort's workgroups fill. (Beside the Gram kernel it does not pay: a sort
         // workgroup on a CU keeps the Gram's 139 KB workgroup off it -- and so does the memory-bound transpose that opens
         // the sort, although its 17 KB of LDS fit beside a Gram workgroup: Gram 0.209 -> 0.244 ms for 0.015 ms saved
-        // afterwards.) REPET_RANK_OVERLAP=0: one after the other.
-        static const bool rank_overlap = [] { const char* e = getenv("REPET_RANK_OVERLAP"); return !(e && e[0] == '0'); }();
-        const bool beside = use_rank && rank_overlap;
+        // afterwards.)
+        const bool beside = use_rank;
         // (Measured and dropped: starting the sort behind the first pass of the peak picking, beside its second level --
         // peaks + sort 0.446 against 0.419 ms: the second level's kernels hold a whole register file per wave and do not share
         // a CU with the sort any better than the first pass does.)
@@ -1092,37 +1050,6 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
                                 c->fork_event, c->join_event));
         mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
-    } else {
-        // Peak picking is LDS/latency-bound, the median mask VALU-bound: run them as a two-stage pipeline over
-        // row chunks -- chunk k+1 is picked on the side stream while chunk k is masked on the main stream.
-        RP_TRY(ensure_chunk_events(c, n_chunks));
-        HIP_TRY(hipEventRecord(c->fork_event, c->stream));              // S is complete here
-        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
-        const int64_t step = round_up(ceil_div(T, n_chunks), 4);
-        for (int k = 0; k < n_chunks; ++k) {
-            const int64_t a0 = k * step, a1 = std::min<int64_t>(T, a0 + step);
-            if (a0 >= a1) break;
-            hipError_t e = launch_local_maxima(c->S.as<float>(), a1 - a0, a0, (int)T, TS, 0, (float)p->sim_threshold,
-                                               p->sim_distance_frames, K, c->idx.as<int32_t>() + a0 * KP, KP,
-                                               c->cnt.as<int32_t>() + a0, c->side_stream, 0, &rf, nullptr, nullptr, nullptr, seg, seg_pitch);
-            if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
-            HIP_TRY(e);
-            HIP_TRY(hipEventRecord(c->chunk_events[k], c->side_stream));
-        }
-        MaskArgs m = mask_args(c, g, p->cutoff_bins);
-        for (int k = 0; k < n_chunks; ++k) {
-            const int64_t a0 = k * step, a1 = std::min<int64_t>(T, a0 + step);
-            if (a0 >= a1) break;
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_events[k], 0));
-            m.frame0 = a0; m.frame_end = a1;
-            HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, nullptr, nullptr, nullptr, 1));
-        }
-        // the Nyquist bins of every frame, beside the last mask chunks
-        m.frame0 = 0; m.frame_end = 0;
-        HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->side_stream, nullptr, nullptr, nullptr, 2));
-        HIP_TRY(hipEventRecord(c->join_event, c->side_stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->join_event, 0));
-        mark(c, "peaks+mask", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     }
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = KP; c->last_idx_number = K;
@@ -1265,8 +1192,7 @@ __global__ void queue_probe_kernel(unsigned long long ticks) {          // ticks
 }
 
 hipError_t pick_side_stream(repet_ctx* c, bool probe_wanted) {
-    static const bool probe_on = [] { const char* e = getenv("REPET_QUEUE_PROBE"); return !(e && e[0] == '0'); }();
-    const bool probe = probe_on && probe_wanted;
+    const bool probe = probe_wanted;
     hipError_t e = hipSuccess;
     hipEvent_t t_begin = nullptr, t_end = nullptr;           // device-side timing: a loaded host (profiler, sanitizer build) must
     if (probe) {                                             // not make every candidate look serialised
@@ -1303,8 +1229,6 @@ hipError_t pick_side_stream(repet_ctx* c, bool probe_wanted) {
             float ms = 0.f;
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, t_begin, t_end);
             overlaps = ms < 0.32f;
-            static const bool say = [] { const char* v = getenv("REPET_QUEUE_PROBE"); return v && v[0] == '2'; }();
-            if (say) fprintf(stderr, "repet: side-stream candidate %d: %.0f us on the device, %s the main stream\n", attempt, ms * 1e3, overlaps ? "overlaps" : "is serialised with");
         }
         if (overlaps || attempt == 7) { c->side_stream = cand; break; }
         c->ballast_streams.push_back(cand);
@@ -1336,7 +1260,7 @@ int ctx_create(int device, repet_ctx** out, bool probe_side_stream) {
     // independent kernels of two streams on one queue still overlap -- it is the fork / dependent kernels / join pattern of
     // a run that does not. So the context times exactly that pattern with wait kernels (pick_side_stream): 0.2 ms when the
     // candidate overlaps the main stream, 0.4 ms when not. A candidate that does not is kept open (it raises its queue's
-    // use count, the next one goes elsewhere) until the context is destroyed. REPET_QUEUE_PROBE=0 skips the test, =2 logs it.
+    // use count, the next one goes elsewhere) until the context is destroyed.
     if (e == hipSuccess) e = pick_side_stream(c, probe_side_stream);
     if (e != hipSuccess) { repet_ctx_destroy(c); return fail(REPET_ERR_HIP, hipGetErrorString(e)); }
     *out = c;
@@ -1369,7 +1293,6 @@ int repet_ctx_destroy(repet_ctx* c) {
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipStream_t b : c->ballast_streams) (void)hipStreamDestroy(b);
-    for (hipEvent_t e : c->chunk_events) (void)hipEventDestroy(e);
     if (c->fork_event) (void)hipEventDestroy(c->fork_event);
     if (c->join_event) (void)hipEventDestroy(c->join_event);
     (void)hipStreamDestroy(c->stream);
@@ -1441,11 +1364,10 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     // converted; the caller's array has been read completely when this returns (the last DMAs may still be in flight
     // on the context's stream, which every later operation of the context is ordered behind)
     // float64 input: the fp32 remainders travel too where they are not zero (peaks_exact.hip takes its float64 spectra from
-    // sample + remainder); REPET_INPUT_LO=0 drops them (the second level then works on the fp32 samples alone)
-    static const bool want_lo = [] { const char* e = getenv("REPET_INPUT_LO"); return !(e && e[0] == '0'); }();
+    // sample + remainder)
     c->has_lo = false;
     float* lo_dst = nullptr;
-    if (dtype == REPET_F64 && want_lo && count > 0) {
+    if (dtype == REPET_F64 && count > 0) {
         HIP_TRY(c->audio_lo.ensure((size_t)count * sizeof(float)));
         lo_dst = c->audio_lo.as<float>();
     }
@@ -1522,48 +1444,6 @@ int repet_ctx_upload(repet_ctx* c, const void* audio, int dtype, int64_t n, int3
 }
 
 namespace {
-// REPET_CHAIN=1: pipelines of different contexts on one device run back to back on the GPU instead of interleaved. It
-// was the default while an interaction between contexts was unexplained (DESIGN.md "Contexts and concurrency": on
-// gfx950 packed-fp32 VALU results are corrupted beside another kernel's v_mfma_f32_32x32x16_f16; the library is now
-// built without packed-fp32 ops and 4 million overlapped pipelines came back clean). Interleaving is worth 14 % on
-// four 180-s clips and 1.8x on eight 30-s clips, so the chain is opt-in: a mutex covers the ENQUEUE of a pipeline,
-// the ordering itself is a stream-wait on an event, nobody blocks on the host for GPU work.
-struct DeviceChain {
-    std::mutex m;
-    hipEvent_t ring[8] = {};
-    int next = 0;
-    bool have_tail = false;
-    hipEvent_t tail = nullptr;
-};
-DeviceChain g_chains[16];
-
-struct ChainScope {
-    DeviceChain* d;
-    repet_ctx* c;
-    bool published = false;
-    explicit ChainScope(repet_ctx* ctx) : d(&g_chains[ctx->device & 15]), c(ctx) {
-        static const bool on = [] { const char* e = getenv("REPET_CHAIN"); return e && atoi(e) != 0; }();
-        if (!on) { published = true; return; }
-        d->m.lock();
-        if (d->have_tail) (void)hipStreamWaitEvent(c->stream, d->tail, 0);
-    }
-    void publish() {                       // everything enqueued on c->stream so far precedes the next pipeline
-        if (published) return;
-        published = true;
-        hipEvent_t& e = d->ring[d->next];
-        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-        if (e && hipEventRecord(e, c->stream) == hipSuccess) {
-            d->tail = e;
-            d->have_tail = true;
-            d->next = (d->next + 1) & 7;
-        }
-        d->m.unlock();
-    }
-    ~ChainScope() { publish(); }
-};
-}  // namespace
-
-namespace {
 int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
     // (the pipelines that never reach make_refine must not leave "cleared by the housekeeping launch" standing for a later
     // caller -- the streaming handle's make_refine -- to trust)
@@ -1605,14 +1485,12 @@ int repet_ctx_execute(repet_ctx* c, int algo, const repet_params* p, repet_timin
     RP_TRY(check_params(p));
     if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
     DeviceGuard guard(c->device);
-    ChainScope chain(c);
     begin_timing(c, timing);
     c->last_algo = algo;
     c->last_n_periods = 0;
     c->last_idx_rows = 0;
     c->last_idx_batch = 1;
     int rc = run_algo(c, algo, p);
-    chain.publish();
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
     if (rc == REPET_OK) end_timing(c);
@@ -1625,7 +1503,6 @@ int repet_ctx_execute_async(repet_ctx* c, int algo, const repet_params* p) {
     RP_TRY(check_params(p));
     if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
     DeviceGuard guard(c->device);
-    ChainScope chain(c);
     c->timing = nullptr;
     const bool timed = c->series_on && c->series_steps < c->series_cap;
     if (timed) {
@@ -1709,12 +1586,10 @@ int repet_ctx_execute_extended_range(repet_ctx* c, const repet_params* p, int64_
     if (n_seg < 0) return fail(REPET_ERR_BAD_ARG, "negative segment count");
     if (c->n_clips > 1) return fail(REPET_ERR_BAD_ARG, "segment ranges apply to a single resident clip, not to a batch context");
     DeviceGuard guard(c->device);
-    ChainScope chain(c);
     begin_timing(c, timing);
     c->last_algo = REPET_EXTENDED;
     c->last_n_periods = 0;
     int rc = exec_extended(c, p, first, n_seg);
-    chain.publish();
     hipError_t e = hipStreamSynchronize(c->stream);
     if (rc == REPET_OK && e != hipSuccess) rc = fail(REPET_ERR_HIP, std::string("execute: ") + hipGetErrorString(e));
     if (rc == REPET_OK) end_timing(c);
@@ -2170,8 +2045,7 @@ int repet_last_batch_info(int64_t out[4]) {
 
 int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
                     const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {
-    const char* e = getenv("REPET_BATCH_TRANSPORT");
-    return run_batch_impl(algo, n_clips, audio, dtype, n_samples, n_channels, p, out, n_devices, (e && e[0] == 'r') ? 1 : 0);
+    return run_batch_impl(algo, n_clips, audio, dtype, n_samples, n_channels, p, out, n_devices, 0);
 }
 
 int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
@@ -2611,7 +2485,6 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
     Tables* tb = nullptr;
     RP_TRY(get_tables(c, o->W, &tb));
     RP_TRY(online_ensure_windows(o, n_new));
-    ChainScope chain(c);                                         // after the (synchronising) window growth
     const int64_t plane = (o->rows_cap + kPadRows) * o->FS;      // chan_stride of X and V
     const int64_t r0 = o->Hh - o->hist_valid;                    // first valid window row
     const int64_t Tw = o->hist_valid + n_new;                    // valid rows (history + new), relative to r0
@@ -2710,7 +2583,6 @@ int online_process(repet_online* o, int64_t n_new, int64_t n_emit, double* out) 
         o->pend_count = left;
         o->frames_done += n_new;
     }
-    chain.publish();
     HIP_TRY(hipStreamSynchronize(c->stream));
     o->emitted += n_emit;
     return REPET_OK;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void split_f16_rows_kernel(const float* __rest
 
 // BAND: out[t][l] = row t . row t+l for 0 <= l < n_lags (pitch = band pitch), only the tiles that touch those lags;
 // blockIdx.y = clip of a batch (strides in halves / floats).
-template <bool BAND, bool DMA>
+template <bool BAND>
 __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
                                                        float* __restrict__ out, int64_t pitch,
                                                        const int2* __restrict__ tiles, int n_lags,
@@ -126,13 +126,14 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    if constexpr (DMA) {
-    // Round 3: the K loop of gram_f16_big.hip's rescheduled kernel on this tile. The K-tiles go global -> LDS directly
+    {
+    // Round 3: the K loop of gram_f16_big.hip's rescheduled kernel on this tile (the register-staged loop of rounds 1-2 -- three
+    // staging register sets, ds_write_b128 -- is in the history). The K-tiles go global -> LDS directly
     // (global_load_lds_dwordx4, 1-KB pieces of 16 rows x 64 bytes of one plane, the XOR swizzle applied on the per-lane
     // SOURCE chunk): no staging registers (three sets of 32 were a third of the register file) and no ds_write_b128
     // traffic (32 KB per K-tile at 79 B/clk was more LDS time than the fragment reads). One barrier per K-tile, in its
     // middle; the DMA pieces of tile k+2 and the fragment reads of the next half tile ride between the MFMAs, the
-    // fragments into a second register set. Same products in the same order: bit-identical to the loop below.
+    // fragments into a second register set. Same products in the same order as every other f16-split kernel.
     const unsigned grow = (unsigned)(2 * FS);
     const int prow = lane >> 2;
     const _Float16* src_lane[8];
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
     auto half_tile = [&](const Frags& f, Frags& g, int g_kt, int g_ks, int dma_kt, bool dma) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-            const int grp = i >> 2, m = (i >> 1) & 1, n = i & 1;          // lo hi', hi lo', hi hi': the order of the loop below
+            const int grp = i >> 2, m = (i >> 1) & 1, n = i & 1;          // lo hi', hi lo', hi hi'
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(grp == 0 ? f.al[m] : f.ah[m], grp == 1 ? f.bl[n] : f.bh[n],
                                                                 acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -200,107 +201,6 @@ __global__ __launch_bounds__(256) void gram_f16_kernel(const _Float16* __restric
         half_tile(fb, fa, kt + 1 < nk ? kt + 1 : kt, 0, kt + 2, kt + 2 < nk);
     }
     __syncthreads();
-    } else {
-    // staging: per operand and K-tile 128 rows x (4 hi + 4 lo chunks of 16 bytes) = one cache line per row; a thread
-    // takes chunk (tid & 7) of rows (tid >> 3) + 32 j, j < 4: a wave-load covers 8 whole lines
-    const int srow = tid >> 3, sch = tid & 7;
-    const int splane = sch >> 2, schunk = sch & 3;                       // hi / lo, 16-byte chunk inside the plane row
-    const unsigned grow = (unsigned)(2 * FS);                            // halves per row of the interleaved image
-    const unsigned g0 = (unsigned)(srow * grow + sch * 8);               // halves, relative to (tile row 0, K-tile 0)
-    // LDS: plane p of an operand at p * kPlanePitch; chunk c of row r at c ^ ((r >> 2) & 3)
-    const int l0 = splane * kPlanePitch + srow * HBK + ((schunk ^ ((srow >> 2) & 3)) << 3);
-    // three staging register sets: tile t travels in set t % 3, so a K-tile has TWO iterations (~2 x 800 cycles of
-    // MFMA) to arrive before it is written to LDS -- with the 768-cycle f16 iterations one iteration of slack (two
-    // sets) left the loop waiting on L2 / Infinity-Cache latency; a fourth set does not fit beside the accumulators
-    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define F16_LOAD_TILE(S, kt)                                                          \
-    {                                                                                 \
-        const _Float16* ap = planes + a_row0 * grow + (kt) * 64 + g0;                 \
-        const _Float16* bp = planes + b_row0 * grow + (kt) * 64 + g0;                 \
-        S##a0 = *reinterpret_cast<const float4*>(ap);                                 \
-        S##b0 = *reinterpret_cast<const float4*>(bp);                                 \
-        S##a1 = *reinterpret_cast<const float4*>(ap + 32 * grow);                     \
-        S##b1 = *reinterpret_cast<const float4*>(bp + 32 * grow);                     \
-        S##a2 = *reinterpret_cast<const float4*>(ap + 64 * grow);                     \
-        S##b2 = *reinterpret_cast<const float4*>(bp + 64 * grow);                     \
-        S##a3 = *reinterpret_cast<const float4*>(ap + 96 * grow);                     \
-        S##b3 = *reinterpret_cast<const float4*>(bp + 96 * grow);                     \
-    }
-#define F16_STORE_TILE(S, buf)                                                        \
-    {                                                                                 \
-        _Float16* abase = ldsh + (buf) * 2 * kOperandHalves + l0;                     \
-        _Float16* bbase = abase + kOperandHalves;                                     \
-        *reinterpret_cast<float4*>(abase) = S##a0;                                    \
-        *reinterpret_cast<float4*>(bbase) = S##b0;                                    \
-        *reinterpret_cast<float4*>(abase + 32 * HBK) = S##a1;                         \
-        *reinterpret_cast<float4*>(bbase + 32 * HBK) = S##b1;                         \
-        *reinterpret_cast<float4*>(abase + 64 * HBK) = S##a2;                         \
-        *reinterpret_cast<float4*>(bbase + 64 * HBK) = S##b2;                         \
-        *reinterpret_cast<float4*>(abase + 96 * HBK) = S##a3;                         \
-        *reinterpret_cast<float4*>(bbase + 96 * HBK) = S##b3;                         \
-    }
-    // fragment of lane (lr, lh) for MFMA block row/col `blk` (0/1) of this wave and K-step `ks` (0/1): 8 halves
-    // k = 16 ks + 8 lh .. +7 of tile row  w*64 + blk*32 + lr  -> chunk 2 ks + lh, swizzled by the row
-#define F16_FRAG(plane_ptr, w, blk, ks)                                                                        \
-    (*reinterpret_cast<const halfx8*>((plane_ptr) + ((w) * 64 + (blk) * 32 + lr) * HBK +                       \
-                                      (((2 * (ks) + lh) ^ (((lr) >> 2) & 3)) << 3)))
-#define F16_COMPUTE(buf)                                                                                        \
-    {                                                                                                           \
-        const _Float16* base = ldsh + (buf) * 2 * kOperandHalves;                                               \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                      \
-            const halfx8 ah0 = F16_FRAG(base, wr, 0, ks), ah1 = F16_FRAG(base, wr, 1, ks);                      \
-            const halfx8 al0 = F16_FRAG(base + kPlanePitch, wr, 0, ks), al1 = F16_FRAG(base + kPlanePitch, wr, 1, ks); \
-            const halfx8 bh0 = F16_FRAG(base + kOperandHalves, wc, 0, ks), bh1 = F16_FRAG(base + kOperandHalves, wc, 1, ks); \
-            const halfx8 bl0 = F16_FRAG(base + kOperandHalves + kPlanePitch, wc, 0, ks), bl1 = F16_FRAG(base + kOperandHalves + kPlanePitch, wc, 1, ks); \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);                    \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);                    \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);                    \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);                    \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);                    \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);                    \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);                    \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);                    \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);                    \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);                    \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);                    \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);                    \
-        }                                                                                                       \
-    }
-
-    const int nk = FS / HBK;                // FS is a multiple of 32; nk >= 2 for every supported window
-    const int klast = nk - 1;
-    F16_LOAD_TILE(p, 0)
-    F16_LOAD_TILE(q, min(1, klast))
-    F16_LOAD_TILE(r, min(2, klast))
-    F16_STORE_TILE(p, 0)
-    __syncthreads();
-    // iteration kt: LDS[kt & 1] holds tile kt, the sets hold kt+1 and kt+2, the set of tile kt is free for kt+3.
-    // No branch inside a step: past the end the loads re-read the last tile and the LDS store goes to the buffer
-    // nobody reads any more. With conditional loads hipcc's waitcnt pass gave up at the joins and waited vmcnt(0)
-    // -- for the prefetches just issued -- before every barrier.
-#define F16_STEP(FREE, NEXT, kt)                                    \
-    {                                                               \
-        F16_LOAD_TILE(FREE, min((kt) + 3, klast))                   \
-        F16_COMPUTE((kt) & 1)                                       \
-        F16_STORE_TILE(NEXT, ((kt) + 1) & 1)                        \
-        __syncthreads();                                            \
-    }
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 3) {
-        F16_STEP(p, q, kt)
-        F16_STEP(q, r, kt + 1)
-        F16_STEP(r, p, kt + 2)
-    }
-    if (kt < nk) { F16_STEP(p, q, kt) ++kt; }
-    if (kt < nk) { F16_STEP(q, r, kt) ++kt; }
-#undef F16_STEP
-#undef F16_LOAD_TILE
-#undef F16_STORE_TILE
-#undef F16_FRAG
-#undef F16_COMPUTE
-
     }
 
     // ---- epilogue. acc[m][n][r]: i = wr*64 + m*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wc*64 + n*32 + lr
@@ -431,18 +331,9 @@ hipError_t launch_split_f16_rows(const float* src, void* planes, int64_t n_rows,
 hipError_t launch_gram_full_f16(const void* planes, int64_t T, int32_t FS, float* S, int64_t TS,
                                 const int2* tiles, int32_t n_tiles, hipStream_t s) {
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
-    static const bool dma = [] { const char* e = getenv("REPET_GRAM_DMA"); return !(e && e[0] == '0'); }();
-    if (dma) {
-        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false, true>), kGramF16LdsAsk);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL((gram_f16_kernel<false, true>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
-                           reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
-                           (const float*)nullptr, (int64_t)0, 0);
-        return hipGetLastError();
-    }
-    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false, false>), kGramF16LdsAsk);
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<false>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gram_f16_kernel<false, false>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
+    hipLaunchKernelGGL((gram_f16_kernel<false>), dim3((unsigned)n_tiles), dim3(256), kGramF16LdsAsk, s,
                        reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, 0, (int64_t)0, (int64_t)0,
                        (const float*)nullptr, (int64_t)0, 0);
     return hipGetLastError();
@@ -452,19 +343,9 @@ hipError_t launch_gram_band_f16(const void* planes, int64_t T, int32_t FS, float
                                 const int2* tiles, int32_t n_tiles, int32_t n_batch, int64_t plane_batch_stride,
                                 int64_t band_batch_stride, hipStream_t s, const float* row_inv, int64_t inv_batch_stride, bool lookback) {
     if (T <= 0 || n_lags <= 0 || n_tiles <= 0) return hipSuccess;
-    // REPET_GRAM_DMA=0: the register-staged K loop of rounds 1-2
-    static const bool dma = [] { const char* e = getenv("REPET_GRAM_DMA"); return !(e && e[0] == '0'); }();
-    if (dma) {
-        hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true, true>), kGramF16LdsAsk);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL((gram_f16_kernel<true, true>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
-                           kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
-                           plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride, lookback ? 1 : 0);
-        return hipGetLastError();
-    }
-    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true, false>), kGramF16LdsAsk);
+    hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_kernel<true>), kGramF16LdsAsk);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gram_f16_kernel<true, false>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
+    hipLaunchKernelGGL((gram_f16_kernel<true>), dim3((unsigned)n_tiles, (unsigned)(n_batch > 0 ? n_batch : 1)), dim3(256),
                        kGramF16LdsAsk, s, reinterpret_cast<const _Float16*>(planes), T, FS, band, (int64_t)LP, tiles, n_lags,
                        plane_batch_stride, band_batch_stride, row_inv, inv_batch_stride, lookback ? 1 : 0);
     return hipGetLastError();

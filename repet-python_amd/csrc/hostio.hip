@@ -45,8 +45,15 @@ public:
     // for the next job for a while before it goes back to sleep on the condition variable, and the caller spins for the parts
     // -- woken through the condition variable every time, the hand-over cost 30 .. 50 us per chunk, a millisecond per clip.
     void run(const std::function<void(int, int)>& fn, size_t work_items = ~(size_t)0) {
-        if (n_threads_ <= 1 || work_items < 65536) { fn(0, 1); return; }     // not worth waking anybody up
-        std::lock_guard<std::mutex> one_job(job_mutex_);
+        if (!start(fn, work_items)) { fn(0, 1); return; }
+        finish(fn);
+    }
+    // The same in two steps: start() hands the job to the workers and returns (false: too small, the caller runs fn(0, 1)
+    // itself at finish time); the caller does something else -- enqueue the previous chunk's DMA -- and then finish() runs its
+    // own part and waits for the others. A job that was started must be finished by the same thread.
+    bool start(const std::function<void(int, int)>& fn, size_t work_items = ~(size_t)0) {
+        if (n_threads_ <= 1 || work_items < 65536) return false;     // not worth waking anybody up
+        job_mutex_.lock();
         fn_ = &fn;
         pending_.store(n_threads_ - 1, std::memory_order_relaxed);
         {
@@ -54,11 +61,15 @@ public:
             generation_.fetch_add(1, std::memory_order_release);
         }
         if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+        return true;
+    }
+    void finish(const std::function<void(int, int)>& fn) {
         fn(0, n_threads_);
         for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
             if (spins < 20000) cpu_relax(); else std::this_thread::yield();
         }
         fn_ = nullptr;
+        job_mutex_.unlock();
     }
 
 private:
@@ -242,51 +253,69 @@ hipError_t staged_upload(StagingRing& ring, const void* src, int dtype, float* d
     const size_t n_chunks = (count + StagingRing::kSlotElems - 1) / StagingRing::kSlotElems;
     std::vector<char> chunk_has_lo(deferred ? n_chunks : 0, 0);
     std::atomic<bool> met_not_finite{false};
-    for (size_t c = 0; c < n_chunks; ++c) {
-        const int slot = (int)(c % StagingRing::kSlots);
-        if (ring.busy[slot]) { e = hipEventSynchronize(ring.event[slot]); if (e != hipSuccess) return e; }
-        const size_t lo = c * StagingRing::kSlotElems, cnt = std::min(StagingRing::kSlotElems, count - lo);
-        float* stage = ring.base + (size_t)slot * StagingRing::kSlotElems;
-        float* stage_lo = !split ? nullptr : (deferred ? ring.lo_full + lo : ring.base_lo + (size_t)slot * StagingRing::kSlotElems);
-        std::atomic<unsigned> parts_with_lo{0};                 // (at most 32 parts)
-        int parts_run = 1;
-        pool.run([&](int part, int parts) {
-            const size_t a = cnt * part / parts, b = cnt * (part + 1) / parts;
-            if (part == 0) parts_run = parts;
-            bool bad = false;
-            if (split) {
-                if (split_part(static_cast<const double*>(src) + lo, stage, stage_lo, a, b, &bad)) parts_with_lo.fetch_or(1u << part, std::memory_order_relaxed);
-            }
-            else if (dtype == 1) bad = narrow_f64(static_cast<const double*>(src) + lo, stage, a, b);
-            else if (dtype == 2) narrow_i16(static_cast<const int16_t*>(src) + lo, stage, a, b);
-            else bad = narrow_f32(static_cast<const float*>(src) + lo, stage, a, b);
-            if (bad) met_not_finite.store(true, std::memory_order_relaxed);
-        }, cnt);
+    // Chunk c is converted by the workers WHILE this thread enqueues chunk c - 1 (a copy and an event: 10 .. 20 us of driver
+    // calls per chunk, a third of what converting a chunk takes): convert(c) is started, issue(c - 1) runs, then this thread
+    // takes its own part of chunk c.
+    struct Chunk { size_t lo = 0, cnt = 0; int slot = 0; float* stage = nullptr; float* stage_lo = nullptr; unsigned with_lo = 0; int parts = 1; };
+    auto issue = [&](const Chunk& k, size_t c) -> hipError_t {
         // a chunk's remainders travel whole or not at all: a part that met none wrote nothing, so when another part did, its
         // share of the staged plane is cleared here (mixed chunks are rare: clips are PCM-exact or they are not)
-        const unsigned with_lo = parts_with_lo.load();
-        const bool chunk_lo = with_lo != 0;
+        const bool chunk_lo = k.with_lo != 0;
         if (chunk_lo)
-            for (int part = 0; part < parts_run; ++part)
-                if (!(with_lo >> part & 1u)) {
-                    const size_t a = cnt * part / parts_run, b = cnt * (part + 1) / parts_run;
-                    std::memset(stage_lo + a, 0, (b - a) * sizeof(float));
+            for (int part = 0; part < k.parts; ++part)
+                if (!(k.with_lo >> part & 1u)) {
+                    const size_t a = k.cnt * part / k.parts, b = k.cnt * (part + 1) / k.parts;
+                    std::memset(k.stage_lo + a, 0, (b - a) * sizeof(float));
                 }
-        e = hipMemcpyAsync(dst + lo, stage, cnt * sizeof(float), hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) return e;
+        hipError_t r = hipMemcpyAsync(dst + k.lo, k.stage, k.cnt * sizeof(float), hipMemcpyHostToDevice, s);
+        if (r != hipSuccess) return r;
         if (split && !deferred) {
-            if (chunk_lo) { e = hipMemcpyAsync(dst_lo + lo, stage_lo, cnt * sizeof(float), hipMemcpyHostToDevice, s); if (any_lo) *any_lo = true; }
-            else e = hipMemsetAsync(dst_lo + lo, 0, cnt * sizeof(float), s);
-            if (e != hipSuccess) return e;
+            if (chunk_lo) { r = hipMemcpyAsync(dst_lo + k.lo, k.stage_lo, k.cnt * sizeof(float), hipMemcpyHostToDevice, s); if (any_lo) *any_lo = true; }
+            else r = hipMemsetAsync(dst_lo + k.lo, 0, k.cnt * sizeof(float), s);
+            if (r != hipSuccess) return r;
         }
         if (deferred && chunk_lo) {
             chunk_has_lo[c] = 1;
             if (any_lo) *any_lo = true;
         }
-        e = hipEventRecord(ring.event[slot], s);
-        if (e != hipSuccess) return e;
-        ring.busy[slot] = true;
+        r = hipEventRecord(ring.event[k.slot], s);
+        if (r != hipSuccess) return r;
+        ring.busy[k.slot] = true;
+        return hipSuccess;
+    };
+    Chunk prev;
+    bool have_prev = false;
+    for (size_t c = 0; c < n_chunks; ++c) {
+        Chunk k;
+        k.slot = (int)(c % StagingRing::kSlots);
+        if (ring.busy[k.slot]) { e = hipEventSynchronize(ring.event[k.slot]); if (e != hipSuccess) return e; }
+        k.lo = c * StagingRing::kSlotElems;
+        k.cnt = std::min(StagingRing::kSlotElems, count - k.lo);
+        k.stage = ring.base + (size_t)k.slot * StagingRing::kSlotElems;
+        k.stage_lo = !split ? nullptr : (deferred ? ring.lo_full + k.lo : ring.base_lo + (size_t)k.slot * StagingRing::kSlotElems);
+        std::atomic<unsigned> parts_with_lo{0};                 // (at most 32 parts)
+        int parts_run = 1;
+        const std::function<void(int, int)> convert = [&](int part, int parts) {
+            const size_t a = k.cnt * part / parts, b = k.cnt * (part + 1) / parts;
+            if (part == 0) parts_run = parts;
+            bool bad = false;
+            if (split) {
+                if (split_part(static_cast<const double*>(src) + k.lo, k.stage, k.stage_lo, a, b, &bad)) parts_with_lo.fetch_or(1u << part, std::memory_order_relaxed);
+            }
+            else if (dtype == 1) bad = narrow_f64(static_cast<const double*>(src) + k.lo, k.stage, a, b);
+            else if (dtype == 2) narrow_i16(static_cast<const int16_t*>(src) + k.lo, k.stage, a, b);
+            else bad = narrow_f32(static_cast<const float*>(src) + k.lo, k.stage, a, b);
+            if (bad) met_not_finite.store(true, std::memory_order_relaxed);
+        };
+        const bool started = pool.start(convert, k.cnt);
+        if (have_prev) { e = issue(prev, c - 1); if (e != hipSuccess) { if (started) pool.finish(convert); return e; } }
+        if (started) pool.finish(convert); else convert(0, 1);
+        k.with_lo = parts_with_lo.load();
+        k.parts = parts_run;
+        prev = k;
+        have_prev = true;
     }
+    if (have_prev) { e = issue(prev, n_chunks - 1); if (e != hipSuccess) return e; }
     if (deferred) {
         // the remainder plane: behind the last chunk of samples, on the other stream
         e = hipEventRecord(ring.hi_done, s);

@@ -503,9 +503,7 @@ static hipError_t launch_by_size(const PeakArgs& a, dim3 grid, size_t bytes, hip
 // Elements per segment of a long row: what 8 float4 groups per thread hold beside the two halos of d elements
 // (0: the window is too wide to segment, the whole-row kernel is used).
 static int peak_segment_length(int d) {
-    static const int forced = [] { const char* e = getenv("REPET_PEAK_SEGMENT"); return e ? atoi(e) & ~3 : 0; }();   // experiments
     const int seg = ((8 * 256 - 3) * 4 - (int)round_up(d, 4) - d) & ~3;
-    if (forced >= 512 && forced < seg) return forced;
     return seg >= 2048 ? seg : 0;
 }
 

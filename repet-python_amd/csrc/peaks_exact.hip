@@ -398,7 +398,7 @@ __device__ __forceinline__ void wave_unit_row_f64_reg(const ExactSource& s, int 
 }
 
 // Which transform a kernel instance carries (one per instance: their registers must not add up): the register transform of the
-// 2048-sample window, the radix-4 Stockham transform in LDS (W < 2048; REPET_EXACT_FFT=lds: W = 2048 too), the radix-2 one
+// 2048-sample window, the radix-4 Stockham transform in LDS (W < 2048), the radix-2 one
 // (W > 2048).
 constexpr int kFftReg = 0, kFftLds4 = 1, kFftLdsAcc = 2;
 template <int V>
@@ -412,12 +412,10 @@ __device__ __forceinline__ void unit_row_variant(const ExactSource& src, int log
 // Which transform a launch carries and what it needs of the LDS.
 struct FftPlan { int variant, tw_count, wave_bytes, fixed_bytes; };
 static FftPlan fft_plan(int W, bool allow_reg = true) {
-    // W = 2048: the register transform (62 us per stereo frame alone; REPET_EXACT_FFT=lds: the radix-4 LDS transform, 80 us alone
-    // with a third of the registers -- beside the column sort both take 130 us, so the smaller footprint buys nothing)
-    static const bool want_lds = [] { const char* e = getenv("REPET_EXACT_FFT"); return e && e[0] == 'l'; }();
+    // W = 2048: the register transform (62 us per stereo frame alone; the radix-4 LDS transform 80 us with a third of the registers)
     const int Mh = W / 2;
     FftPlan p{};
-    if (W == 2048 && !want_lds && allow_reg) {
+    if (W == 2048 && allow_reg) {
         p.variant = kFftReg; p.tw_count = 0; p.wave_bytes = f64fft::kExPitch * (int)sizeof(double2);
         p.fixed_bytes = f64fft::kTwCount * (int)sizeof(double2);
     } else if (W <= 2048) {
@@ -433,57 +431,13 @@ static FftPlan fft_plan(int W, bool allow_reg = true) {
     return p;
 }
 
-// The float64 unit rows of the frames the first pass queued (PeakArgs::frame_list), one wavefront per frame: the lean kernel
-// between the first pass and local_maxima_lite_kernel (peaks_wave.hip). Frames a workgroup of the general kernel needs
-// beyond these are transformed there, on demand.
-constexpr int kUnitWaves = 4;      // (four transforms per CU at a time: registers for 16 double2 + 17 sums + the loads in flight)
+// The float64 unit rows of the frames the first pass queued (PeakArgs::frame_list): the lean kernel between the first pass and
+// local_maxima_lite_kernel (peaks_wave.hip). Frames a workgroup of the general kernel needs beyond these are transformed there,
+// on demand. (The one-wavefront-per-frame forms of this kernel -- REPET_EXACT_FFT -- are in the history: round 3.)
 struct UnitRowsArgs {
     ExactSource src; const int* frame_list; unsigned int* stats; unsigned int gen;
-    int logM, reg_fft, tw_count, wave_bytes, waves;
+    int logM;
 };
-template <int V>
-__global__ __launch_bounds__(64 * kUnitWaves) void unit_rows_f64_kernel(UnitRowsArgs x) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char unit_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int M = x.src.W >> 1;
-    if (x.stats[11] >= x.stats[10]) return;                    // queue empty (or already drained by the other workgroups)
-    const double2* tws = nullptr;
-    unsigned char* work = unit_smem;
-    f64fft::Twiddles rtw{nullptr, nullptr};
-    if (x.reg_fft) {
-        rtw = f64fft::load_twiddles(reinterpret_cast<double2*>(unit_smem), x.src.twiddle64, tid, (int)blockDim.x);
-        work += (size_t)f64fft::kTwCount * sizeof(double2);
-    } else if (x.tw_count > 0) {
-        double2* t = reinterpret_cast<double2*>(unit_smem);
-        for (int k = tid; k < x.tw_count; k += (int)blockDim.x) t[k] = x.src.twiddle64[2 * k];       // exp(-2 pi i k / M)
-        tws = t;
-        work += (size_t)x.tw_count * sizeof(double2);
-    }
-    __syncthreads();
-    if (wave >= x.waves) return;
-    double2* Zw = reinterpret_cast<double2*>(work + (size_t)wave * x.wave_bytes);
-    double* accw = reinterpret_cast<double*>(Zw + M);
-    const unsigned int n_frames = x.stats[10];
-    for (;;) {
-        unsigned int slot = 0;
-        if (lane == 0) slot = atomicAdd(&x.stats[11], 1u);
-        slot = __shfl(slot, 0);
-        if (slot >= n_frames) return;
-        const int64_t lin = x.frame_list[slot];
-        const int clip = (int)(lin / x.src.gen_clip_stride);
-        const int64_t fr = lin - (int64_t)clip * x.src.gen_clip_stride;
-        // (No fence, no acquire / release here: the queue holds every frame once, and the rows are read by LATER kernels on
-        // the stream. An agent-scope release per transform wrote back this XCD's whole L2 -- the similarity matrix had just
-        // been written -- and an acquire invalidated it: 11 + 9 us of a 68-us transform.)
-        unsigned int* g = x.src.u64_gen + lin;
-        if (*g == x.gen) continue;
-        unit_row_variant<V>(x.src, x.logM, clip, fr, Zw, accw, tws, rtw, lane);
-        if (lane == 0) {
-            *g = x.gen;
-            stat_add(x.stats, 9, 1u);
-        }
-    }
-}
 
 // The same rows by ONE WORKGROUP per frame (windows up to 8192): the lean kernel's default. A transform is a chain of
 // dependent steps; one wavefront per frame (above) walks it alone -- 62 us per stereo frame however many frames there are --
@@ -1089,39 +1043,16 @@ hipError_t launch_unit_rows_f64(const ExactSource& src, const PeakRefine* refine
     int logM = 0;
     while ((2 << logM) < src.W) ++logM;
     x.logM = logM;
-    static const bool per_wave = [] { const char* e = getenv("REPET_EXACT_FFT"); return e != nullptr; }();      // reg / lds / wave: one wavefront per frame
-    if (!per_wave) {
-        const int Mh = src.W / 2;
-        const int lds = 2 * Mh * (int)sizeof(double2);
-        auto go_wg = [&](auto tag) -> hipError_t {
-            constexpr int KQ = decltype(tag)::value;
-            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&unit_rows_f64_wg_kernel<KQ>), lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(unit_rows_f64_wg_kernel<KQ>, dim3(1024), dim3(256), lds, s, x);
-            return hipGetLastError();
-        };
-        return Mh <= 1024 ? go_wg(std::integral_constant<int, 1>{}) : go_wg(std::integral_constant<int, 4>{});
-    }
-    const FftPlan plan = fft_plan(src.W);
-    x.reg_fft = plan.variant == kFftReg; x.tw_count = plan.tw_count; x.wave_bytes = plan.wave_bytes;
-    // the LDS transforms need few registers: two waves per workgroup, two or more workgroups per CU
-    const int budget = plan.variant == kFftReg ? 150 * 1024 : 76 * 1024;
-    int waves = plan.variant == kFftReg ? kUnitWaves : 2;
-    while (waves > 1 && plan.fixed_bytes + waves * x.wave_bytes > budget) --waves;
-    if (plan.fixed_bytes + waves * x.wave_bytes > 150 * 1024) return hipErrorInvalidValue;
-    x.waves = waves;
-    const int lds = plan.fixed_bytes + waves * x.wave_bytes;
-    const unsigned grid = plan.variant == kFftReg ? 256u : 1024u;
-    auto go = [&](auto tag) -> hipError_t {
-        constexpr int V = decltype(tag)::value;
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&unit_rows_f64_kernel<V>), lds);
+    const int Mh = src.W / 2;
+    const int lds = 2 * Mh * (int)sizeof(double2);
+    auto go_wg = [&](auto tag) -> hipError_t {
+        constexpr int KQ = decltype(tag)::value;
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&unit_rows_f64_wg_kernel<KQ>), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(unit_rows_f64_kernel<V>, dim3(grid), dim3(64 * waves), lds, s, x);
+        hipLaunchKernelGGL(unit_rows_f64_wg_kernel<KQ>, dim3(1024), dim3(256), lds, s, x);
         return hipGetLastError();
     };
-    if (plan.variant == kFftReg) return go(std::integral_constant<int, kFftReg>{});
-    if (plan.variant == kFftLds4) return go(std::integral_constant<int, kFftLds4>{});
-    return go(std::integral_constant<int, kFftLdsAcc>{});
+    return Mh <= 1024 ? go_wg(std::integral_constant<int, 1>{}) : go_wg(std::integral_constant<int, 4>{});
 }
 
 }  // namespace repet

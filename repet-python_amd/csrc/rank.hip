@@ -217,7 +217,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
         }
     }
     store_run(s, tid, k);
-    if (!(a.ablate & 1)) Phases<LOG2N, 6>::run(s, tid, k);
+    Phases<LOG2N, 6>::run(s, tid, k);
     // code of every original key: 0x0400 + lower_bound(sorted, key), 32 independent binary searches per thread. The
     // keys are fetched again (cache-resident: this workgroup read them a few microseconds ago) rather than held in 32
     // registers through the whole sort.
@@ -245,7 +245,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
             tree[n] = s[phys((((2 * j + 1) << (LOG2N - 1 - l))) - 1)];
         }
     __syncthreads();
-    if (!(a.ablate & 2)) {
+    {
 #pragma unroll
         for (int e = 0; e < 32; ++e) pos[e] = 1;
 #pragma unroll 1
@@ -270,9 +270,6 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
                 pos[e] += (probe < orig[e] ? step : 0) + d;
             }
         }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 32; ++e) pos[e] = 0;
     }
     // back to logical positions: physical p = i + 4 (i / 32)  =>  i = p - 4 (p / 36)
 #pragma unroll
@@ -331,8 +328,6 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
 hipError_t launch_rank_columns(const RankArgs& a0, hipStream_t s) {
     if (!rank_columns_supported(a0.T) || a0.n_cols <= 0 || (a0.n_cols & 127) || (a0.vs_pitch & 31) || (a0.FS & 1)) return hipErrorInvalidValue;
     RankArgs a = a0;
-    static const int ablate = [] { const char* e = getenv("REPET_RANK_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only
-    a.ablate = ablate;
     if (a.T <= 2048) return launch_rank_n<11>(a, s);
     if (a.T <= 4096) return launch_rank_n<12>(a, s);
     if (a.T <= 8192) return launch_rank_n<13>(a, s);

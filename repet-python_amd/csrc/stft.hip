@@ -1194,10 +1194,8 @@ static hipError_t dispatch_window(int W, Fn&& fn) {
 // Frames (or hops) per workgroup. A launch runs in rounds of the device's resident workgroup slots and a workgroup's time
 // is its run plus a fixed part (tables, the frame before an overlap-add run), so the run is chosen to minimise
 // rounds x (run + fixed): cfg 2's forward STFT was 1 939 workgroups of 4 frames on 768 slots -- three rounds, the last
-// half empty; 705 workgroups of 11 frames are one. REPET_FFT_RUN=n fixes the run (diagnostics).
+// half empty; 705 workgroups of 11 frames are one.
 static int frames_per_workgroup(const void* kernel, size_t dynamic_lds, int64_t units, int64_t batches, int least, double fixed) {
-    static const int forced = [] { const char* e = getenv("REPET_FFT_RUN"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced;
     static std::mutex mu;
     static std::map<std::pair<const void*, size_t>, int> slots_of;
     int slots;
@@ -1255,9 +1253,8 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
             }
         });
     }
-    static const bool pair = [] { const char* e = getenv("REPET_FFT_PAIR"); return e ? atoi(e) != 0 : true; }();   // REPET_FFT_PAIR=0: one transform per pass
     const int64_t batches = a.n_batch > 0 ? a.n_batch : 1;
-    if (pair && (a.n_channels % 2) == 0 && a.W <= 2048) {
+    if ((a.n_channels % 2) == 0 && a.W <= 2048) {
         return dispatch_window(a.W, [&](auto w) {
             constexpr int Wc = decltype(w)::value;
             if constexpr (Wc <= 2048) {

@@ -687,7 +687,7 @@ hipError_t launch_stft_reg(const StftArgs& a, hipStream_t s) {
         return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(units, kFwdWaves), cus);
-    static const int balance = [] { const char* e = getenv("REPET_FWD_BALANCE"); return e ? atoi(e) : 1; }();
+    const int balance = 1;
     const size_t dyn = (size_t)kFwdLdsFloat2 * sizeof(float2);
     auto go = [&](auto kernel) {
         (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)dyn);

@@ -204,9 +204,10 @@ def test_integer_intermediates_through_the_context():
 
     timing = ctx.execute("sim", p, timing=True)
     names = [s["name"] for s in timing["stages"]]
-    # (the column sort of the rank-domain median runs beside the peak picking: one stage entry for the two)
-    assert [n.replace("_f16x3", "").replace("peaks+rank_columns", "local_maxima") for n in names if n != "rank_columns"] in (
-        ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"], ["stft", "similarity_gemm", "peaks+mask", "istft_ola"])
+    # (the column sort of the rank-domain median runs beside the peak picking: one stage entry for the two; clips of fewer than
+    # 2 048 frames get their segment records from a pass over the matrix, a stage of its own)
+    assert [n.replace("_f16x3", "").replace("peaks+rank_columns", "local_maxima") for n in names if n not in ("rank_columns", "segment_maxima")] == \
+        ["stft", "similarity_gemm", "local_maxima", "mask_sim", "istft_ola"]
     assert timing["total_ms"] > 0
     ctx.close()
 
@@ -580,8 +581,8 @@ def test_fft_paths_agree():
 
 def test_mask_plane_gives_the_same_bits():
     """Three ways to apply the soft mask, one result. (a) multiplied into the spectrum in place (REPET_MASK_PLANE=0);
-    (b) kept as a plane of its own and applied by the inverse STFT while it fetches the spectrum (REPET_MASK_PLANE=1 with
-    REPET_MASK_MODEL=0); (c) original / extended on the register inverse STFT (default): the mask kernel writes only the
+    (b) kept as a plane of its own and applied by the inverse STFT while it fetches the spectrum (REPET_MASK_PLANE=p);
+    (c) original / extended on the register inverse STFT (REPET_MASK_PLANE=1, their default): the mask kernel writes only the
     repeating-segment model [period][F] and the inverse STFT computes soft_mask(V, model[t mod period]) itself. The same
     rounded products every way, so every variant's output must be IDENTICAL -- batched extended segments, a batch
     context of simonline clips, a batch context of original clips, a mono clip and the 4-channel block-kernel path included."""
@@ -598,66 +599,13 @@ def test_mask_plane_gives_the_same_bits():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "repet-python_amd"), root)
     outs = []
-    for plane, model in (("0", "1"), ("1", "0"), ("1", "1")):
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_plane_{plane}{model}_{os.getpid()}.npy")
-        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MASK_PLANE=plane, REPET_MASK_MODEL=model))
+    for plane in ("0", "p", "1"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_plane_{plane}_{os.getpid()}.npy")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MASK_PLANE=plane))
         outs.append(np.load(out))
         os.remove(out)
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
     assert np.array_equal(outs[0], outs[2], equal_nan=True)
-
-
-def test_lookback_band_gives_the_same_bits():
-    """simonline's banded similarity in the look-back layout band[j][l] = sim(j, j - l) (default on the f16-split kernel:
-    the peak picking of a frame reads one contiguous row) against band[t][l] = sim(t, t + l) read down a diagonal
-    (REPET_BAND_LOOKBACK=0): the same numbers in another place, so a single clip, a batch context and a pushed stream
-    must come out IDENTICAL, similar-frame lists included."""
-    import os
-    import subprocess
-    import sys
-    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth, synth_groove; "
-            "x = synth(31, 44100, 2, 3); y = repet.simonline(x, 44100); g = synth_groove(24, 22050, 1, 2); yg = repet.simonline(g, 22050); "
-            "c = repet.Context(0); c.upload_batch(np.stack([synth(13, 16000, 2, s) for s in range(3)])); p = repet.derive_params(16000); c.execute('simonline', p); "
-            "yb = c.download(); idx, cnt = c.last_sim_indices(c.last_frame_count() - p.buffer_frames + 1, p.sim_number); "
-            "h = repet.online(16000, 2); z = synth(14, 16000, 2, 9); ys = np.concatenate([h.push(z[i:i + 4096]) for i in range(0, len(z), 4096)] + [h.finish()]); "
-            "np.savez(sys.argv[1], y=y, yg=yg, yb=yb, idx=idx, cnt=cnt, ys=ys)")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = code % (os.path.join(root, "repet-python_amd"), root)
-    outs = []
-    for lookback in ("1", "0"):
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_lookback_{lookback}_{os.getpid()}.npz")
-        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_BAND_LOOKBACK=lookback))
-        with np.load(out) as z:
-            outs.append({k: z[k] for k in z.files})
-        os.remove(out)
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
-
-
-@pytest.mark.slow
-def test_power_planes_from_the_stft_give_the_same_bits():
-    """extended with enough segments for the f16-split banded Gram (>= 512 tiles: a 400-s clip): the row-scaled f16 planes
-    of the power spectra written by the forward STFT's own waves (default) against the separate pass over an fp32 P
-    (REPET_P_PLANES=0). The same values are split by the same arithmetic, so periods and output must be identical."""
-    import os
-    import subprocess
-    import sys
-    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
-            "x = synth(400.0, 44100, 2, 17); p = repet.derive_params(44100); c = repet.Context(0); c.upload(x); "
-            "tm = c.execute('extended', p, timing=True); y = c.download(); per = c.last_periods(256); "
-            "np.savez(sys.argv[1], y=y, per=per, stages=np.array([s['name'] for s in tm['stages']]))")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = code % (os.path.join(root, "repet-python_amd"), root)
-    outs = []
-    for planes in ("1", "0"):
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_pplanes_{planes}_{os.getpid()}.npz")
-        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_P_PLANES=planes))
-        with np.load(out) as z:
-            outs.append({k: z[k] for k in z.files})
-        os.remove(out)
-    assert "gram_band_f16x3" in outs[0]["stages"].tolist()            # the path under test really ran
-    assert np.array_equal(outs[0]["per"], outs[1]["per"])
-    assert np.array_equal(outs[0]["y"], outs[1]["y"])
 
 
 def test_gram_paths_agree():
@@ -699,15 +647,9 @@ def test_gram_tile_sizes_give_the_same_matrix():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = code % (os.path.join(root, "repet-python_amd"), root)
     outs = []
-    # the third: f16 planes written by the STFT epilogue itself; the fourth: the two-buffer K loop of round 2
-    # and the intermediate interleaves of the rescheduled K loop (REPET_GRAM_PIPE=2, 3, 4)
-    # and the 128 x 128 kernel with the register-staged K loop of rounds 1-2 (REPET_GRAM_DMA=0)
-    for tile in ("256", "128", "256+split-in-stft", "256+two-buffers", "256+pipe=2", "256+pipe=3.", "256+pipe=4..", "128+register-staged"):
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile[:3]}_{len(tile)}_{os.getpid()}.npz")
-        pipe = "0" if "two" in tile else tile[9] if "pipe" in tile else "1"
-        env = dict(os.environ, REPET_GRAM_TILE=tile[:3], REPET_SPLIT_IN_STFT="1" if "split" in tile else "0", REPET_GRAM_PIPE=pipe,
-                   REPET_GRAM_DMA="0" if "register" in tile else "1")
-        subprocess.check_call([sys.executable, "-c", code, out], env=env)
+    for tile in ("256", "128"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_tile_{tile}_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_GRAM_TILE=tile))
         with np.load(out) as z:
             outs.append({k: z[k] for k in z.files})
         os.remove(out)
@@ -715,8 +657,7 @@ def test_gram_tile_sizes_give_the_same_matrix():
     assert np.array_equal(s, outs[1]["s"], equal_nan=True)
     assert np.array_equal(s, s.T, equal_nan=True)
     assert np.all(np.isnan(s[700])) and np.all(np.isnan(s[:, 700])) and np.isnan(s).sum() == 2 * 2300 - 1
-    assert all(np.array_equal(s, o["s"], equal_nan=True) for o in outs[3:])
-    assert all(np.array_equal(outs[0]["y"], o["y"]) for o in outs[1:])
+    assert np.array_equal(outs[0]["y"], outs[1]["y"])
 
 
 @pytest.mark.parametrize("seconds,fs,channels,number,distance", [(50, 44100, 2, 100, 1.0), (110, 22050, 1, 100, 0.3),
@@ -807,7 +748,7 @@ def test_contexts_overlapping_on_the_device_do_not_disturb_each_other():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "pk_pairs.py"), "600", "stft:selfsim"],
-                         env={k: v for k, v in os.environ.items() if k != "REPET_CHAIN"}, capture_output=True, text=True, timeout=300)
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "0 of 600 differ" in out.stdout, out.stdout
 
@@ -1064,12 +1005,12 @@ def _lists_under(env):
 
 def test_second_level_paths_agree():
     """The second level of the peak picking has a fast path (the wavefront kernel's records + the lean float64 unit-row kernel
-    + local_maxima_lite_kernel) and a general one (local_maxima_exact_kernel: rescans the row, no caps). REPET_PEAK_LITE=0
-    sends every row through the general path, REPET_PEAKS=block takes the workgroup kernel as first pass (general path
-    only): the lists and the audio must be the default's, bit for bit. REPET_PEAK_EXACT=0 (first level alone) must still
+    + local_maxima_lite_kernel) and a general one (local_maxima_exact_kernel: rescans the row, no caps). REPET_PEAKS=block
+    takes the workgroup kernel as first pass, whose rows all go through the general path: the lists and the audio must be
+    the default's, bit for bit. REPET_PEAK_EXACT=0 (first level alone) must still
     produce lists, and go through no float64 spectra."""
     base = _lists_under({})
-    for env in ({"REPET_PEAK_LITE": "0"}, {"REPET_PEAKS": "block"}):
+    for env in ({"REPET_PEAKS": "block"},):
         other = _lists_under(env)
         for key in base:
             assert other[key]["cnt"] == base[key]["cnt"], (env, key)

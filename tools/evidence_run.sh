@@ -1,10 +1,23 @@
-mkdir -p gpurun_out/round gpurun_out/pmc_r03
-timeout 1500 bash tools/round_profile.sh > gpurun_out/round/round.log 2>&1
-timeout 900 bash tools/pmc_profile.sh gpurun_out/pmc_r03 > gpurun_out/pmc_r03/pmc.log 2>&1
-timeout 120 python3 tools/pmc_traffic.py gpurun_out/pmc_r03 gpurun_out/round/pmc_traffic.json > gpurun_out/round/pmc_traffic.log 2>&1
-timeout 120 python3 tools/pmc_summary.py gpurun_out/pmc_r03 > gpurun_out/round/pmc_summary.txt 2>&1
-find gpurun_out/pmc_r03 -name "*.csv" -size +2M -delete
-timeout 300 python3 tools/stream_bench.py > gpurun_out/round/stream_latency.json 2> gpurun_out/round/stream.err
-timeout 120 tools/microbench/cex_rate > gpurun_out/round/cex_rate.txt 2>&1
-timeout 200 python3 tools/peak_stamps.py > gpurun_out/round/peak_gram_spans.txt 2>&1
-tail -n 3 gpurun_out/round/round.log | cut -c1-400; tail -3 gpurun_out/round/pmc_traffic.log; ls -la gpurun_out/round
+#!/bin/bash
+# Everything the round's profiles/ files come from, in one call on the GPU box (rocprofv3 kernel statistics and bench lines
+# of cfg 2-5, the PMC passes and their summaries, the stream latency bench, the VALU issue rates, the spans of the peak and
+# Gram kernels). A step that fails stops the script: a missing file must not look like evidence.
+# usage: tools/evidence_run.sh <round tag, e.g. r04>      -> gpurun_out/round/, gpurun_out/pmc_<tag>/
+set -euo pipefail
+tag=${1:?usage: tools/evidence_run.sh <round tag>}
+root="$GRAFT_REPO_ROOT"
+mkdir -p "$root/gpurun_out/round" "$root/gpurun_out/pmc_$tag"
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+step() { echo "== $*"; "$@"; }
+step timeout 1800 bash tools/round_profile.sh > gpurun_out/round/round.log 2>&1
+step timeout 1200 bash tools/pmc_profile.sh "gpurun_out/pmc_$tag" > "gpurun_out/pmc_$tag/pmc.log" 2>&1
+step timeout 120 python3 tools/pmc_traffic.py "gpurun_out/pmc_$tag" gpurun_out/round/pmc_traffic.json > gpurun_out/round/pmc_traffic.log 2>&1
+step timeout 120 python3 tools/pmc_summary.py "gpurun_out/pmc_$tag" > gpurun_out/round/pmc_summary.txt 2>&1
+find "gpurun_out/pmc_$tag" -name "*.csv" -size +2M -delete
+step timeout 300 python3 tools/stream_bench.py > gpurun_out/round/stream_latency.json 2> gpurun_out/round/stream.err
+step timeout 300 bash tools/valu_rates.sh > gpurun_out/round/valu_rate.log 2>&1
+cp gpurun_out/valu_rate.txt gpurun_out/round/valu_rate.txt
+step timeout 300 python3 tools/peak_stamps.py > gpurun_out/round/peak_gram_spans.txt 2>&1
+tail -n 3 gpurun_out/round/round.log | cut -c1-400
+tail -3 gpurun_out/round/pmc_traffic.log
+ls -la gpurun_out/round

@@ -1,5 +1,5 @@
 """One host thread, two contexts, execute_async on both: device-side overlap without host threading.
-usage: python tools/overlap_stress.py [rounds] [algo_a algo_b]   (REPET_CHAIN must not be set)"""
+usage: python tools/overlap_stress.py [rounds] [algo_a algo_b]   """
 import os
 import sys
 

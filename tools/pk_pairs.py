@@ -1,7 +1,7 @@
 """Which kernel pair shows the packed-fp32 interaction (DESIGN.md "Contexts and concurrency")? Thread A repeats ONE
 stage export on its own context and compares every result with its first; thread B repeats another stage on a second
 context. With a library built WITH packed-fp32 ops (REPET_HIP_LIB=...) about one STFT result in five differs beside
-the f16 similarity kernels; with the shipped library none may (REPET_CHAIN must not be set).
+the f16 similarity kernels; with the shipped library none may .
 usage: [REPET_HIP_LIB=path/to/lib_with_packed_fp32.so] python tools/pk_pairs.py [iterations] [victim:aggressor]"""
 import ctypes as C
 import os
