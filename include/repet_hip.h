@@ -225,7 +225,7 @@ int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dty
  * rounds of one clip per device -- a round goes to its devices as ONE group of ncclSend / ncclRecv (fp32, interleaved; a
  * float64 clip as two planes, samples and remainders; ncclCommInitAll over devices 0 .. n_devices-1, cached; librccl opened
  * on first use), is separated from the received device buffers while the root stages the next round, and its results
- * return in a group of their own. repet_run_batch takes this path when REPET_BATCH_TRANSPORT=rccl.
+ * return in a group of their own.
  * REPET_RCCL_SELF=1 with n_devices == 1 (test switch): every clip is sent by device 0 to itself inside the group.
  * repet_last_batch_info: what the calling thread's last batch call did -- out[0] transport (0 host, 1 RCCL), out[1] clips that
  * went through send / receive, out[2] clips whose remainder plane was resident when they were separated, out[3] RCCL groups

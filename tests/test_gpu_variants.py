@@ -1040,6 +1040,37 @@ def test_segment_record_paths_agree():
             assert other[key]["exact"] == base[key]["exact"], (env, key)
 
 
+def test_level_one_stays_far_inside_the_second_levels_band():
+    """The second level re-takes every verdict whose level-1 values (float64 dot products of the fp32 unit rows) are closer
+    than delta2 = 2.5e-7. That band is derived (an error of about sqrt(2 / F) times the relative rms error of the
+    fp32 spectrum, sigma ~ 1.2e-8 at F = 1 025, whatever the spectrum's sparsity) and checked here where it could break:
+    sparse spectra (a pure tone, a square wave's comb) over a noise floor 100 dB down, 90 dB of level change inside frames,
+    a passage just above the silence that gives NaN, 96 kHz with the 4 096-sample window. The largest level-1 / level-2
+    difference the device meets (repet_ctx_last_exact_stats) must stay below delta2 / 4."""
+    rs = np.random.RandomState(3)
+    fs = 44100
+    n = 40 * fs
+    t = np.arange(n) / fs
+    base = synth(40, fs, 2, 5)
+    cases = [
+        ("tone over -100 dB noise", 0.9 * np.sin(2 * np.pi * 997.0 * t)[:, None] * np.ones((1, 2)) + 1e-5 * rs.standard_normal((n, 2)), fs),
+        ("90 dB gate inside frames", base * np.where((t * 7.3) % 1.0 < 0.5, 1.0, 3e-5)[:, None], fs),
+        ("a passage at -140 dB", base * np.where((t >= 10) & (t < 20), 1e-7, 1.0)[:, None], fs),
+        ("96 kHz", synth(30, 96000, 2, 6), 96000),
+        ("square wave comb", np.sign(np.sin(2 * np.pi * 220.0 * t))[:, None] * np.array([[0.99, 0.7]]) + 1e-4 * rs.standard_normal((n, 2)), fs),
+    ]
+    met = 0
+    for name, x, rate in cases:
+        ctx = repet.Context(0)
+        ctx.upload(np.clip(x, -1.0, 1.0))
+        ctx.execute("sim", repet.derive_params(rate))
+        ex = ctx.last_exact_stats()
+        ctx.close()
+        met += ex["rows_exact"]
+        assert ex["level2_max_diff"] < 2.5e-7 / 4, (name, ex)
+    assert met > 1000                                                      # (the second level really ran on these clips)
+
+
 def test_remainders_of_float64_input_travel_only_when_needed():
     """A float64 clip whose samples are exact in fp32 (what wavread yields for PCM files, repet.py:929) uploads no remainders;
     the synth clip (float64 noise) does, and dropping them changes nothing audible (same lists on this clip)."""
