@@ -35,7 +35,7 @@ VALU_QUARTER_RATE_GINSTR = 1024 * 2.4 / 4.0
 # be put in, whatever its instruction class -- profiles/r03_valu_rate.txt holds the control rows (v_add / v_fma / v_and at
 # 2.0-2.4 cycles) beside the min / max / packed-min classes (4.2-4.75 cycles) at the measured shader clock
 VALU_FULL_RATE_GINSTR = 1024 * 2.4 / 2.0
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 # arithmetic type of the path: fp32 end to end, except that the similarity GEMM of sim / simonline runs on the f16 matrix
 # cores as a three-product split of the fp32 operands (22 significant bits per product, fp32 accumulate; gram_f16.hip)
 DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on 16-bit rank codes)",
@@ -412,11 +412,19 @@ def main():
                     wall.append(time.perf_counter() - t1)
                 return {"value": round(args.duration / min(wall[1:]), 1), "unit": "audio-seconds/sec",
                         "ms_min": round(min(wall[1:]) * 1e3, 2), "ms_median": round(sorted(wall[1:])[1] * 1e3, 2)}
-            line["array_in_array_out"] = drop_in(clip)
+            # the floor of such a call: the fp32 samples in and the fp32 result out at PCIe Gen5 x16's 63 GB/s (MI355X_MICROARCH.md)
+            # + the device step; the remainder plane of a float64 clip travels beside the computation and is not counted
+            floor_ms = 2 * clip.size * 4 / 63e9 * 1e3 + elapsed / max(args.steps, 1) * 1e3
+
+            def with_floor(entry):
+                entry["pcie_floor_ms"] = round(floor_ms, 2)
+                entry["frac_of_pcie_floor"] = round(floor_ms / entry["ms_min"], 3)
+                return entry
+            line["array_in_array_out"] = with_floor(drop_in(clip))
             line["array_in_array_out"]["note"] = ("repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads "
-                                                  "narrow/widen through a pinned ring; fp32 samples + their fp32 remainders over PCIe)" % args.algo)
+                                                  "narrow/widen through a pinned ring; fp32 samples over PCIe, their fp32 remainders behind them beside the computation)" % args.algo)
             if example_clip is None:
-                line["array_in_array_out_pcm16"] = drop_in(np.round(clip * 32768.0).clip(-32768, 32767) / 32768.0)
+                line["array_in_array_out_pcm16"] = with_floor(drop_in(np.round(clip * 32768.0).clip(-32768, 32767) / 32768.0))
                 line["array_in_array_out_pcm16"]["note"] = "the same call on the clip rounded to 16-bit PCM values (float64 array, exact in fp32: no remainders travel)"
         if world == 1 and args.config == 2 and not args.no_variants and example_clip is None:
             # north_star names an fp32 MFMA GEMM for the similarity matrix; the default is the f16x3 split of the fp32 operands.

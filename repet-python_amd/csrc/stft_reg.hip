@@ -350,6 +350,9 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
         const float norm = sqrtf(ss);        // 0 for a silent frame: 0/0 = NaN like repet.py:1220
+        // (the row times the correctly rounded reciprocal: seventeen IEEE divisions were 180 instructions per frame in a
+        // kernel bound by instruction issue; a silent frame gives 0 * inf = NaN, as 0 / 0 did)
+        const float inv_norm = 1.0f / norm;
         const int64_t mrow = b * a.batch_mean_stride + row;
         float* Vm = a.Vm ? a.Vm + mrow : nullptr;
         float* Vn = a.Vn ? a.Vn + mrow : nullptr;
@@ -364,15 +367,15 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         for (int s = 0; s < 16; ++s) {
             const int k = lane + 64 * s;
             if (Vm) Vm[k] = acc[s];
-            if (Vn) Vn[k] = acc[s] / norm;
-            if (Vh) store_split_f16_at(vh_lane + 128 * s, acc[s] / norm);
+            if (Vn) Vn[k] = acc[s] * inv_norm;
+            if (Vh) store_split_f16_at(vh_lane + 128 * s, acc[s] * inv_norm);
             if (P) P[k] = acc[s] * acc[s];
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (lane == 0) {
             if (Vm) Vm[N] = acc[16];
-            if (Vn) Vn[N] = acc[16] / norm;
-            if (Vh) store_split_f16(Vh, row + N, acc[16] / norm);
+            if (Vn) Vn[N] = acc[16] * inv_norm;
+            if (Vh) store_split_f16(Vh, row + N, acc[16] * inv_norm);
             if (P) P[N] = acc[16] * acc[16];
         }
         if (lane < a.FS - (N + 1)) {

@@ -21,7 +21,8 @@ KERNELS = [
     ("split_f16_kernel", "similarity_gemm", 2, "16 B/lane"), ("split_f16_rows_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_f16_big_pipe_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_big_kernel", "similarity_gemm", 2, "16 B/lane LDS-DMA"), ("gram_f16_kernel", "similarity_gemm", 2, "16 B/lane"),
     ("gram_kernel", "similarity_gemm", 2, "16 B/lane"),
-    ("local_maxima_wave_kernel", "local_maxima", 2, "16 B/lane"), ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
+    ("local_maxima_wave_kernel", "local_maxima", 1, "4 B/lane record loads, a few 16-byte groups of S"), ("local_maxima_kernel", "local_maxima", 2, "16 B/lane"),
+    ("segment_maxima_kernel", "local_maxima", 2, "16 B/lane"),
     ("columns_from_rows_kernel", "rank_columns", 1, "4 B/lane"), ("rank_columns_kernel", "rank_columns", 2, "16 B/lane"),
     ("rows_from_code_columns_kernel", "rank_columns", 1, "4 B/lane"),
     ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
@@ -35,7 +36,9 @@ KERNELS = [
 # "measured" figure below them means a wrong correction factor, and the tool refuses to write it
 N_, C_, T_, F_, K_ = 7938000, 2, 7753, 1025, 99.85
 COMPULSORY = {"stft": 4 * N_ * C_ + 12 * F_ * T_ * C_ + 4 * F_ * T_, "similarity_gemm": 4 * F_ * T_ + 4 * T_ * T_,
-              "local_maxima": 4 * T_ * T_ + 4 * K_ * T_, "istft_ola": 8 * F_ * T_ * C_ + 4 * N_ * C_}
+              # round 4: the peak picking reads the segment records (three planes of 244 entries per row), not S, and writes the lists
+              "local_maxima": 12 * 244 * T_ + 4 * K_ * T_, "istft_ola": 8 * F_ * T_ * C_ + 4 * N_ * C_}
+SURVEY_8D = {"local_maxima": 4 * T_ * T_ + 4 * K_ * T_}      # what SURVEY 8d counts for K4 (S read once): kept beside the measured bytes
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
@@ -65,5 +68,9 @@ for stage, need in COMPULSORY.items():
         stages[stage]["compulsory_bytes"] = need
         stages[stage]["measured_over_compulsory"] = round(stages[stage]["hbm_bytes_per_launch"] / need, 3)
         assert stages[stage]["hbm_bytes_per_launch"] >= 0.97 * need, (stage, stages[stage]["hbm_bytes_per_launch"], need, "below the bytes the stage must move: wrong fetch correction?")
+for stage, b8d in SURVEY_8D.items():
+    if stage in stages:
+        stages[stage]["survey_8d_bytes"] = b8d
+        stages[stage]["measured_over_survey_8d"] = round(stages[stage]["hbm_bytes_per_launch"] / b8d, 3)
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in stages.items()}))
