@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         // loops and spills them
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
+        lane &= 63;                                    // (the range again: addresses as scalar base + 32-bit lane offset + immediate)
         const int partner = (64 - lane) & 63;
         const bool inside = start >= 0 && start + W <= a.n_samples;       // wave-uniform
         // a frame over an edge of the clip: positions [lo, hi) of it exist (32-bit, relative to the frame's first sample;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             } else {
                 int lane = lane_id;                    // opaque per channel: see above
                 asm volatile("" : "+v"(lane));
+        lane &= 63;                                    // (the range again: addresses as scalar base + 32-bit lane offset + immediate)
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
                     const int p0 = 2 * (64 * n1 + lane), p1 = p0 + 1;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
         for (int c = 0; c < C; ++c) {
             int lane = lane_id;                                          // opaque per transform (see the forward kernel)
             asm volatile("" : "+v"(lane));
+        lane &= 63;                                    // (the range again: addresses as scalar base + 32-bit lane offset + immediate)
             float2 v[16];
             if (have) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
             const bool one_later = later_any && n_base >= 0 && n_base + 2 * (int64_t)N < 2 * (int64_t)step;
             int lane = lane_id;                                          // opaque: no per-slot addresses kept across rounds
             asm volatile("" : "+v"(lane));
+        lane &= 63;                                    // (the range again: addresses as scalar base + 32-bit lane offset + immediate)
             // an accumulating class of `extended` segments: the eight old values of this lane are fetched together before
             // the first is used (each behind its own "mode == 1" branch they were eight memory round trips per hop)
             using OldT = std::conditional_t<C == 2, Float4A, Float2A>;
