@@ -252,6 +252,13 @@ int repet_istft(repet_ctx* ctx, const float* spec, int64_t n_frames, const float
 
 /* _selfsimilaritymatrix, repet.py:1209-1225. v[T][F] (frame-major magnitudes) -> s[T][T]. */
 int repet_selfsim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, float* s_out);
+/* The same with the SEGMENT RECORDS the peak picking of `sim` takes its candidates from (repet.py:1294-1345 scans every element;
+ * a strict maximum of a window of +-d >= 31 elements is the maximum of its aligned 32-element segment): for every row and every
+ * run of columns [32 u, 32 u + 32) the largest value (NaN counted as +inf), the largest of the run's OTHER elements (-inf for
+ * a run of one), and the offset of the largest inside the run (the lowest among equals). max_out / second_out / at_out:
+ * [n_frames][ceil(n_frames / 32)]. */
+int repet_selfsim_records(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, float* s_out, float* max_out,
+                          float* second_out, int32_t* at_out);
 
 /* _similaritymatrix, repet.py:1228-1246 (the online variant's frame-vs-buffer similarity):
  * a[TA][F], b[TB][F] frame-major magnitudes -> s[TA][TB] cosine similarities. */

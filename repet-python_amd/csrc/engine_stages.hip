@@ -87,6 +87,32 @@ int repet_selfsim(repet_ctx* c, const float* v, int64_t T, int32_t F, float* s_o
     return d2h_pitched(c, s_out, c->S.as<float>(), TS, T, T);
 }
 
+int repet_selfsim_records(repet_ctx* c, const float* v, int64_t T, int32_t F, float* s_out, float* max_out, float* second_out,
+                          int32_t* at_out) {
+    if (!c || !v || !s_out || !max_out || !second_out || !at_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    DeviceGuard guard(c->device);
+    const int FS = (int)round_up(F, kFreqAlign);
+    const int64_t Tpad = round_up(T, kTile), TS = round_up(T, 64);
+    const int seg_pitch = segment_pitch((int)TS), n_seg = (int)ceil_div(T, kSegWidth);
+    HIP_TRY(c->tmp_a.ensure((size_t)T * F * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->tmp_a.p, v, (size_t)T * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->Vn.ensure((size_t)Tpad * FS * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(c->Vn.p, 0, (size_t)Tpad * FS * sizeof(float), c->stream));
+    HIP_TRY(launch_unit_rows(c->tmp_a.as<float>(), c->Vn.as<float>(), T, F, FS, c->stream));
+    HIP_TRY(c->S.ensure((size_t)T * TS * sizeof(float)));
+    HIP_TRY(c->seg.ensure((size_t)T * 3 * seg_pitch * sizeof(float)));
+    // the records as `sim` gets them: from the 256 x 256 kernel's epilogue for clips of 2 048 frames and more, else by a pass over S
+    RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, FS, c->S.as<float>(), TS, true, false, c->seg.as<float>(), seg_pitch));
+    RP_TRY(d2h_pitched(c, s_out, c->S.as<float>(), TS, T, T));
+    for (int plane = 0; plane < 3; ++plane) {
+        void* dst = plane == 0 ? (void*)max_out : plane == 1 ? (void*)second_out : (void*)at_out;
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)n_seg * 4, c->seg.as<float>() + (size_t)plane * seg_pitch, (size_t)3 * seg_pitch * 4,
+                                 (size_t)n_seg * 4, (size_t)T, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
 int repet_similarity(repet_ctx* c, const float* a, int64_t TA, const float* b, int64_t TB, int32_t F, float* s_out) {
     if (!c || !a || !b || !s_out) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (TA < 1 || TB < 1 || F < 1) return fail(REPET_ERR_BAD_ARG, "bad size");

@@ -485,7 +485,6 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
         for (int c = 0; c < C; ++c) {
             int lane = lane_id;                                          // opaque per transform (see the forward kernel)
             asm volatile("" : "+v"(lane));
-        lane &= 63;                                    // (the range again: addresses as scalar base + 32-bit lane offset + immediate)
             float2 v[16];
             if (have) {
                 const float2* Y = a.Y + c * a.chan_stride + t * a.FS;
@@ -589,7 +588,6 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
             const bool one_later = later_any && n_base >= 0 && n_base + 2 * (int64_t)N < 2 * (int64_t)step;
             int lane = lane_id;                                          // opaque: no per-slot addresses kept across rounds
             asm volatile("" : "+v"(lane));
-        lane &= 63;                                    // (the range again: addresses as scalar base + 32-bit lane offset + immediate)
             // an accumulating class of `extended` segments: the eight old values of this lane are fetched together before
             // the first is used (each behind its own "mode == 1" branch they were eight memory round trips per hop)
             using OldT = std::conditional_t<C == 2, Float4A, Float2A>;

@@ -213,6 +213,19 @@ def _selfsimilaritymatrix(data_matrix):
     return s.astype(np.float64)
 
 
+def _selfsimilarity_records(data_matrix):
+    """(similarity matrix, largest, second largest, offset of the largest) per row and aligned run of 32 columns: the segment
+    records the peak picking of ``sim`` works from (``repet_selfsim_records``)."""
+    rows = _f32(np.asarray(data_matrix).T)
+    t, f = rows.shape
+    n_seg = -(-t // 32)
+    s = np.empty((t, t), dtype=np.float32)
+    top, second, at = (np.empty((t, n_seg), dtype=np.float32), np.empty((t, n_seg), dtype=np.float32), np.empty((t, n_seg), dtype=np.int32))
+    _native.check(_native.lib().repet_selfsim_records(_native.default_context(_device).handle, _native.ptr(rows), t, f, _native.ptr(s),
+                                                      _native.ptr(top), _native.ptr(second), _native.ptr(at)))
+    return s, top, second, at
+
+
 def _similaritymatrix(data_matrix1, data_matrix2):
     """Cosine similarity between the columns of two matrices (repet.py:1228-1246)."""
     a = _f32(np.asarray(data_matrix1).T)

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "repet_stft": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64]),
     "repet_istft": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, C.c_int64]),
     "repet_selfsim": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "repet_selfsim_records": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "repet_similarity": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
     "repet_acorr": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "repet_beat_spectrum": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),

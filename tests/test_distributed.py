@@ -188,3 +188,17 @@ def test_extended_segments_sharded_over_two_ranks(tmp_path):
     assert np.max(np.abs(got["f64"] - orc.extended(x, FS))) < 1e-12
     assert np.max(np.abs(got["f32"] - orc.extended(x, FS))) < 2e-6              # fp32 on the wire and in the root's sums
     assert np.max(np.abs(got["short_step"] - orc.extended(x, FS, orc.Params(segment_length=8, segment_step=2)))) < 1e-12
+
+
+def test_bench_refuses_a_world_that_is_not_what_gpus_says():
+    """`python bench.py --gpus N` without RANK in the environment starts its own N ranks -- after counting the devices, which
+    on this CPU box stops it with a clear message -- and inside a job whose WORLD_SIZE differs from --gpus it refuses to run
+    (round 3 silently ran one rank and reported n_gpus 1)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    alone = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert alone.returncode != 0 and "this node shows 0 GPU(s)" in alone.stderr, alone.stderr[-500:]
+    inside = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"],
+                            env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=300)
+    assert inside.returncode != 0 and "the two must agree" in inside.stderr, inside.stderr[-500:]

@@ -157,6 +157,34 @@ def test_local_maxima_from_segment_records():
                     assert set(idx.tolist()) == set(wi.tolist()), (n, d, k, r)
 
 
+@pytest.mark.parametrize("t", [300, 2300])
+def test_segment_records_of_the_similarity_matrix(t):
+    """The records the peak picking of `sim` takes its candidates from, against NumPy on the matrix they belong to: written by the
+    256 x 256 Gram kernel's epilogue (2 300 frames; the diagonal patches and the matrix's ragged edge take their own path) or by
+    a pass over the matrix (300 frames). A silent frame gives a NaN row and column: NaN counts as +inf, so it is every
+    segment's maximum wherever it lies, and its own row is all +inf."""
+    rs = np.random.RandomState(17)
+    v = np.abs(rs.standard_normal((257, t)))
+    v[:, t // 3] = 0.0
+    v[:, 40:44] = v[:, 40:41]                                    # four identical frames: exact ties inside segments
+    s, top, second, at = repet._selfsimilarity_records(v)
+    assert np.array_equal(s, s.T, equal_nan=True)
+    n_seg = -(-t // 32)
+    padded = np.full((t, n_seg * 32), -np.inf, dtype=np.float32)
+    padded[:, :t] = np.where(np.isnan(s), np.inf, s)
+    runs = padded.reshape(t, n_seg, 32)
+    want_at = np.argmax(runs, axis=2)                             # (the lowest index among equals)
+    want_top = np.take_along_axis(runs, want_at[:, :, None], axis=2)[:, :, 0]
+    others = runs.copy()
+    np.put_along_axis(others, want_at[:, :, None], -np.inf, axis=2)
+    want_second = others.max(axis=2)
+    assert np.array_equal(top, want_top)
+    assert np.array_equal(second, want_second)
+    assert np.array_equal(at, want_at)
+    assert np.all(np.isinf(top[t // 3])) and np.all(top[:, (t // 3) // 32] == np.inf)
+    assert np.any(top[:, 1] == second[:, 1])                      # the tied frames really produced ties
+
+
 def test_indices_on_similarity_matrix(clip):
     x, fs = clip
     w, window, h = orc.stft_geometry(fs)
