@@ -816,6 +816,34 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
                     const float4 v = *reinterpret_cast<const float4*>(src + s0 + 4 * (64 * q + lane));
                     L.buf[phys4(64 * q + lane)] = make_float4(nan_to_inf(v.x), nan_to_inf(v.y), nan_to_inf(v.z), nan_to_inf(v.w));
                 }
+            } else if (a.mode == 2 && n_chunks == 1 && (a.pitch & 3) == 0) {
+                // simonline on the look-back band (round 4): element i of the row is lag l = (j - i) mod n of band row j -- ONE
+                // contiguous row read backwards from a rotation point. The row comes in with 16-byte loads in lag order and
+                // every value is put at its element's place in the buffer (the buffer is filled with -inf first: halo and
+                // tail); element by element the chunk cost sixteen integer divisions per lane, 40 % of such a row's time.
+                const float* row = a.M + (j - a.shift) * a.pitch;
+                const int jm = (int)(j % n);                                   // element jm is lag 0
+                float4 got[4];
+                const int n4 = (n + 3) >> 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    got[q] = (64 * q + lane < n4) ? *reinterpret_cast<const float4*>(row + 4 * (64 * q + lane)) : ninf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) L.buf[phys4(64 * q + lane)] = ninf;
+                wave_sync();
+                float* flat = reinterpret_cast<float*>(L.buf);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float vals[4] = {got[q].x, got[q].y, got[q].z, got[q].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int l = 4 * (64 * q + lane) + k;
+                        int i = jm - l;
+                        i += i < 0 ? n : 0;                                   // (l < n: one wrap at most)
+                        const int p_ = i - s0;                                 // place in the chunk
+                        if (l < n) flat[4 * phys4(p_ >> 2) + (p_ & 3)] = nan_to_inf(vals[k]);
+                    }
+                }
             } else {
                 // the first and the last chunk of a row, circular-buffer order (simonline: element i of the row is a walk
                 // down a diagonal of the banded matrix) or an unaligned pitch: sixteen single loads per lane, ALL issued
