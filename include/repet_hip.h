@@ -231,6 +231,9 @@ int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dty
  * went through send / receive, out[2] clips whose remainder plane was resident when they were separated, out[3] RCCL groups
  * completed. */
 int repet_last_batch_info(int64_t out[4]);
+/* The resident clip as the engine holds it: the fp32 samples and, for a float64 upload, their fp32 remainders
+ * (x - (double)(float)x; zeros and *has_remainders = 0 when none was needed). [n_clips][n_samples][n_channels] floats each. */
+int repet_ctx_download_input(repet_ctx* ctx, float* samples_out, float* remainders_out, int32_t* has_remainders);
 int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype,
                          const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
                          double* const* out, int32_t n_devices);

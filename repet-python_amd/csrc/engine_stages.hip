@@ -306,6 +306,20 @@ int repet_rank_columns(repet_ctx* c, const float* v, int64_t T, int32_t F, uint1
     return d2h_pitched(c, sorted_out, c->Vs.as<float>(), vs_pitch, n_cols, T);
 }
 
+int repet_ctx_download_input(repet_ctx* c, float* samples_out, float* remainders_out, int32_t* has_remainders) {
+    if (!c || !samples_out || !remainders_out || !has_remainders) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    DeviceGuard guard(c->device);
+    const size_t bytes = (size_t)c->n_samples * c->n_channels * c->n_clips * sizeof(float);
+    if (c->has_lo && c->ring.lo_in_flight) HIP_TRY(hipStreamWaitEvent(c->stream, c->ring.lo_done, 0));
+    HIP_TRY(hipMemcpyAsync(samples_out, c->audio.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (c->has_lo) HIP_TRY(hipMemcpyAsync(remainders_out, c->audio_lo.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    else std::memset(remainders_out, 0, bytes);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *has_remainders = c->has_lo ? 1 : 0;
+    return REPET_OK;
+}
+
 int repet_ctx_last_periods(repet_ctx* c, int32_t* out, int32_t capacity, int32_t* n_written) {
     if (!c || !out || !n_written) return fail(REPET_ERR_BAD_ARG, "null argument");
     DeviceGuard guard(c->device);

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "repet_ctx_upload_device_split": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32]),
     "repet_ctx_download_device": (C.c_int, [_P, _P]),
     "repet_last_batch_info": (C.c_int, [C.POINTER(C.c_int64)]),
+    "repet_ctx_download_input": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32)]),
     "repet_ctx_set_window": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "repet_wav_parse": (C.c_int, [_P, C.c_int64, C.POINTER(WavInfo)]),
     "repet_ctx_upload_wav": (C.c_int, [_P, _P, C.c_int64, C.POINTER(WavInfo)]),
@@ -266,6 +267,14 @@ class Context:
         check(lib().repet_ctx_upload_device_split(self._h, C.c_void_p(int(data_ptr)), C.c_void_p(int(remainder_ptr)) if remainder_ptr else None,
                                                   int(number_samples), int(number_channels), int(number_clips)))
         self.shape = (number_samples, number_channels) if number_clips == 1 else (number_clips, number_samples, number_channels)
+
+    def resident_input(self):
+        """(fp32 samples, fp32 remainders, has_remainders) of the resident clip as the engine holds it."""
+        hi = np.empty(self.shape, dtype=np.float32)
+        lo = np.empty(self.shape, dtype=np.float32)
+        flag = C.c_int32(0)
+        check(lib().repet_ctx_download_input(self._h, ptr(hi), ptr(lo), C.byref(flag)))
+        return hi, lo, bool(flag.value)
 
     def download_device(self, data_ptr):
         """The result as fp32 interleaved samples into device memory of at least ``prod(self.shape)`` floats."""

@@ -1071,6 +1071,38 @@ def test_level_one_stays_far_inside_the_second_levels_band():
     assert met > 1000                                                      # (the second level really ran on these clips)
 
 
+def test_staged_upload_splits_float64_exactly():
+    """The host side of a float64 upload (hostio.hip): worker threads narrow the samples chunk by chunk and part by part, store
+    remainders only from the first one that is not zero on, clear the shares of parts that met none when the chunk travels,
+    send the plane behind the samples on its own stream. What arrives must be NumPy's split of the array to the bit -- for a
+    clip whose remainders begin in the middle of a chunk and of a worker's part, for one that has them only in its last
+    samples, for a PCM-exact one, and after a larger clip has used the same pinned buffers."""
+    fs = 44100
+    x = synth(42, fs, 2, 9)                                      # 3.7 M elements: four 1-M-element chunks
+    pcm = np.round(x * 32768.0) / 32768.0
+    cases = []
+    mixed = x.copy()
+    mixed[:651_217] = pcm[:651_217]                              # remainders from element 1 302 434 on: inside chunk 1
+    cases.append(mixed)
+    tail = pcm.copy()
+    tail[-3:] = x[-3:]
+    cases.append(tail)
+    cases.append(synth(60, fs, 2, 4))                            # a larger clip in between
+    cases.append(pcm)
+    gap = x.copy()
+    gap[1_000_000:1_600_000] = pcm[1_000_000:1_600_000]          # a PCM-exact stretch inside a noisy clip
+    cases.append(gap[: 30 * fs])
+    ctx = repet.Context(0)
+    for k, clip in enumerate(cases):
+        ctx.upload(clip)
+        hi, lo, has = ctx.resident_input()
+        want_hi, want_lo = parallel.split_float64(clip)
+        assert np.array_equal(hi, want_hi), k
+        assert has == (want_lo is not None), k
+        assert np.array_equal(lo, want_lo if want_lo is not None else np.zeros_like(hi)), k
+    ctx.close()
+
+
 def test_remainders_of_float64_input_travel_only_when_needed():
     """A float64 clip whose samples are exact in fp32 (what wavread yields for PCM files, repet.py:929) uploads no remainders;
     the synth clip (float64 noise) does, and dropping them changes nothing audible (same lists on this clip)."""
