@@ -312,6 +312,15 @@ int repet_ctx_last_periods(repet_ctx* ctx, int32_t* out, int32_t capacity, int32
 int repet_ctx_last_sim_indices(repet_ctx* ctx, int32_t* idx_out, int32_t* count_out, int32_t n_rows,
                                int32_t number);
 int repet_ctx_last_frame_count(repet_ctx* ctx, int64_t* n_frames);
+/* sim: which form of np.median (repet.py:1535) the last run took -- 0 the selection network on the float magnitudes,
+ * 1 the packed 16-bit network on the rank codes (rank.hip), 2 the bit-sliced selection on the same codes (mask_bits.hip).
+ * All three give the same bits; REPET_MEDIAN=f32|rank forces the first two. */
+int repet_ctx_last_median_path(repet_ctx* ctx, int32_t* path);
+/* After a run on path 2: what the selection left per cell, out[channel][frame][bin] for the first n_bins bins (n_bins <=
+ * n_freq - 1: the Nyquist bin is not ranked): bits 0-14 the rank code (number of strictly smaller magnitudes of the bin over
+ * the clip, rank.hip, without its 0x0400 base) of the lower median of the frame's similar frames, bit 15 set where that is
+ * below the frame's own code, bits 16-30 the code of the upper median (equal to the lower one for an odd list). */
+int repet_ctx_last_median_codes(repet_ctx* ctx, uint32_t* out, int64_t n_frames, int32_t n_bins);
 /* sim / simonline: counters of the near-tie refinement of the last run's peak picking (_localmaxima,
  * repet.py:1294-1345): out[0] rows with a decision inside the fp32 tolerance, out[1] near-tied elements
  * re-decided from float64 similarities, out[2] decisions that changed, out[3] flat rows left to fp32. */

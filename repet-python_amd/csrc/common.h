@@ -358,6 +358,11 @@ struct MaskArgs {
     // 0x7C00 at pad_row, pad_row+1) and the rank -> value table Vs[c][f][vs_pitch] of the first n_rank_cols bins of
     // every channel. R == nullptr: select on the floats themselves.
     const unsigned short* R; int64_t r_chan_stride; const float* Vs; int64_t vs_pitch; int32_t n_rank_cols;
+    // the same codes (minus their base) bit-sliced, for the bit-sliced selection (mask_bits.hip): P[t][plane][64] words,
+    // bit b of word l = bit `plane` of the code of cell 64 b + l, cells numbered channel-major over the ranked bins.
+    // P == nullptr: the packed network on R.
+    const unsigned* P; int32_t n_planes;
+    unsigned* median_codes;       // bit-sliced selection: one word per cell, V's geometry (upper code << 16 | lower code | flag)
 };
 constexpr int kPadRows = 8;       // rows kept behind the Tpad frame rows of V (2 used)
 constexpr int kMinIdxPitch = 128; // index lists are readable up to the largest network size
@@ -371,6 +376,12 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
                            hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3);
 int median_network_instructions(int max_n, int* net_size);
+// bit-sliced selection (mask_bits.hip): lists of at most 128 entries, at most 32 blocks of 64 ranked bins over all channels
+int code_planes_for(int64_t T);                       // planes of the codes of a T-frame clip (bits of T - 1, at least 11)
+bool mask_sim_bits_supported(int64_t T, int32_t n_channels, int32_t n_cols, int32_t max_count);
+int mask_sim_bits_instructions(int32_t max_count, int32_t n_planes);
+hipError_t launch_mask_sim_bits(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count, int32_t max_count,
+                                unsigned n_launch, hipStream_t s);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
                               int32_t min_period, hipStream_t s);
@@ -386,6 +397,7 @@ struct RankArgs {
     unsigned short* R; int64_t r_chan_stride;
     float* Vs; int64_t vs_pitch;          // Vs[c * n_cols + f][vs_pitch], vs_pitch = round_up(T, 32)
     unsigned short* codes;                // scratch: the codes column-major, [c * n_cols + f][vs_pitch]
+    unsigned* P; int32_t n_planes;        // (nullable) the codes bit-sliced as well: MaskArgs::P
 };
 bool rank_columns_supported(int64_t T);
 hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s);

@@ -124,6 +124,7 @@ struct repet_ctx {
     unsigned int exact_gen = 0;
     bool refine_stats_cleared = false;   // ensure_spectra's housekeeping launch has zeroed them for the run being enqueued
     DevBuf R, Vs, rank_codes;     // rank codes of V, the sorted columns and the column-major codes (rank-domain median of `sim`, rank.hip)
+    DevBuf code_planes, median_codes;   // the same codes bit-sliced, and the selected codes per cell (mask_bits.hip)
     // geometry for which the constant median-pad rows of R are in place (they survive every run of that geometry)
     const void* r_pads_ptr = nullptr; int64_t r_pads_stride = 0, r_pads_row = 0; int r_pads_channels = 0, r_pads_fs = 0;
     std::map<int, std::unique_ptr<Tables>> tables;
@@ -138,6 +139,8 @@ struct repet_ctx {
     int64_t last_idx_rows = 0;
     int32_t last_idx_pitch = 0;
     int32_t last_idx_number = 0;
+    int32_t last_FS = 0; int64_t last_chan_stride = 0;     // sim: geometry of the last run's per-cell arrays
+    int32_t last_median_path = 0;     // sim: 0 selection on the float magnitudes, 1 packed network on rank codes, 2 bit-sliced selection
     int32_t last_idx_batch = 1;   // clips whose lists sit back to back in idx / cnt (batch contexts)
     bool band_on_f16 = false;     // the last banded Gram ran on the f16-split kernel (stage label / roofline of bench.py)
     // timing
@@ -192,7 +195,7 @@ int run_exact_rows(repet_ctx* c, const Tables* tb, const Geo& g, const float* M,
                    const PeakRefine& rf, const PeakBatch* batch, const float* hi, const float* lo, int64_t n_samples,
                    int64_t clip_stride, int64_t frame_sample0, int64_t n_frames, int clips);
 bool rank_median_enabled();
-int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark);
+int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count);
 int exec_sim(repet_ctx* c, const repet_params* p);
 int exec_simonline(repet_ctx* c, const repet_params* p);
 int prepare_power_planes(repet_ctx* c, const Geo& g, int64_t T, int B);

@@ -552,7 +552,7 @@ int repet_ctx_destroy(repet_ctx* c) {
     }
     c->ring.release();
     for (DevBuf* b : {&c->staging, &c->audio, &c->out, &c->out64, &c->X, &c->V, &c->Mk, &c->Wm, &c->Vn, &c->Vh, &c->amax, &c->beat_partial, &c->peak_scratch, &c->P, &c->S, &c->band, &c->beat,
-                      &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->tiles_big,
+                      &c->refine_stats, &c->R, &c->Vs, &c->rank_codes, &c->code_planes, &c->median_codes, &c->tiles_big,
                       &c->audio_lo, &c->redo_list, &c->redo_flag, &c->u64, &c->u64_gen, &c->exact_scratch,
                       &c->lite_list, &c->lite_flag, &c->lite_records, &c->frame_list, &c->frame_flag,
                       &c->seg,

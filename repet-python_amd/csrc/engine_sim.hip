@@ -112,9 +112,15 @@ bool rank_median_enabled() {
     static const bool on = [] { const char* e = getenv("REPET_MEDIAN"); return !(e && e[0] == 'f'); }();
     return on;
 }
+// REPET_MEDIAN=rank keeps the rank-domain selection on the packed 16-bit network (mask_sim_rank_kernel); default: the
+// bit-sliced selection on the same codes (mask_bits.hip) where its layout applies.
+static bool bits_median_enabled() {
+    static const bool on = [] { const char* e = getenv("REPET_MEDIAN"); return !(e && (e[0] == 'f' || e[0] == 'r')); }();
+    return on;
+}
 
 // Sort every column of V and fill m's rank fields (bins [0, F-1); the lone Nyquist bin stays on the float kernel).
-int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark) {
+int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count) {
     const int n_cols = g.F - 1;
     const int64_t vs_pitch = round_up(g.T, 32);
     HIP_TRY(c->R.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned short)));
@@ -129,8 +135,16 @@ int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream
     a.V = c->V.as<float>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.n_cols = n_cols;
     a.R = c->R.as<unsigned short>(); a.r_chan_stride = g.chan_stride; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
     a.codes = c->rank_codes.as<unsigned short>();
+    if (bits_median_enabled() && mask_sim_bits_supported(g.T, g.C, n_cols, max_count)) {
+        a.n_planes = code_planes_for(g.T);
+        HIP_TRY(c->code_planes.ensure((size_t)g.T * a.n_planes * 64 * sizeof(unsigned)));
+        a.P = c->code_planes.as<unsigned>();
+        HIP_TRY(c->median_codes.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned)));
+        m->median_codes = c->median_codes.as<unsigned>();
+    }
     HIP_TRY(launch_rank_columns(a, stream));
     m->R = a.R; m->r_chan_stride = a.r_chan_stride; m->Vs = a.Vs; m->vs_pitch = vs_pitch; m->n_rank_cols = n_cols;
+    m->P = a.P; m->n_planes = a.n_planes;
     // V read, columns written / read twice / written sorted, codes written column-major, read, written frame-major
     if (with_mark) mark(c, "rank_columns", (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * n_cols * (double)g.T * g.C, 0);
     return REPET_OK;
@@ -200,7 +214,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         if (beside) {
             HIP_TRY(hipEventRecord(c->fork_event, c->stream));          // V is complete (so is S)
             HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
-            RP_TRY(run_rank_columns(c, g, &m, c->side_stream, false));
+            RP_TRY(run_rank_columns(c, g, &m, c->side_stream, false, max_peaks));
             HIP_TRY(hipEventRecord(c->join_event, c->side_stream));
         }
         const size_t scratch = local_maxima_scratch_bytes(T, (int)T, p->sim_distance_frames);
@@ -224,10 +238,12 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             mark(c, "peaks+rank_columns", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * (g.F - 1) * (double)g.T * g.C, 0);
         } else {
             mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
-            if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true));
+            if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true, max_peaks));
         }
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
                                 c->fork_event, c->join_event));
+        c->last_median_path = m.P ? 2 : m.R ? 1 : 0;
+        c->last_FS = g.FS; c->last_chan_stride = g.chan_stride;
         mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     }
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));

@@ -343,6 +343,24 @@ int repet_ctx_last_sim_indices(repet_ctx* c, int32_t* idx_out, int32_t* count_ou
     return REPET_OK;
 }
 
+int repet_ctx_last_median_codes(repet_ctx* c, uint32_t* out, int64_t n_frames, int32_t n_bins) {
+    if (!c || !out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (c->last_median_path != 2 || !c->median_codes.p) return fail(REPET_ERR_BAD_ARG, "the last run did not take the bit-sliced selection");
+    if (n_frames != c->last_T || n_bins < 1 || n_bins > c->last_FS) return fail(REPET_ERR_BAD_ARG, "shape does not match the last run");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int ch = 0; ch < c->n_channels; ++ch)
+        HIP_TRY(hipMemcpy2D(out + (size_t)ch * n_frames * n_bins, (size_t)n_bins * 4, c->median_codes.as<unsigned>() + (size_t)ch * c->last_chan_stride,
+                            (size_t)c->last_FS * 4, (size_t)n_bins * 4, n_frames, hipMemcpyDeviceToHost));
+    return REPET_OK;
+}
+
+int repet_ctx_last_median_path(repet_ctx* c, int32_t* path) {
+    if (!c || !path) return fail(REPET_ERR_BAD_ARG, "null argument");
+    *path = c->last_median_path;
+    return REPET_OK;
+}
+
 int repet_ctx_last_frame_count(repet_ctx* c, int64_t* n_frames) {
     if (!c || !n_frames) return fail(REPET_ERR_BAD_ARG, "null argument");
     *n_frames = c->last_T;

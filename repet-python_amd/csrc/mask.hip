@@ -405,6 +405,7 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
     const int64_t rows = m.T - first_frame;
     const unsigned n_launch = (unsigned)(t_end - m.frame0);   // frames [frame0, t_end) are processed
     const unsigned nb = (unsigned)(m.n_batch > 1 ? m.n_batch : 1);
+    hipError_t bits_error = hipSuccess;
     dispatch_net(max_count, [&](auto net) {
         constexpr int NET = decltype(net)::value;
         if (split) {
@@ -416,7 +417,10 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
             }
             if (parts & 1) {
                 if constexpr (NET >= 2) {
-                    if (m.R != nullptr && ((m.F - 1) & 127) == 0 && nb == 1 && first_frame == 0) {
+                    if (m.P != nullptr && m.R != nullptr && nb == 1 && first_frame == 0 &&
+                        mask_sim_bits_supported(m.T, m.n_channels, m.n_rank_cols, max_count) && m.n_rank_cols == m.F - 1) {
+                        bits_error = launch_mask_sim_bits(m, idx, idx_pitch, count, max_count, n_launch, s);
+                    } else if (m.R != nullptr && ((m.F - 1) & 127) == 0 && nb == 1 && first_frame == 0) {
                         const int n_quads = (int)ceil_div(n_launch, 4);
                         const int combos = m.n_channels * ((m.F - 1) >> 7);
                         hipLaunchKernelGGL(mask_sim_rank_kernel<NET>, dim3((unsigned)(8 * ceil_div(combos, 8) * n_quads)), dim3(256), 0, s,
@@ -435,6 +439,7 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                                m, idx, idx_pitch, count, first_frame);
         }
     });
+    if (bits_error != hipSuccess) return bits_error;
     return hipGetLastError();
 }
 

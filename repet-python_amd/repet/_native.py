@@ -111,6 +111,8 @@ _SIGNATURES = {
     "repet_mask_sim": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "repet_rank_columns": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "repet_ctx_last_periods": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    "repet_ctx_last_median_path": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "repet_ctx_last_median_codes": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
     "repet_ctx_last_sim_indices": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "repet_ctx_last_frame_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "repet_ctx_last_refine_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -357,6 +359,20 @@ class Context:
         n = C.c_int32()
         check(lib().repet_ctx_last_periods(self._h, ptr(out), capacity, C.byref(n)))
         return out[:n.value].copy()
+
+    def last_median_path(self):
+        """'f32', 'rank' or 'bits': the form of sim's median the last run took (see repet_ctx_last_median_path)."""
+        v = C.c_int32()
+        check(lib().repet_ctx_last_median_path(self._h, C.byref(v)))
+        return ("f32", "rank", "bits")[v.value]
+
+    def last_median_codes(self, number_bins):
+        """uint32[channels][frames][number_bins] of the last `sim` run on the bit-sliced path (repet_ctx_last_median_codes)."""
+        t = self.last_frame_count()
+        ch = self.shape[-1]
+        out = np.empty((ch, t, number_bins), dtype=np.uint32)
+        check(lib().repet_ctx_last_median_codes(self._h, ptr(out), t, number_bins))
+        return out
 
     def last_frame_count(self):
         t = C.c_int64()

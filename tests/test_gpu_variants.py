@@ -661,12 +661,14 @@ def test_gram_tile_sizes_give_the_same_matrix():
 
 
 @pytest.mark.parametrize("seconds,fs,channels,number,distance", [(50, 44100, 2, 100, 1.0), (110, 22050, 1, 100, 0.3),
-                                                                  (70, 16000, 3, 64, 0.2), (30, 44100, 2, 31, 0.1)])
+                                                                  (70, 16000, 3, 64, 0.2), (30, 44100, 2, 31, 0.1),
+                                                                  (40, 44100, 2, 128, 0.05), (100, 8000, 4, 101, 0.1)])
 def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance):
-    """sim's median: the rank-domain form (default on clips of more than 1 024 frames: rank.hip + packed 16-bit
-    selection network) against the selection on the float magnitudes (REPET_MEDIAN=f32). A median is a selection, so
-    the two must agree BIT FOR BIT, not to a tolerance -- odd (25, 31) and even (64, 100) list lengths, short lists
-    padded, several network sizes, 1-3 channels."""
+    """sim's median on clips of more than 1 024 frames: the bit-sliced selection on the rank codes (default: rank.hip +
+    mask_bits.hip) and the packed 16-bit selection network on the same codes (REPET_MEDIAN=rank) against the selection on
+    the float magnitudes (REPET_MEDIAN=f32). A median is a selection, so the three must agree BIT FOR BIT, not to a
+    tolerance -- odd (31, 101) and even (64, 100, 128) list lengths, short lists, both list halves of the bit-sliced
+    kernel (50 and 64 entries per wave), 11 to 13 code planes, 1-4 channels (8, 16, 24 and 32 blocks of 64 bins)."""
     import os
     import subprocess
     import sys
@@ -674,18 +676,20 @@ def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance)
             "repet.similarity_number = {number}; repet.similarity_distance = {distance}; "
             "x = synth({seconds}, {fs}, {channels}, 33); p = repet.derive_params({fs}); c = repet.Context(0); c.upload(x); "
             "tm = c.execute('sim', p, timing=True); y = c.download(); _, cnt = c.last_sim_indices(c.last_frame_count(), p.sim_number); "
-            "np.savez(sys.argv[1], y=y, cnt=cnt, stages=np.array([s['name'] for s in tm['stages']]))")
+            "np.savez(sys.argv[1], y=y, cnt=cnt, stages=np.array([s['name'] for s in tm['stages']]), path=np.array(c.last_median_path()))")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (code % (os.path.join(root, "repet-python_amd"), root)).format(number=number, distance=distance, seconds=seconds, fs=fs, channels=channels)
     outs = []
-    for path in ("rank", "f32"):
+    for path in ("bits", "rank", "f32"):
         out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_median_{path}_{os.getpid()}.npz")
         subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MEDIAN=path))
         with np.load(out) as z:
             outs.append({k: z[k] for k in z.files})
         os.remove(out)
-    assert any("rank_columns" in n for n in outs[0]["stages"].tolist()) and not any("rank_columns" in n for n in outs[1]["stages"].tolist())
-    assert np.array_equal(outs[0]["y"], outs[1]["y"])
+        assert str(outs[-1]["path"]) == path
+    assert any("rank_columns" in n for n in outs[0]["stages"].tolist()) and not any("rank_columns" in n for n in outs[2]["stages"].tolist())
+    assert np.array_equal(outs[1]["y"], outs[2]["y"])
+    assert np.array_equal(outs[0]["y"], outs[2]["y"])
 
 
 def test_long_similarity_number_uses_bisection_path():

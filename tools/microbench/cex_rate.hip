@@ -50,6 +50,14 @@ KERNEL(pk_maximum3_f16, asm volatile(E8_3("v_pk_maximum3_f16") IO);)
 KERNEL(minimum3_f32, asm volatile(E8_3("v_minimum3_f32") IO);)
 KERNEL(bfi_b32, asm volatile(E8_3("v_bfi_b32") IO);)
 KERNEL(perm_b32, asm volatile(E8_3("v_perm_b32") IO);)
+// three-input boolean forms (bit-sliced counters): gfx950's v_bitop3_b32 (any truth table) beside the two-input ones
+#define E8_3T(OP, TAIL) OP " %0, %0, %8, %9" TAIL "\n" OP " %1, %1, %8, %9" TAIL "\n" OP " %2, %2, %8, %9" TAIL "\n" OP " %3, %3, %8, %9" TAIL "\n" OP " %4, %4, %8, %9" TAIL "\n" OP " %5, %5, %8, %9" TAIL "\n" OP " %6, %6, %8, %9" TAIL "\n" OP " %7, %7, %8, %9" TAIL "\n"
+KERNEL(bitop3_xor3, asm volatile(E8_3T("v_bitop3_b32", " bitop3:0x96") IO);)
+KERNEL(bitop3_maj, asm volatile(E8_3T("v_bitop3_b32", " bitop3:0xe8") IO);)
+KERNEL(or_b32, asm volatile(E8("v_or_b32") IO);)
+KERNEL(xor_b32, asm volatile(E8("v_xor_b32") IO);)
+KERNEL(xnor_b32, asm volatile(E8("v_xnor_b32") IO);)
+KERNEL(bitop3_b16, asm volatile(E8_3T("v_bitop3_b16", " bitop3:0x96") IO);)
 KERNEL(min_u32_dpp, asm volatile(
     "v_min_u32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
     "v_min_u32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
@@ -135,6 +143,9 @@ int main() {
     run("v_pk_minimum3_f16", k_pk_minimum3_f16, d, 64, 0, ""); run("v_pk_maximum3_f16", k_pk_maximum3_f16, d, 64, 0, "");
     run("v_minimum3_f32", k_minimum3_f32, d, 64, 0, "");
     run("v_bfi_b32", k_bfi_b32, d, 64, 0, ""); run("v_perm_b32", k_perm_b32, d, 64, 0, "");
+    run("v_bitop3_b32 xor3", k_bitop3_xor3, d, 64, 0, ""); run("v_bitop3_b32 maj", k_bitop3_maj, d, 64, 0, "");
+    run("v_or_b32", k_or_b32, d, 64, 0, ""); run("v_xor_b32", k_xor_b32, d, 64, 0, ""); run("v_xnor_b32", k_xnor_b32, d, 64, 0, "");
+    run("v_bitop3_b16", k_bitop3_b16, d, 64, 0, "");
     run("v_min_u32 dpp", k_min_u32_dpp, d, 64, 0, ""); run("v_mov_b32 dpp", k_mov_dpp, d, 64, 0, "");
     run("v_permlane32_swap", k_permlane32_swap, d, 64, 0, ""); run("v_permlane16_swap", k_permlane16_swap, d, 64, 0, "");
     run("ds_swizzle_b32", k_ds_swizzle, d, 64 + 8, 0, "");
