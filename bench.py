@@ -35,10 +35,13 @@ VALU_QUARTER_RATE_GINSTR = 1024 * 2.4 / 4.0
 # be put in, whatever its instruction class -- profiles/r03_valu_rate.txt holds the control rows (v_add / v_fma / v_and at
 # 2.0-2.4 cycles) beside the min / max / packed-min classes (4.2-4.75 cycles) at the measured shader clock
 VALU_FULL_RATE_GINSTR = 1024 * 2.4 / 2.0
+# rows gathered from a table that an XCD's L2 holds: 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, 'Indexed rows'); the
+# vector memory path of the CUs caps the same traffic at 256 CUs x 64 B/clk x 2.4 GHz = 39 TB/s, which it never reaches
+L2_GATHER_PEAK_GBS = 17800.0
 PMC_FILE = "r04_pmc_traffic.json"
 # arithmetic type of the path: fp32 end to end, except that the similarity GEMM of sim / simonline runs on the f16 matrix
 # cores as a three-product split of the fp32 operands (22 significant bits per product, fp32 accumulate; gram_f16.hip)
-DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on 16-bit rank codes)",
+DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on bit-sliced rank codes)",
               "simonline": "f32 (similarity band: f16x3 split of the fp32 unit rows, fp32 accumulate)"}
 
 
@@ -299,7 +302,43 @@ def main():
             meta = stage_meta[name]
             sec = ms * 1e-3
             entry = {"name": name, "ms": round(ms, 4)}
-            if name.startswith("mask_sim") and net_instr:
+            if name == "mask_sim_select":
+                # the bit-sliced selection (mask_bits.hip): per frame and list entry one 256-byte row of every code plane,
+                # gathered through L2 / Infinity Cache -- what bounds it is that gather path, not the ~9 400 boolean wave
+                # instructions per frame (tools/microbench/bitslice_select.hip: same time with the lists in a 1 MB window,
+                # 20 % more with uniformly random lists)
+                planes = max(int(T - 1).bit_length(), 11)
+                gathered = 256.0 * planes * (k_mean + 1.0) * rows
+                ni = ctypes.c_int32()
+                _native.lib().repet_median_network_info(-int(bound), None, ctypes.byref(ni))      # (negative bound: the bit-sliced form)
+                instr = ni.value * planes * rows if ni.value > 0 else None
+                ach = gathered / sec / 1e9
+                entry.update({"bound": "l2", "achieved": round(ach, 1), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s (gathered plane rows)",
+                              "frac": round(ach / L2_GATHER_PEAK_GBS, 4), "algorithmic": gathered,
+                              "peak_note": "L2-served row gathers, 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md 'Indexed rows: gather into LDS')",
+                              "planes": planes, "k_mean": round(k_mean, 2)})
+                if instr:
+                    gi = instr / sec / 1e9
+                    entry["valu_view"] = {"wave_instructions": instr, "achieved": round(gi, 1), "peak": VALU_FULL_RATE_GINSTR, "unit": "G wave-instr/s",
+                                          "frac": round(gi / VALU_FULL_RATE_GINSTR, 4),
+                                          "note": "v_bitop3_b32 is in the fast VALU class (2.6 cycles at 8 waves per SIMD, profiles/r04_valu_rate.txt)"}
+                b8d = 4.0 * F * rows * C * (1.0 + k_mean + 1.0)
+                entry["survey_8d_bytes"] = {"algorithmic": b8d, "note": "SURVEY 8d prices K5 as one stage: see mask_sim"}
+            elif name == "mask_sim" and "mask_sim_select" in stage_ms:
+                # lookups of the two middle values in the sorted columns (L2-resident by construction: one block of columns per
+                # XCD at a time) + the mask: V and the code word in, X masked in place
+                ach = meta["bytes"] / sec / 1e9
+                entry.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "algorithmic": meta["bytes"],
+                              "note": "streams V, the selected codes and X; the scattered 4-byte table reads (two per cell that needs them, a 128-byte "
+                                      "L2 line each) are what it waits for"})
+                both = sec + stage_ms["mask_sim_select"] / steps * 1e-3
+                b8d = 4.0 * F * rows * C * (1.0 + k_mean + 1.0)
+                entry["survey_8d_bytes"] = {"algorithmic": b8d, "GB/s": round(b8d / both / 1e9, 1), "frac_of_hbm_peak": round(b8d / both / 1e9 / HBM_PEAK_GBS, 4),
+                                            "k_mean": round(k_mean, 2), "ms": round(both * 1e3, 4),
+                                            "note": "SURVEY 8d's byte view of K5 over BOTH kernels of the median (selection + lookups): cache-served gathers, "
+                                                    "and 13 bits per gathered value instead of 32"}
+            elif name.startswith("mask_sim") and net_instr:
                 # VALU-issue-bound: one selection network per wave and block of bins. A wave covers 64 bins
                 # on the float path, 128 (two 16-bit rank codes per lane) on the rank path; v_min/v_max-class
                 # instructions issue at one per 4 cycles per SIMD (1 024 SIMDs, 2.4 GHz max clock).
@@ -351,7 +390,9 @@ def main():
                                      "latency-bound) and the column sort of V (transpose, per-column sort + rank search in LDS, transpose back); "
                                      "bytes = S read once + the sort's passes, time = both")
             stages.append(entry)
-        dom = max(stages, key=lambda s: s["ms"])
+        # the dominant KERNEL: "peaks+rank_columns" is two chains of seven launches side by side on two streams, not a kernel
+        single = [s for s in stages if s["name"] != "peaks+rank_columns"] or stages
+        dom = max(single, key=lambda s: s["ms"])
         roof = {"kernel": dom["name"]}
         roof.update({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in dom})
         roof["traffic"] = None
@@ -368,7 +409,7 @@ def main():
             pass
         roof["ms_per_launch"] = dom["ms"]
         roof["algorithmic_per_launch"] = dom.get("algorithmic")
-        for extra in ("network", "survey_8d_bytes", "fp32_equivalent", "frac_vs_full_rate_valu", "full_rate_valu_peak", "peak_note"):
+        for extra in ("network", "survey_8d_bytes", "fp32_equivalent", "frac_vs_full_rate_valu", "full_rate_valu_peak", "peak_note", "valu_view", "planes", "k_mean"):
             if extra in dom:
                 roof[extra] = dom[extra]
         line = {

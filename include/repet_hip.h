@@ -204,7 +204,9 @@ int repet_ctx_execute_extended_range(repet_ctx* ctx, const repet_params* p, int6
 /* ---- one-shot drop-in: replaces repet.<algo>(audio_signal, fs) (repet.py:67,205,422,571,712) -- */
 /* Measurement aid (bench.py's roofline): the median of a list of at most list_bound values is a compare-exchange
  * selection network evaluated per lane (np.median, repet.py:1535); *network_size = wires of the compiled network
- * (0: lists longer than 128 use bisection), *instructions = min/max instructions per evaluation. */
+ * (0: lists longer than 128 use bisection), *instructions = min/max instructions per evaluation. A NEGATIVE list_bound asks
+ * about the bit-sliced selection (mask_bits.hip) for lists of at most -list_bound entries: *network_size = 0, *instructions =
+ * boolean wave instructions per frame (all its cells) and code plane. */
 int repet_median_network_info(int32_t list_bound, int32_t* network_size, int32_t* instructions);
 
 /* repet_run keeps one context per calling thread and device (stream, tables, grow-only workspaces -- for `sim` the

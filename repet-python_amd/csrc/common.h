@@ -374,14 +374,17 @@ hipError_t launch_fill_pad_rows(float* V, int64_t chan_stride, int32_t n_channel
 // parts: 1 = main kernel only, 2 = Nyquist-bin kernel only, 3 = both (chunked pipelines launch them separately).
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side = nullptr,
-                           hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3);
+                           hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int parts = 3, bool lookups_by_caller = false);
 int median_network_instructions(int max_n, int* net_size);
 // bit-sliced selection (mask_bits.hip): lists of at most 128 entries, at most 32 blocks of 64 ranked bins over all channels
 int code_planes_for(int64_t T);                       // planes of the codes of a T-frame clip (bits of T - 1, at least 11)
 bool mask_sim_bits_supported(int64_t T, int32_t n_channels, int32_t n_cols, int32_t max_count);
 int mask_sim_bits_instructions(int32_t max_count, int32_t n_planes);
+// the selection (codes of both medians per cell into m.median_codes), and the lookups + mask from those codes (the caller
+// launches the second behind the first; launch_mask_sim does both unless told that the caller will)
 hipError_t launch_mask_sim_bits(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count, int32_t max_count,
                                 unsigned n_launch, hipStream_t s);
+hipError_t launch_mask_from_codes(const MaskArgs& m, const int32_t* count, hipStream_t s);
 hipError_t launch_mask_adaptive(const MaskArgs& m, const int32_t* periods, int32_t order, hipStream_t s);
 hipError_t launch_mask_period(const MaskArgs& m, const int32_t* period_dev, int32_t period_host,
                               int32_t min_period, hipStream_t s);

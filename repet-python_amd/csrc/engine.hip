@@ -1007,6 +1007,11 @@ static int thread_ctx(int device, repet_ctx** out) {
 }
 
 int repet_median_network_info(int32_t list_bound, int32_t* network_size, int32_t* instructions) {
+    if (list_bound < 0) {                // the bit-sliced selection: wave instructions per frame and PLANE (mask_bits.hip)
+        if (network_size) *network_size = 0;
+        if (instructions) *instructions = mask_sim_bits_instructions(-list_bound, 1);
+        return REPET_OK;
+    }
     int size = 0;
     const int n = median_network_instructions(list_bound, &size);
     if (network_size) *network_size = size;

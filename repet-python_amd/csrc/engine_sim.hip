@@ -241,10 +241,17 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true, max_peaks));
         }
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
-                                c->fork_event, c->join_event));
+                                c->fork_event, c->join_event, 3, m.P != nullptr));
         c->last_median_path = m.P ? 2 : m.R ? 1 : 0;
         c->last_FS = g.FS; c->last_chan_stride = g.chan_stride;
-        mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
+        if (m.P) {
+            // the selection gathers one 256-byte plane row per list entry and plane (+ the frame's own), and leaves a word per cell
+            mark(c, "mask_sim_select", 256.0 * m.n_planes * (K + 1.0) * T + 4.0 * (g.F - 1) * T * g.C, 0);
+            HIP_TRY(launch_mask_from_codes(m, c->cnt.as<int32_t>(), c->stream));
+            // V and the code word read, X masked in place (or the mask written), two table entries for the cells that need them
+            mark(c, "mask_sim", (4.0 + 4.0 + 8.0 + (c->mask_plane ? 4.0 : 16.0)) * (g.F - 1) * T * g.C, 0);
+        } else
+            mark(c, "mask_sim", (4.0 + 4.0 * K + (c->mask_plane ? 4.0 : 16.0)) * g.F * T * g.C, 0);
     }
     RP_TRY(run_istft(c, g, tb, g.W - g.H, N, 0, false, 0, 0));
     c->last_T = T; c->last_idx_rows = T; c->last_idx_pitch = KP; c->last_idx_number = K;

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const 
 
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
                            int64_t first_frame, int32_t max_count, hipStream_t s, hipStream_t side,
-                           hipEvent_t fork, hipEvent_t join, int parts) {
+                           hipEvent_t fork, hipEvent_t join, int parts, bool lookups_by_caller) {
     const int64_t t_end = m.frame_end > 0 ? m.frame_end : m.T;
     if (t_end - m.frame0 <= 0) return hipSuccess;
     // the Nyquist-bin kernel (a few hundred latency-bound waves) runs on `side` next to the main kernel
@@ -420,6 +420,7 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                     if (m.P != nullptr && m.R != nullptr && nb == 1 && first_frame == 0 &&
                         mask_sim_bits_supported(m.T, m.n_channels, m.n_rank_cols, max_count) && m.n_rank_cols == m.F - 1) {
                         bits_error = launch_mask_sim_bits(m, idx, idx_pitch, count, max_count, n_launch, s);
+                        if (bits_error == hipSuccess && !lookups_by_caller) bits_error = launch_mask_from_codes(m, count, s);
                     } else if (m.R != nullptr && ((m.F - 1) & 127) == 0 && nb == 1 && first_frame == 0) {
                         const int n_quads = (int)ceil_div(n_launch, 4);
                         const int combos = m.n_channels * ((m.F - 1) >> 7);

@@ -275,10 +275,14 @@ hipError_t launch_mask_sim_bits(const MaskArgs& m, const int32_t* idx, int32_t i
         return hipErrorInvalidValue;
     int bpc_shift = 0;
     while ((64 << bpc_shift) < m.n_rank_cols) ++bpc_shift;
-    hipError_t e = max_count <= 100 ? launch_bits_h<25>(m, idx, idx_pitch, count, n_launch, bpc_shift, s)
-                                    : launch_bits_h<32>(m, idx, idx_pitch, count, n_launch, bpc_shift, s);
-    if (e != hipSuccess) return e;
-    const int n_quads = (int)ceil_div(n_launch, 4);
+    return max_count <= 100 ? launch_bits_h<25>(m, idx, idx_pitch, count, n_launch, bpc_shift, s)
+                            : launch_bits_h<32>(m, idx, idx_pitch, count, n_launch, bpc_shift, s);
+}
+
+hipError_t launch_mask_from_codes(const MaskArgs& m, const int32_t* count, hipStream_t s) {
+    const int64_t t_end = m.frame_end > 0 ? m.frame_end : m.T;
+    if (!m.median_codes || !m.Vs || t_end <= m.frame0 || (m.n_rank_cols & 127)) return hipErrorInvalidValue;
+    const int n_quads = (int)ceil_div(t_end - m.frame0, 4);
     const int combos = m.n_channels * (m.n_rank_cols >> 7);
     hipLaunchKernelGGL(mask_from_codes_kernel, dim3((unsigned)(8 * ceil_div(combos, 8) * n_quads)), dim3(256), 0, s, m, count, n_quads);
     return hipGetLastError();
