@@ -32,12 +32,9 @@ namespace repet {
 
 namespace {
 
+// (the builtin, not inline asm: around opaque asm the compiler pads possible hazards with s_nop -- 31 per plane in the counter)
 template <int IMM>
-__device__ __forceinline__ unsigned bitop3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(IMM));
-    return r;
-}
+__device__ __forceinline__ unsigned bitop3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, IMM); }
 // truth tables: operand 0 = 0xF0, operand 1 = 0xCC, operand 2 = 0xAA
 __device__ __forceinline__ unsigned bs_xor3(unsigned a, unsigned b, unsigned c) { return bitop3<0x96>(a, b, c); }
 __device__ __forceinline__ unsigned bs_maj(unsigned a, unsigned b, unsigned c) { return bitop3<0xE8>(a, b, c); }
@@ -76,7 +73,7 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
     constexpr int kD = BitsliceCount<H>::kDigits;          // digits of a wave's own count
     constexpr int kR = bit_length(4 * H);                  // digits of the whole count and of the rank
     constexpr int kRowWords = 64, kRowBytes = NP * kRowWords * 4;
-    __shared__ unsigned xch[4][kD + 1][64];                // per wave: the digits of its count, "one of my entries has a zero"
+    __shared__ uint4 xch[4][2][64];                        // per wave and lane: the digits of its count, "one of my entries has a zero"
     __shared__ unsigned dec[2][64];                        // the leader's verdicts of this plane
     __shared__ unsigned lu[2][NP][64];                     // the code images of the lower and the upper median
     const int64_t t_end = a.frame_end > 0 ? a.frame_end : a.T;
@@ -97,10 +94,11 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
         off[k] = __builtin_amdgcn_readlane(off_v, k);
         A1[k] = (w * H + k < n) ? ~0u : 0u;
         A2[k] = A1[k];
-        B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, off[k] + (NP - 1) * (kRowWords * 4), 0);
+        B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + (NP - 1) * (kRowWords * 4), off[k], 0);
     }
-    // the leader's state (wave 0): the rank still wanted among the entries in the running, D = cells whose upper median has
+    // the leader's state: the rank still wanted among the entries in the running, D = cells whose upper median has
     // left the lower one's path. An odd list has ONE middle entry: the two never part.
+    const int lead = (blockIdx.x >> 8) & 3;                 // (not always wave 0: the waves of one number share a SIMD)
     unsigned r1[kR], D = 0u;
     const unsigned even = (n & 1) ? 0u : ~0u;
 #pragma unroll
@@ -118,35 +116,55 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
             for (int k = 0; k + 1 < H; k += 2) any2 = bs_or3(any2, z[k], z[k + 1]);
             if (H & 1) any2 |= z[H - 1];
         }
-        if (w != 0) {
+        static_assert(kD + 1 <= 8, "two 16-byte words per lane");
+        if (w != lead) {
+            unsigned v[8];
 #pragma unroll
-            for (int d = 0; d < kD; ++d) xch[w][d][lane] = c1[d];
-            xch[w][kD][lane] = any2;
+            for (int d = 0; d < 8; ++d) v[d] = d < kD ? c1[d] : d == kD ? any2 : 0u;
+            xch[w][0][lane] = make_uint4(v[0], v[1], v[2], v[3]);
+            xch[w][1][lane] = make_uint4(v[4], v[5], v[6], v[7]);
         }
         __syncthreads();
-        if (w == 0) {                                       // the leader adds the partial counts up and decides for everybody
-            unsigned tot[kR];
+        if (w == lead) {                                    // the leader adds the partial counts up and decides for everybody
+            __builtin_amdgcn_s_setprio(3);                  // (the other three wait for this: first in line on its SIMD)
+            unsigned q[3][8];
 #pragma unroll
-            for (int d = 0; d < kR; ++d) tot[d] = d < kD ? c1[d] : 0u;
-#pragma unroll
-            for (int ow = 1; ow < 4; ++ow) {
-                unsigned cy = 0u;
-#pragma unroll
-                for (int d = 0; d < kR; ++d) {
-                    const unsigned x = tot[d], y = d < kD ? xch[ow][d][lane] : 0u;
-                    tot[d] = bs_xor3(x, y, cy);
-                    cy = bs_maj(x, y, cy);
-                }
-                any2 |= xch[ow][kD][lane];
+            for (int oi = 0; oi < 3; ++oi) {
+                const int ow = (lead + 1 + oi) & 3;
+                const uint4 lo = xch[ow][0][lane], hi = xch[ow][1][lane];
+                q[oi][0] = lo.x; q[oi][1] = lo.y; q[oi][2] = lo.z; q[oi][3] = lo.w;
+                q[oi][4] = hi.x; q[oi][5] = hi.y; q[oi][6] = hi.z; q[oi][7] = hi.w;
             }
-            unsigned diff[kR], bw = 0u, all = ~0u;          // rank - count; the borrow out says rank < count
+            any2 = bs_or3(any2, q[0][kD], q[1][kD]) | q[2][kD];
+            // The four counts in carry-save form (every digit on its own, no carry chain): count = A + B. Then
+            // rank - count = rank + ~A + ~B + 2 in kR + 1 digits of two's complement -- one more carry-save layer and ONE ripple;
+            // its sign digit says rank < count.
+            unsigned s1_[kD], c1_[kD], A[kR + 1], Bv[kR + 1];
 #pragma unroll
-            for (int d = 0; d < kR; ++d) {
-                diff[d] = bs_xor3(r1[d], tot[d], bw);
-                bw = bs_borrow(r1[d], tot[d], bw);
-                all &= diff[d];
+            for (int d = 0; d < kD; ++d) { s1_[d] = bs_xor3(c1[d], q[0][d], q[1][d]); c1_[d] = bs_maj(c1[d], q[0][d], q[1][d]); }
+#pragma unroll
+            for (int d = 0; d <= kR; ++d) { A[d] = 0u; Bv[d] = 0u; }
+#pragma unroll
+            for (int d = 0; d < kD; ++d) {
+                const unsigned cin = d > 0 ? c1_[d - 1] : 0u;
+                A[d] = bs_xor3(s1_[d], q[2][d], cin);
+                Bv[d + 1] = bs_maj(s1_[d], q[2][d], cin);
             }
-            // count == rank + 1 (the difference is -1: every digit set): here the two medians part
+            A[kD] = c1_[kD - 1];                            // the top carry of the first layer
+            unsigned diff[kR + 1], cy = ~0u, prev = ~0u;     // (the + 2: a carry into the ripple and a 1 in the vacant digit 0 of the carries)
+#pragma unroll
+            for (int d = 0; d <= kR; ++d) {
+                const unsigned rd = d < kR ? r1[d] : 0u;
+                const unsigned s3 = bs_xor3(rd, A[d], Bv[d]);
+                const unsigned c3 = bitop3<0x71>(rd, A[d], Bv[d]);      // maj(r, ~a, ~b)
+                diff[d] = bs_xor3(s3, prev, cy);
+                cy = bs_maj(s3, prev, cy);
+                prev = c3;
+            }
+            const unsigned bw = diff[kR];                   // negative: rank < count
+            unsigned all = diff[0];
+#pragma unroll
+            for (int d = 1; d <= kR; ++d) all &= diff[d];
             const unsigned part = all & bw & even;
             const unsigned s1 = bw, s2 = bs_sel(D, any2, bw & ~part);
             D = bs_or_andn(D, s1, s2);
@@ -154,15 +172,17 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
             for (int d = 0; d < kR; ++d) r1[d] = bs_sel(bw, r1[d], diff[d]);
             dec[0][lane] = s1; dec[1][lane] = s2;
             lu[0][p][lane] = ~s1; lu[1][p][lane] = ~s2;
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         const unsigned s1 = dec[0][lane], s2 = dec[1][lane];
-        const int pn = p > 0 ? p - 1 : 0;                   // (the last round reads plane 0 again rather than branching)
+        // the plane's offset travels in the lanes' offset, the entry's row in the scalar one (no scalar add per load)
+        const int next = lane * 4 + (p > 0 ? p - 1 : 0) * (kRowWords * 4);     // (the last round reads plane 0 again rather than branching)
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             A1[k] = bs_keep(A1[k], B[k], s1);
             A2[k] = bs_keep(A2[k], B[k], s2);
-            B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, off[k] + pn * (kRowWords * 4), 0);
+            B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, next, off[k], 0);
         }
     }
     // ---- the two code images back into numbers: wave w for the cells of bits [8 w, 8 w + 8) ----
