@@ -18,6 +18,12 @@ step timeout 300 python3 tools/stream_bench.py > gpurun_out/round/stream_latency
 step timeout 300 bash tools/valu_rates.sh > gpurun_out/round/valu_rate.log 2>&1
 cp gpurun_out/valu_rate.txt gpurun_out/round/valu_rate.txt
 step timeout 300 python3 tools/peak_stamps.py > gpurun_out/round/peak_gram_spans.txt 2>&1
+# the bit-sliced selection on its own, on the lists of the bench clip: time, and cycles per phase of a wave
+step timeout 300 python3 tools/dump_sim_lists.py /tmp/sim_lists.bin > gpurun_out/round/bitslice_select.txt 2>&1
+for flags in "" "-DSTAMPS"; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $flags -mllvm -pragma-unroll-threshold=131072 -Irepet-python_amd/csrc tools/microbench/bitslice_select.hip -o /tmp/bitslice_select 2>/dev/null
+  { echo "# bitslice_select $flags: real lists, lists inside +-150 frames, uniform lists"; /tmp/bitslice_select 0 /tmp/sim_lists.bin; /tmp/bitslice_select 150; /tmp/bitslice_select 0; } >> gpurun_out/round/bitslice_select.txt 2>&1
+done
 tail -n 3 gpurun_out/round/round.log | cut -c1-400
 tail -3 gpurun_out/round/pmc_traffic.log
 ls -la gpurun_out/round

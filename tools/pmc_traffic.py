@@ -25,6 +25,9 @@ KERNELS = [
     ("segment_maxima_kernel", "local_maxima", 2, "16 B/lane"),
     ("columns_from_rows_kernel", "rank_columns", 1, "4 B/lane"), ("rank_columns_kernel", "rank_columns", 2, "16 B/lane"),
     ("rows_from_code_columns_kernel", "rank_columns", 1, "4 B/lane"),
+    ("mask_sim_bits_kernel", "mask_sim_select", 1, "4 B/lane gathers of plane rows"),
+    ("mask_from_codes_kernel", "mask_sim", 1, "8-16 B/lane streams beside 4-byte table reads: uncalibrated"),
+    ("code_planes_kernel", "rank_columns", 1, "2 B/lane"),
     ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("mask_sim_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("istft_ola_reg_kernel", "istft_ola", 2, "16 B/lane spectrum loads"), ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
