@@ -299,6 +299,13 @@ int repet_mask_adaptive(repet_ctx* ctx, const float* v, int64_t n_frames, int32_
 int repet_mask_sim(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, const int32_t* idx,
                    const int32_t* count, int32_t number, float* mask_out);
 
+/* repet_mask_sim through the rank transform below (what `sim` does on clips of more than 1 024 frames): path 1 = the packed
+ * 16-bit selection network on the rank codes, path 2 = the bit-sliced selection on the same codes; both give the bits of
+ * repet_mask_sim. n_freq - 1 a multiple of 128 (path 2: a power of two <= 2048), lists of at most 128 entries.
+ * median_codes_out (nullable, path 2): out[n_frames][n_freq - 1] as repet_ctx_last_median_codes describes them. */
+int repet_mask_sim_ranked(repet_ctx* ctx, const float* v, int64_t n_frames, int32_t n_freq, const int32_t* idx,
+                          const int32_t* count, int32_t number, int32_t path, float* mask_out, uint32_t* median_codes_out);
+
 /* Rank transform behind the median of `sim` (np.median over the similar frames is a selection, repet.py:1535: it only
  * needs the ORDER of a bin's magnitudes over the clip). v[T][F] -> codes_out[T][n] (0x0400 + number of frames whose
  * magnitude in that bin is strictly smaller) and sorted_out[n][T] (every bin's magnitudes in ascending order), for the

@@ -284,6 +284,54 @@ int repet_mask_sim(repet_ctx* c, const float* v, int64_t T, int32_t F, const int
     return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
 }
 
+int repet_mask_sim_ranked(repet_ctx* c, const float* v, int64_t T, int32_t F, const int32_t* idx, const int32_t* count,
+                          int32_t number, int32_t path, float* mask_out, uint32_t* median_codes_out) {
+    if (!c || !v || !idx || !count || !mask_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (path != 1 && path != 2) return fail(REPET_ERR_BAD_ARG, "path: 1 packed network on rank codes, 2 bit-sliced selection");
+    const int n_cols = F - 1;
+    if (F <= 128 || (n_cols & 127) || !rank_columns_supported(T) || number < 2 || number > 128)
+        return fail(REPET_ERR_LIMIT, "rank-domain median: 1024 < n_frames <= 30720, n_freq - 1 a multiple of 128, lists of 2..128 entries");
+    if (path == 2 && !mask_sim_bits_supported(T, 1, n_cols, number)) return fail(REPET_ERR_LIMIT, "bit-sliced selection: n_freq - 1 a power of two, at most 2048");
+    DeviceGuard guard(c->device);
+    MaskArgs m; int FS;
+    RP_TRY(stage_mask_common(c, v, T, F, &m, &FS));
+    const int64_t rows = T + kPadRows, vs_pitch = round_up(T, 32);
+    HIP_TRY(c->R.ensure((size_t)rows * FS * sizeof(unsigned short)));
+    c->r_pads_ptr = nullptr;                              // this export lays R out differently
+    HIP_TRY(launch_fill_rank_pad_rows(c->R.as<unsigned short>(), rows * FS, 1, T, FS, c->stream));
+    HIP_TRY(c->Vs.ensure((size_t)n_cols * vs_pitch * sizeof(float)));
+    HIP_TRY(c->rank_codes.ensure((size_t)n_cols * vs_pitch * sizeof(unsigned short)));
+    RankArgs a{};
+    a.V = c->V.as<float>(); a.chan_stride = rows * FS; a.n_channels = 1; a.T = T; a.FS = FS; a.n_cols = n_cols;
+    a.R = c->R.as<unsigned short>(); a.r_chan_stride = rows * FS; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
+    a.codes = c->rank_codes.as<unsigned short>();
+    if (path == 2) {
+        a.n_planes = code_planes_for(T);
+        HIP_TRY(c->code_planes.ensure((size_t)T * a.n_planes * 64 * sizeof(unsigned)));
+        a.P = c->code_planes.as<unsigned>();
+        HIP_TRY(c->median_codes.ensure((size_t)rows * FS * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(c->median_codes.p, 0, (size_t)rows * FS * sizeof(unsigned), c->stream));
+        m.median_codes = c->median_codes.as<unsigned>();
+    }
+    HIP_TRY(launch_rank_columns(a, c->stream));
+    m.R = a.R; m.r_chan_stride = a.r_chan_stride; m.Vs = a.Vs; m.vs_pitch = vs_pitch; m.n_rank_cols = n_cols;
+    m.P = a.P; m.n_planes = a.n_planes;
+    const int KP = std::max(number, kMinIdxPitch);
+    HIP_TRY(c->idx.ensure((size_t)T * KP * sizeof(int32_t)));
+    HIP_TRY(c->cnt.ensure((size_t)T * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(c->idx.p, 0, (size_t)T * KP * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemcpy2DAsync(c->idx.p, (size_t)KP * sizeof(int32_t), idx, (size_t)number * sizeof(int32_t),
+                             (size_t)number * sizeof(int32_t), T, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->cnt.p, count, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, number, c->stream));
+    if (median_codes_out) {
+        if (path != 2) return fail(REPET_ERR_BAD_ARG, "median codes exist on path 2 only");
+        HIP_TRY(hipMemcpy2DAsync(median_codes_out, (size_t)n_cols * 4, c->median_codes.p, (size_t)FS * 4, (size_t)n_cols * 4, T,
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    return d2h_pitched(c, mask_out, c->tmp_c.as<float>(), FS, T, F);
+}
+
 int repet_rank_columns(repet_ctx* c, const float* v, int64_t T, int32_t F, uint16_t* codes_out, float* sorted_out) {
     if (!c || !v || !codes_out || !sorted_out) return fail(REPET_ERR_BAD_ARG, "null argument");
     if (F < 128) return fail(REPET_ERR_BAD_ARG, "needs at least 128 bins");

@@ -341,6 +341,27 @@ def _simmask(audio_spectrogram, similarity_indices):
     return out.T.astype(np.float64)
 
 
+def _simmask_ranked(audio_spectrogram, similarity_indices, path="bits", want_codes=False):
+    """``_simmask`` the way ``sim`` computes it on clips of more than 1 024 frames: through the rank transform of every bin
+    (``_rank_columns``) and the packed 16-bit selection network (``path="rank"``) or the bit-sliced selection (``"bits"``).
+    ``(F, T)`` with ``F - 1`` a multiple of 128 (a power of two for ``"bits"``); ``want_codes``: also the ``uint32 (F - 1, T)``
+    words the bit-sliced selection leaves (lower median's rank | flag << 15 | upper median's rank << 16)."""
+    rows = _f32(np.asarray(audio_spectrogram).T)
+    t, f = rows.shape
+    width = max(2, max((len(ix) for ix in similarity_indices), default=2))
+    idx = np.full((t, width), -1, dtype=np.int32)
+    cnt = np.zeros(t, dtype=np.int32)
+    for i, ix in enumerate(similarity_indices):
+        idx[i, :len(ix)] = ix
+        cnt[i] = len(ix)
+    out = np.empty((t, f), dtype=np.float32)
+    codes = np.empty((t, f - 1), dtype=np.uint32) if want_codes else None
+    _native.check(_native.lib().repet_mask_sim_ranked(_native.default_context(_device).handle, _native.ptr(rows), t, f,
+                                                      _native.ptr(idx), _native.ptr(cnt), width, {"rank": 1, "bits": 2}[path],
+                                                      _native.ptr(out), _native.ptr(codes) if want_codes else None))
+    return (out.T.astype(np.float64), codes.T) if want_codes else out.T.astype(np.float64)
+
+
 def _rank_columns(audio_spectrogram):
     """Rank transform behind the median of ``sim`` (no counterpart in the reference: np.median at repet.py:1535 only
     needs the order of a bin's magnitudes). ``(F, T)`` -> (codes ``(n, T)`` uint16 = 0x0400 + number of strictly smaller

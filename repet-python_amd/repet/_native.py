@@ -110,6 +110,7 @@ _SIGNATURES = {
     "repet_mask_adaptive": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, _P]),
     "repet_mask_sim": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "repet_rank_columns": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
+    "repet_mask_sim_ranked": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "repet_ctx_last_periods": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "repet_ctx_last_median_path": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "repet_ctx_last_median_codes": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),

@@ -261,6 +261,46 @@ def test_rank_columns_against_numpy(t, f):
     assert np.array_equal(np.take_along_axis(ordered, codes.astype(np.int64) - 0x0400, axis=1), v[:n])
 
 
+@pytest.mark.parametrize("t,f,longest", [(1400, 1025, 100), (2100, 513, 100), (1100, 2049, 100), (4200, 257, 128), (8200, 129, 37)])
+def test_median_selection_on_rank_codes_against_numpy(t, f, longest):
+    """The two rank-domain forms of sim's median (mask.hip: the packed 16-bit network; mask_bits.hip: the bit-sliced radix
+    descent, lists of up to 100 and up to 128 entries, 11 to 14 code planes, 2 to 32 blocks of 64 bins) against NumPy, on
+    random magnitudes with ties and zeros and lists of every length from 0 to the longest, odd and even:
+      * the INTEGERS the bit-sliced selection leaves -- rank of the lower median, rank of the upper one, "the lower median
+        is below the frame's own value" -- are exactly what sorting the list's ranks gives;
+      * both masks have the bits of the float selection (repet._simmask), NaN for an empty list (np.median, repet.py:1535)."""
+    rs = np.random.RandomState(t + f + longest)
+    v = np.abs(rs.standard_normal((f, t))).astype(np.float32) * np.exp(rs.uniform(-10, 2, size=(f, 1))).astype(np.float32)
+    v[:, rs.randint(0, t, size=t // 9)] = v[:, rs.randint(0, t, size=t // 9)]        # ties between frames
+    v[1, : t // 3] = 0.0                                                             # zeros
+    v[2, :] = 0.5                                                                    # a constant bin
+    lengths = rs.randint(0, longest + 1, size=t)
+    lengths[:longest + 1] = np.arange(longest + 1)                                   # every length at least once
+    lists = [rs.choice(t, size=k, replace=False) for k in lengths]
+    for i in range(0, t, 3):                                                         # a frame is usually in its own list
+        if len(lists[i]) and i not in lists[i]:
+            lists[i][0] = i
+    want = repet._simmask(v, lists)
+    got_rank = repet._simmask_ranked(v, lists, "rank")
+    got_bits, codes = repet._simmask_ranked(v, lists, "bits", want_codes=True)
+    for got in (got_rank, got_bits):
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0))
+    ranks = np.empty((f - 1, t), dtype=np.int64)
+    for b in range(f - 1):
+        ranks[b] = np.searchsorted(np.sort(v[b]), v[b], side="left")
+    for i in range(0, t, 7):
+        n = len(lists[i])
+        if n == 0:
+            continue
+        r = np.sort(ranks[:, lists[i]], axis=1)
+        lower, upper = r[:, (n - 1) // 2], r[:, n // 2]
+        c = codes[:, i].astype(np.int64)
+        assert np.array_equal(c & 0x7fff, lower), i
+        assert np.array_equal(c >> 16, upper), i
+        assert np.array_equal((c >> 15) & 1, (lower < ranks[:, i]).astype(np.int64)), i
+
+
 def test_rank_columns_limits():
     with pytest.raises(RuntimeError):
         repet._rank_columns(np.ones((128, 1024), dtype=np.float32))      # too short: selecting on the floats is cheaper
