@@ -9,6 +9,9 @@ root="$GRAFT_REPO_ROOT"
 mkdir -p "$root/gpurun_out/round" "$root/gpurun_out/pmc_$tag"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 step() { echo "== $*"; "$@"; }
+# the diagnostic build travels with the snapshot (make -C repet-python_amd/csrc stamps, in the build container): an older one
+# than the library lacks its newest entry points, and the step that loads it would fail after everything else has run
+[ build_diag/lib_stamps.so -nt repet-python_amd/lib/librepet_hip.so ] || { echo "build_diag/lib_stamps.so is older than the library: run 'make -C repet-python_amd/csrc stamps' first"; exit 1; }
 step timeout 1800 bash tools/round_profile.sh > gpurun_out/round/round.log 2>&1
 step timeout 1200 bash tools/pmc_profile.sh "gpurun_out/pmc_$tag" > "gpurun_out/pmc_$tag/pmc.log" 2>&1
 step timeout 120 python3 tools/pmc_traffic.py "gpurun_out/pmc_$tag" gpurun_out/round/pmc_traffic.json > gpurun_out/round/pmc_traffic.log 2>&1
