@@ -123,19 +123,21 @@ static bool bits_median_enabled() {
 int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count) {
     const int n_cols = g.F - 1;
     const int64_t vs_pitch = round_up(g.T, 32);
-    HIP_TRY(c->R.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned short)));
+    // (the bit-sliced selection reads the code planes only: no frame-major codes R then)
+    const bool bits = bits_median_enabled() && mask_sim_bits_supported(g.T, g.C, n_cols, max_count);
+    if (!bits) HIP_TRY(c->R.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned short)));
     HIP_TRY(c->Vs.ensure((size_t)g.C * n_cols * vs_pitch * sizeof(float)));
     HIP_TRY(c->rank_codes.ensure((size_t)g.C * n_cols * vs_pitch * sizeof(unsigned short)));
-    if (c->r_pads_ptr != c->R.p || c->r_pads_stride != g.chan_stride || c->r_pads_row != g.Tpad || c->r_pads_channels != g.C ||
-        c->r_pads_fs != g.FS) {
+    if (!bits && (c->r_pads_ptr != c->R.p || c->r_pads_stride != g.chan_stride || c->r_pads_row != g.Tpad || c->r_pads_channels != g.C ||
+                  c->r_pads_fs != g.FS)) {
         HIP_TRY(launch_fill_rank_pad_rows(c->R.as<unsigned short>(), g.chan_stride, g.C, g.Tpad, g.FS, stream));
         c->r_pads_ptr = c->R.p; c->r_pads_stride = g.chan_stride; c->r_pads_row = g.Tpad; c->r_pads_channels = g.C; c->r_pads_fs = g.FS;
     }
     RankArgs a{};
     a.V = c->V.as<float>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.n_cols = n_cols;
-    a.R = c->R.as<unsigned short>(); a.r_chan_stride = g.chan_stride; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
+    a.R = bits ? nullptr : c->R.as<unsigned short>(); a.r_chan_stride = g.chan_stride; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
     a.codes = c->rank_codes.as<unsigned short>();
-    if (bits_median_enabled() && mask_sim_bits_supported(g.T, g.C, n_cols, max_count)) {
+    if (bits) {
         a.n_planes = code_planes_for(g.T);
         HIP_TRY(c->code_planes.ensure((size_t)g.T * a.n_planes * 64 * sizeof(unsigned)));
         a.P = c->code_planes.as<unsigned>();

@@ -417,7 +417,7 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
             }
             if (parts & 1) {
                 if constexpr (NET >= 2) {
-                    if (m.P != nullptr && m.R != nullptr && nb == 1 && first_frame == 0 &&
+                    if (m.P != nullptr && nb == 1 && first_frame == 0 &&
                         mask_sim_bits_supported(m.T, m.n_channels, m.n_rank_cols, max_count) && m.n_rank_cols == m.F - 1) {
                         bits_error = launch_mask_sim_bits(m, idx, idx_pitch, count, max_count, n_launch, s);
                         if (bits_error == hipSuccess && !lookups_by_caller) bits_error = launch_mask_from_codes(m, count, s);

@@ -124,23 +124,31 @@ __global__ __launch_bounds__(256) void columns_from_rows_kernel(RankArgs a) {
     __shared__ float tile[64][65];
     const int c = blockIdx.z, f0 = blockIdx.y * 64;
     const int64_t t0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 bytes per lane both ways: 4 bins in, 4 frames out
     const float* in = a.V + c * a.chan_stride;
-    // all sixteen loads first (clamped row: a load behind "t < T ?" sits in a branch and is waited for at its join, one
-    // memory round trip per row of the tile), the choice afterwards
-    float r[16];
+    // all four loads first (clamped row: a load behind "t < T ?" sits in a branch and is waited for at its join), the choice
+    // afterwards
+    float4 r[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int64_t t = t0 + ty + 4 * k;
-        r[k] = in[(t < a.T ? t : a.T - 1) * a.FS + f0 + tx];
+    for (int k = 0; k < 4; ++k) {
+        const int64_t t = t0 + ty + 16 * k;
+        r[k] = *reinterpret_cast<const float4*>(in + (t < a.T ? t : a.T - 1) * a.FS + f0 + 4 * tx);
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = (t0 + ty + 4 * k < a.T) ? r[k] : 0.f;
+    for (int k = 0; k < 4; ++k) {
+        const bool live = t0 + ty + 16 * k < a.T;
+        float* row = tile[ty + 16 * k] + 4 * tx;                   // (pitch 65: the four words go one by one, conflict-free both ways)
+        row[0] = live ? r[k].x : 0.f; row[1] = live ? r[k].y : 0.f; row[2] = live ? r[k].z : 0.f; row[3] = live ? r[k].w : 0.f;
+    }
     __syncthreads();
     float* out = a.Vs + ((int64_t)c * a.n_cols + f0) * a.vs_pitch;
-    if (t0 + tx < a.vs_pitch) {
+    if (t0 + 4 * tx < a.vs_pitch) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) out[(int64_t)(ty + 4 * k) * a.vs_pitch + t0 + tx] = tile[tx][ty + 4 * k];
+        for (int k = 0; k < 4; ++k) {
+            const int f = ty + 16 * k;
+            *reinterpret_cast<float4*>(out + (int64_t)f * a.vs_pitch + t0 + 4 * tx) =
+                make_float4(tile[4 * tx][f], tile[4 * tx + 1][f], tile[4 * tx + 2][f], tile[4 * tx + 3][f]);
+        }
     }
 }
 
@@ -210,6 +218,58 @@ __global__ __launch_bounds__(256) void code_planes_kernel(RankArgs a) {
 #pragma unroll
     for (int p = 0; p < 15; ++p)
         if (p < a.n_planes) out[p * 64] = x[p];
+}
+
+// codes[c * n_cols + f][pitch] (column-major, as the sort leaves them) -> P[t][plane][64] without the detour over R (the
+// bit-sliced selection reads the planes only): a workgroup of 1 024 threads takes 64 frames and the 32 cells 64 b + l of 32
+// values of l -- 1 024 columns, 128 bytes of each, through LDS (column pitch 66 codes: lanes on adjacent l read adjacent
+// banks) -- and a thread builds the plane words of two (frame, l) with the transpose above, lanes adjacent in l so that a
+// wave writes two 128-byte halves of plane rows.
+constexpr int kPlaneFrames = 64, kPlaneColPitch = 66;
+__global__ __launch_bounds__(1024) void code_planes_from_columns_kernel(RankArgs a) {
+    extern __shared__ unsigned short plane_lds[];                 // [1024 columns][66]
+    const int64_t t0 = (int64_t)blockIdx.x * kPlaneFrames;
+    const int l0 = blockIdx.y * 32;
+    const int bpc = a.n_cols >> 6, n_bits = a.n_channels * bpc;
+    // column q of the tile: bit b = q / 32, l = l0 + q % 32 -> cell 64 b + l = channel b / bpc, bin 64 (b % bpc) + l.
+    // 16-byte pieces (8 frames of one column), eight per thread, all loads first
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = threadIdx.x + 1024 * k, q = i >> 3, piece = i & 7;
+        const int b = q >> 5, l = l0 + (q & 31);
+        const int64_t t = t0 + piece * 8;
+        const bool in = b < n_bits && t < a.vs_pitch;
+        const int c = in ? b / bpc : 0, f = in ? (b - c * bpc) * 64 + l : 0;
+        v[k] = *reinterpret_cast<const uint4*>(a.codes + ((int64_t)c * a.n_cols + f) * a.vs_pitch + (in ? t : 0));
+        if (!in) v[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = threadIdx.x + 1024 * k, q = i >> 3, piece = i & 7;
+        unsigned* dst = reinterpret_cast<unsigned*>(plane_lds + q * kPlaneColPitch + piece * 8);      // 4-byte aligned (pitch 132 bytes)
+        dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 31;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int tl = (threadIdx.x >> 5) + 32 * k;
+        const int64_t t = t0 + tl;
+        if (t >= a.T) continue;
+        unsigned x[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const unsigned lo = b < n_bits ? plane_lds[(b * 32 + l) * kPlaneColPitch + tl] - kRankCodeBase : 0u;
+            const unsigned hi = b + 16 < n_bits ? plane_lds[((b + 16) * 32 + l) * kPlaneColPitch + tl] - kRankCodeBase : 0u;
+            x[b] = (lo & 0xffffu) | (hi << 16);
+        }
+        plane_transpose_stage<8>(x); plane_transpose_stage<4>(x); plane_transpose_stage<2>(x); plane_transpose_stage<1>(x);
+        unsigned* out = a.P + t * (int64_t)a.n_planes * 64 + l0 + l;
+#pragma unroll
+        for (int p = 0; p < 15; ++p)
+            if (p < a.n_planes) out[p * 64] = x[p];
+    }
 }
 
 #ifndef REPET_RANK_LEAF_BITS
@@ -358,6 +418,13 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(columns_from_rows_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
                        dim3(256), 0, s, a);
     hipLaunchKernelGGL(rank_columns_kernel<LOG2N>, dim3((unsigned)cols), dim3(N / 32), lds, s, a);
+    if (a.P && !a.R) {                   // the bit-sliced selection reads the planes only
+        constexpr int plane_lds_bytes = 1024 * kPlaneColPitch * 2;
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(&code_planes_from_columns_kernel), plane_lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(code_planes_from_columns_kernel, dim3((unsigned)ceil_div(a.T, kPlaneFrames), 2), dim3(1024), plane_lds_bytes, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(rows_from_code_columns_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 128), (unsigned)(a.n_cols / 128), (unsigned)a.n_channels),
                        dim3(256), 0, s, a);
     if (a.P) hipLaunchKernelGGL(code_planes_kernel, dim3((unsigned)ceil_div(a.T, 4)), dim3(256), 0, s, a);
