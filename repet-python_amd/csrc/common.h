@@ -400,7 +400,7 @@ struct RankArgs {
     unsigned short* R; int64_t r_chan_stride;
     float* Vs; int64_t vs_pitch;          // Vs[c * n_cols + f][vs_pitch], vs_pitch = round_up(T, 32)
     unsigned short* codes;                // scratch: the codes column-major, [c * n_cols + f][vs_pitch]
-    unsigned* P; int32_t n_planes;        // (nullable) the codes bit-sliced as well: MaskArgs::P
+    unsigned* P; int32_t n_planes;        // the codes bit-sliced INSTEAD of R (exactly one of R and P is set): MaskArgs::P
 };
 bool rank_columns_supported(int64_t T);
 hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s);

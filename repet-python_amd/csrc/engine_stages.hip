@@ -303,7 +303,7 @@ int repet_mask_sim_ranked(repet_ctx* c, const float* v, int64_t T, int32_t F, co
     HIP_TRY(c->rank_codes.ensure((size_t)n_cols * vs_pitch * sizeof(unsigned short)));
     RankArgs a{};
     a.V = c->V.as<float>(); a.chan_stride = rows * FS; a.n_channels = 1; a.T = T; a.FS = FS; a.n_cols = n_cols;
-    a.R = c->R.as<unsigned short>(); a.r_chan_stride = rows * FS; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
+    a.R = path == 2 ? nullptr : c->R.as<unsigned short>(); a.r_chan_stride = rows * FS; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
     a.codes = c->rank_codes.as<unsigned short>();
     if (path == 2) {
         a.n_planes = code_planes_for(T);

@@ -3,7 +3,7 @@
 // The packed network of mask_sim_rank_kernel works on two cells (bin x channel) per lane and instruction and is bound by
 // the issue rate of v_pk_min_u16 / v_pk_max_u16 (4.2 cycles per wave instruction): 1 426 of them per 128 cells. Here one
 // 32-bit register holds ONE BIT of the codes of 32 cells -- P[t][plane][l] bit b = bit `plane` of the code of cell
-// 64 b + l of frame t (code_planes_kernel, rank.hip) -- so a boolean instruction works on 32 cells per lane, 2 048 per wave,
+// 64 b + l of frame t (code_planes_from_columns_kernel, rank.hip) -- so a boolean instruction works on 32 cells per lane, 2 048 per wave,
 // and gfx950's v_bitop3_b32 (any function of three words, in the fast VALU class: 2.6 cycles) is a whole full adder's sum
 // or carry. An order statistic is found by a radix descent over the planes, most significant first:
 //   z_k    = alive_k & ~plane_k                  entries still in the running whose code has a 0 here

@@ -182,10 +182,9 @@ __global__ __launch_bounds__(256) void rows_from_code_columns_kernel(RankArgs a)
     }
 }
 
-// R[c][t][FS] -> P[t][plane][64] (MaskArgs::P): one wave per frame, lane l builds word l of every plane from the codes of
-// its 32 cells (bit b: channel b / bpc, bin 64 (b % bpc) + l -- each read a coalesced 128 bytes of the row). With codes b and
-// b + 16 in the two halves of register b, a 16 x 16 bit transpose of both halves at once IS the plane words: bit i of half h
-// of register p = bit p of code 16 h + i.
+// The plane words of the bit-sliced selection (MaskArgs::P) come out of a 16 x 16 bit transpose: with codes b and b + 16 in the
+// two halves of register b, transposing both halves at once gives, in register p, bit p of all 32 codes -- bit i of half h of
+// register p = bit p of code 16 h + i.
 template <int J>
 __device__ __forceinline__ void plane_transpose_stage(unsigned (&x)[16]) {
     constexpr unsigned m = J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu : J == 2 ? 0x33333333u : 0x55555555u;
@@ -197,29 +196,6 @@ __device__ __forceinline__ void plane_transpose_stage(unsigned (&x)[16]) {
             x[k] ^= t << J;
         }
 }
-__global__ __launch_bounds__(256) void code_planes_kernel(RankArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= a.T) return;
-    const int bpc = a.n_cols >> 6, n_bits = a.n_channels * bpc;
-    unsigned code[32];
-#pragma unroll
-    for (int b = 0; b < 32; ++b) {
-        const int bc = b < n_bits ? b : 0;
-        const int c = bc / bpc, f = (bc - c * bpc) * 64 + lane;
-        code[b] = a.R[c * a.r_chan_stride + t * a.FS + f];
-    }
-    unsigned x[16];
-#pragma unroll
-    for (int b = 0; b < 16; ++b)
-        x[b] = ((b < n_bits ? code[b] - kRankCodeBase : 0u) & 0xffffu) | ((b + 16 < n_bits ? code[b + 16] - kRankCodeBase : 0u) << 16);
-    plane_transpose_stage<8>(x); plane_transpose_stage<4>(x); plane_transpose_stage<2>(x); plane_transpose_stage<1>(x);
-    unsigned* out = a.P + t * (int64_t)a.n_planes * 64 + lane;
-#pragma unroll
-    for (int p = 0; p < 15; ++p)
-        if (p < a.n_planes) out[p * 64] = x[p];
-}
-
 // codes[c * n_cols + f][pitch] (column-major, as the sort leaves them) -> P[t][plane][64] without the detour over R (the
 // bit-sliced selection reads the planes only): a workgroup of 1 024 threads takes 64 frames and the 32 cells 64 b + l of 32
 // values of l -- 1 024 columns, 128 bytes of each, through LDS (column pitch 66 codes: lanes on adjacent l read adjacent
@@ -418,7 +394,7 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(columns_from_rows_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
                        dim3(256), 0, s, a);
     hipLaunchKernelGGL(rank_columns_kernel<LOG2N>, dim3((unsigned)cols), dim3(N / 32), lds, s, a);
-    if (a.P && !a.R) {                   // the bit-sliced selection reads the planes only
+    if (a.P) {                           // the bit-sliced selection reads the planes only: no frame-major codes
         constexpr int plane_lds_bytes = 1024 * kPlaneColPitch * 2;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(&code_planes_from_columns_kernel), plane_lds_bytes);
         if (e != hipSuccess) return e;
@@ -427,13 +403,13 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(rows_from_code_columns_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 128), (unsigned)(a.n_cols / 128), (unsigned)a.n_channels),
                        dim3(256), 0, s, a);
-    if (a.P) hipLaunchKernelGGL(code_planes_kernel, dim3((unsigned)ceil_div(a.T, 4)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_rank_columns(const RankArgs& a0, hipStream_t s) {
     if (!rank_columns_supported(a0.T) || a0.n_cols <= 0 || (a0.n_cols & 127) || (a0.vs_pitch & 31) || (a0.FS & 1)) return hipErrorInvalidValue;
-    if (a0.P && (a0.n_planes != code_planes_for(a0.T) || a0.n_planes > 15 || a0.n_channels * (a0.n_cols >> 6) > 32)) return hipErrorInvalidValue;
+    if (a0.P && (a0.R || a0.n_planes != code_planes_for(a0.T) || a0.n_planes > 15 || a0.n_channels * (a0.n_cols >> 6) > 32)) return hipErrorInvalidValue;
+    if (!a0.P && !a0.R) return hipErrorInvalidValue;
     RankArgs a = a0;
     if (a.T <= 2048) return launch_rank_n<11>(a, s);
     if (a.T <= 4096) return launch_rank_n<12>(a, s);

@@ -27,7 +27,7 @@ KERNELS = [
     ("rows_from_code_columns_kernel", "rank_columns", 1, "4 B/lane"),
     ("mask_sim_bits_kernel", "mask_sim_select", 1, "4 B/lane gathers of plane rows"),
     ("mask_from_codes_kernel", "mask_sim", 1, "8-16 B/lane streams beside 4-byte table reads: uncalibrated"),
-    ("code_planes_kernel", "rank_columns", 1, "2 B/lane"),
+    ("code_planes_from_columns_kernel", "rank_columns", 2, "16 B/lane"),
     ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("mask_sim_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("istft_ola_reg_kernel", "istft_ola", 2, "16 B/lane spectrum loads"), ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
