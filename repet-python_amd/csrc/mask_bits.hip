@@ -13,19 +13,20 @@
 // 3.9 instructions per entry and plane. np.median of an even list needs the entry of rank + 1 too: it walks the same path
 // until the plane where exactly rank + 1 zeros are left (the lower median is the largest of them, the upper one the
 // smallest of the ones); from there on it is the MINIMUM of its set, which needs "is any zero left" (an OR) instead of a
-// count: 2.5 instructions per entry and plane. About 11 000 wave instructions per frame (13 planes, 100 entries, both
+// count: 2.5 instructions per entry and plane. About 9 400 wave instructions per frame (13 planes, 100 entries, both
 // channels) against 26 800 of the slower class, and 13 gathered bits per value instead of 16.
 //
 // One workgroup of four waves per frame: each wave owns a quarter of the list (its alive words stay in registers: 2 x 25
-// and the planes of this step, about 110 VGPRs -- four waves per SIMD, which the fast VALU class needs to reach its rate:
-// tools/microbench/issue_rate.hip), counts ITS zeros, and the partial counts meet in LDS once per plane, where wave 0 adds
-// them up and decides for all four. Afterwards wave w turns the two code images back into numbers for the cells of bits
+// and the planes of this step, 117 VGPRs -- four waves per SIMD, which the fast VALU class needs to reach its rate:
+// tools/microbench/issue_rate.hip), counts ITS zeros, and the partial counts meet in LDS once per plane, where one wave (the
+// `lead`, a different one from workgroup to workgroup) adds them up and decides for all four. Afterwards wave w turns the two code images back into numbers for the cells of bits
 // [8 w, 8 w + 8) (a 16 x 16 bit transpose on both halves of the registers at once) and stores them, and a second kernel
 // (mask_from_codes_kernel, scheduled by blocks of columns) looks the magnitudes up in the sorted columns Vs and applies the
 // mask exactly as mask_sim_rank_kernel does: same codes, same table, same soft_mask -- the same bits
-// (tests/test_gpu_variants.py::test_median_paths_agree_bit_for_bit). What bounds it (tools/microbench/bitslice_select.hip):
-// the gathers -- 100 x 13 x 256 B per frame through the CU's 64 B/clk vector memory path -- rather than the ~9 400 wave
-// instructions.
+// (tests/test_gpu_variants.py::test_median_paths_agree_bit_for_bit, tests/test_gpu_stages.py::
+// test_median_selection_on_rank_codes_against_numpy). What bounds it (tools/microbench/bitslice_select.hip, gather_rate.hip):
+// the gathers -- 1 300 dword wave-loads per frame, of which a CU's vector memory path takes one every ~11 cycles whatever the
+// cache says -- rather than the wave instructions.
 #include "common.h"
 
 namespace repet {
