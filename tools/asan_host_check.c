@@ -177,6 +177,10 @@ static void check_context_calls(void) {
     CHECK(repet_ctx_destroy(NULL) == REPET_OK);
     CHECK(repet_online_close(NULL) == REPET_OK || repet_last_error()[0] != 0);
     CHECK(repet_ctx_create(0, NULL) != REPET_OK);
+    CHECK(repet_ctx_last_median_path(NULL, &n32) != REPET_OK);
+    CHECK(repet_ctx_last_median_codes(NULL, NULL, 1, 1) != REPET_OK);
+    CHECK(repet_ctx_download_input(NULL, fout, fout, &n32) != REPET_OK);
+    CHECK(repet_mask_sim_ranked(NULL, fout, 2000, 1025, &n32, &n32, 100, 2, fout, NULL) != REPET_OK);
 
     const int devices = repet_device_count();
     repet_ctx* ctx = NULL;
@@ -209,6 +213,23 @@ static void check_context_calls(void) {
         for (int64_t i = 0; i < 2 * n; ++i) energy += y[i] * y[i];
         CHECK(isfinite(energy) && energy > 0);
     }
+    /* sim once more: 1 562 frames take the rank transform and the bit-sliced median; its per-cell words come back */
+    CHECK(repet_ctx_execute(ctx, REPET_SIM, &p, NULL) == REPET_OK);
+    CHECK(repet_ctx_last_median_path(ctx, &n32) == REPET_OK && n32 == 2);
+    CHECK(repet_ctx_last_frame_count(ctx, &n64) == REPET_OK && n64 > 1024);
+    {
+        const int32_t bins = p.window_length / 2;
+        uint32_t* codes = (uint32_t*)malloc((size_t)2 * (size_t)n64 * (size_t)bins * sizeof(uint32_t));
+        CHECK(repet_ctx_last_median_codes(ctx, codes, n64, bins) == REPET_OK);
+        CHECK(repet_ctx_last_median_codes(ctx, codes, n64 + 1, bins) != REPET_OK);
+        CHECK(repet_ctx_last_median_codes(ctx, codes, n64, 100000) != REPET_OK);
+        uint32_t top = 0;
+        for (size_t i = 0; i < (size_t)2 * (size_t)n64 * (size_t)bins; ++i) top = (codes[i] & 0x7fffu) > top ? (codes[i] & 0x7fffu) : top;
+        CHECK(top > 0 && top < (uint32_t)n64);          /* ranks of a column of n64 frames */
+        free(codes);
+    }
+    CHECK(repet_mask_sim_ranked(ctx, fout, 100, 1025, &n32, &n32, 100, 2, fout, NULL) != REPET_OK);       /* too few frames */
+    CHECK(repet_mask_sim_ranked(ctx, fout, 2000, 1025, &n32, &n32, 100, 3, fout, NULL) != REPET_OK);      /* no such path */
     CHECK(repet_ctx_execute(ctx, 77, &p, NULL) != REPET_OK);
     CHECK(repet_ctx_execute(ctx, REPET_SIM, NULL, NULL) != REPET_OK);
     CHECK(repet_ctx_last_frame_count(ctx, &n64) == REPET_OK && n64 > 0);
