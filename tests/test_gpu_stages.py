@@ -261,10 +261,12 @@ def test_rank_columns_against_numpy(t, f):
     assert np.array_equal(np.take_along_axis(ordered, codes.astype(np.int64) - 0x0400, axis=1), v[:n])
 
 
-@pytest.mark.parametrize("t,f,longest", [(1400, 1025, 100), (2100, 513, 100), (1100, 2049, 100), (4200, 257, 128), (8200, 129, 37)])
+@pytest.mark.parametrize("t,f,longest", [(1400, 1025, 100), (2100, 513, 100), (1100, 2049, 100), (4200, 257, 128), (8200, 129, 37),
+                                         (1025, 129, 100), (2048, 129, 64), (2049, 129, 100), (16385, 129, 101), (30720, 129, 25)])
 def test_median_selection_on_rank_codes_against_numpy(t, f, longest):
     """The two rank-domain forms of sim's median (mask.hip: the packed 16-bit network; mask_bits.hip: the bit-sliced radix
-    descent, lists of up to 100 and up to 128 entries, 11 to 14 code planes, 2 to 32 blocks of 64 bins) against NumPy, on
+    descent, lists of up to 100 and up to 128 entries, 11 to 15 code planes -- frame counts either side of a power of two --, 2 to
+    32 blocks of 64 bins) against NumPy, on
     random magnitudes with ties and zeros and lists of every length from 0 to the longest, odd and even:
       * the INTEGERS the bit-sliced selection leaves -- rank of the lower median, rank of the upper one, "the lower median
         is below the frame's own value" -- are exactly what sorting the list's ranks gives;
