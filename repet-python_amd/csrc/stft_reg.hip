@@ -321,7 +321,9 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
                 const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
                 const float2 x = cadd(e, cmul(split_lds[k], o));
                 const float mag = magnitude(x);
-                Xrow[k] = x;
+                // non-temporal: the spectrum is read again only after the similarity / period stages -- stored the ordinary way it
+                // pushes the magnitudes and unit rows those stages read next out of the caches (1-2 % of every variant's step)
+                { typedef float f2 __attribute__((ext_vector_type(2))); f2 y; y.x = x.x; y.y = x.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + k)); }
                 Vrow[k] = mag;
                 acc[s] += mag;
                 if ((s & (REPET_FWD_SPLIT_BATCH - 1)) == REPET_FWD_SPLIT_BATCH - 1) __builtin_amdgcn_sched_barrier(0);    // a few bins in flight, not sixteen
