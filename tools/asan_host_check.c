@@ -4,7 +4,7 @@
  * UndefinedBehaviorSanitizer (device code untouched: -fno-gpu-sanitize) -- it drives every entry point of
  * include/repet_hip.h that does its work on the host: settings -> sizes, frame and segment counts, the network table,
  * the RIFF/WAVE header parser (well-formed files of every supported kind, then 200 000 truncated / mutated images),
- * and the argument checks of the context calls. Without a GPU the context calls must fail cleanly; with one, a 25-s
+ * and the argument checks of the context calls. Without a GPU the context calls must fail cleanly; with one, a 40-s
  * clip goes through upload -> execute -> download so that the orchestrator's host buffers are covered as well.
  * Any sanitizer report aborts the program (halt_on_error); a wrong answer returns non-zero. */
 #include "repet_hip.h"
@@ -193,8 +193,8 @@ static void check_context_calls(void) {
     }
     CHECK(rc == REPET_OK && ctx != NULL);
     if (rc != REPET_OK) return;
-    /* a 25-s two-channel clip through every variant: the orchestrator's host-side buffers under the sanitizers */
-    const int64_t n = 25 * 16000;
+    /* a 40-s two-channel clip through every variant: the orchestrator's host-side buffers under the sanitizers */
+    const int64_t n = 40 * 16000;
     double* x = (double*)malloc((size_t)n * 2 * sizeof(double));
     double* y = (double*)malloc((size_t)n * 2 * sizeof(double));
     for (int64_t i = 0; i < 2 * n; ++i) x[i] = sin(0.01 * (double)(i / 2) * (1 + (i & 1))) * 0.3 + ((double)(rnd() % 2001) - 1000.0) * 1e-6;
@@ -213,7 +213,7 @@ static void check_context_calls(void) {
         for (int64_t i = 0; i < 2 * n; ++i) energy += y[i] * y[i];
         CHECK(isfinite(energy) && energy > 0);
     }
-    /* sim once more: 1 562 frames take the rank transform and the bit-sliced median; its per-cell words come back */
+    /* sim once more: 1 251 frames take the rank transform and the bit-sliced median; its per-cell words come back */
     CHECK(repet_ctx_execute(ctx, REPET_SIM, &p, NULL) == REPET_OK);
     CHECK(repet_ctx_last_median_path(ctx, &n32) == REPET_OK && n32 == 2);
     CHECK(repet_ctx_last_frame_count(ctx, &n64) == REPET_OK && n64 > 1024);
@@ -236,7 +236,7 @@ static void check_context_calls(void) {
     free(x);
     free(y);
     CHECK(repet_ctx_destroy(ctx) == REPET_OK);
-    printf("GPU present: five variants on a 25-s clip through the sanitized host code\n");
+    printf("GPU present: five variants on a 40-s clip through the sanitized host code\n");
     gpu_used = 1;
 }
 
