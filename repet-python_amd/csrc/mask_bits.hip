@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
         off[k] = __builtin_amdgcn_readlane(off_v, k);
         A1[k] = (w * H + k < n) ? ~0u : 0u;
         A2[k] = A1[k];
-        B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + (NP - 1) * (kRowWords * 4), off[k], 0);
+        B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + (NP - 1) * (kRowWords * 4) + off[k], 0, 0);
     }
     // the leader's state: the rank still wanted among the entries in the running, D = cells whose upper median has
     // left the lower one's path. An odd list has ONE middle entry: the two never part.
@@ -177,13 +177,15 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
         }
         __syncthreads();
         const unsigned s1 = dec[0][lane], s2 = dec[1][lane];
-        // the plane's offset travels in the lanes' offset, the entry's row in the scalar one (no scalar add per load)
+        // The entry's row offset is ADDED to the lanes' offset (one v_add per load) rather than handed over as the load's scalar
+        // offset: with a scalar offset operand the CU takes a dword wave-load every 11.4 cycles, without one every 8.4
+        // (tools/microbench/gather_rate.hip) -- 0.206 -> 0.190 ms.
         const int next = lane * 4 + (p > 0 ? p - 1 : 0) * (kRowWords * 4);     // (the last round reads plane 0 again rather than branching)
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             A1[k] = bs_keep(A1[k], B[k], s1);
             A2[k] = bs_keep(A2[k], B[k], s2);
-            B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, next, off[k], 0);
+            B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, next + off[k], 0, 0);
         }
     }
     // ---- the two code images back into numbers: wave w for the cells of bits [8 w, 8 w + 8) ----

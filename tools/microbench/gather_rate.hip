@@ -8,6 +8,23 @@
 #include <vector>
 #include <random>
 
+// the same dword rows with the row offset ADDED INTO the lanes' offset (one v_add per load) instead of the scalar offset operand
+__global__ __launch_bounds__(256) void kv(const unsigned* table, const int* rows, int n_rows_list, int iters, unsigned* out, int table_bytes) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(table), 0, table_bytes, 0x00020000);
+    unsigned acc = 0;
+    const int* mine = rows + (wave * 25) % (n_rows_list - 25 * 16);
+    for (int it = 0; it < iters; ++it) {
+        int off[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) off[i] = __builtin_amdgcn_readfirstlane(mine[(it & 15) * 25 + i]);
+#pragma unroll
+        for (int i = 0; i < 25; ++i) acc ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + off[i], 0, 0);
+    }
+    out[wave * 64 + lane] = acc;
+}
+
 template <int WORDS>
 __global__ __launch_bounds__(256) void k(const unsigned* table, const int* rows, int n_rows_list, int iters, unsigned* out, int table_bytes) {
     const int lane = threadIdx.x & 63;
@@ -58,6 +75,19 @@ void run_global(const unsigned* table, const int* rows, int n_list, unsigned* ou
     printf("%-8s global_load_dword  %d waves/SIMD: %7.3f ms  %6.1f B/clk/CU  %5.2f TB/s\n", what, waves_per_simd, ms, bytes / 256 / (ms * 1e-3 * 2.4e9), bytes / ms / 1e9);
 }
 
+void run_voff(const unsigned* table, const int* rows, int n_list, unsigned* out, int table_bytes, int waves_per_simd, const char* what) {
+    const int iters = 400, blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kv, dim3(blocks), dim3(256), 0, 0, table, rows, n_list, 4, out, table_bytes);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kv, dim3(blocks), dim3(256), 0, 0, table, rows, n_list, iters, out, table_bytes);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)blocks * 4 * iters * 25 * 256;
+    printf("%-8s buffer_load_dword, row in the lane offset  %d waves/SIMD: %7.3f ms  %6.1f B/clk/CU  %5.2f TB/s\n", what, waves_per_simd, ms, bytes / 256 / (ms * 1e-3 * 2.4e9), bytes / ms / 1e9);
+}
+
 template <int WORDS> void run(const unsigned* table, const int* rows, int n_list, unsigned* out, int table_bytes, int waves_per_simd, const char* what) {
     const int iters = 400, blocks = 256 * waves_per_simd;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -87,6 +117,7 @@ int main() {
             run<2>(table, d_rows, n_list, out, table_bytes, w, local ? "window" : "table");
             run<4>(table, d_rows, n_list, out, table_bytes, w, local ? "window" : "table");
             run_global(table, d_rows, n_list, out, w, local ? "window" : "table");
+            run_voff(table, d_rows, n_list, out, table_bytes, w, local ? "window" : "table");
         }
         hipFree(d_rows);
     }
