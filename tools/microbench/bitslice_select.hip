@@ -9,7 +9,8 @@
 // wave adding all partial counts itself (one barrier per plane) 0.236 against 0.217 with a leader; the next plane's loads
 // prefetched into a second register set 0.246 against 0.202 (a wave per SIMD less); planes in groups of four behind
 // buffer_load_dwordx4 0.28 (two waves per SIMD). What bounds all of them: gather_rate.hip -- the CU takes one dword wave-load
-// per ~11 cycles whatever the cache says, and a frame needs 1 300 of them.
+// per 11.4 cycles whatever the cache says when the row comes as the load's scalar offset, per 8.4 when it is added into the
+// lanes' offset (0.218 -> 0.20 here), and a frame needs 1 300 of them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void select_kernel(const unsigned* __restrict_
         off[k] = __builtin_amdgcn_readlane(off_v, k);
         A1[k] = (w * kH + k < n) ? ~0u : 0u;
         A2[k] = A1[k];
-        B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + (NP - 1) * (kRowWords * 4), off[k], 0);
+        B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + (NP - 1) * (kRowWords * 4) + off[k], 0, 0);
     }
     unsigned r1[kR], D = 0u;
     const unsigned even = (n & 1) ? 0u : ~0u;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void select_kernel(const unsigned* __restrict_
 #endif
         const int next = lane * 4 + (p > 0 ? p - 1 : 0) * (kRowWords * 4);
 #pragma unroll
-        for (int k = 0; k < kH; ++k) B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, next, off[k], 0);
+        for (int k = 0; k < kH; ++k) B[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, next + off[k], 0, 0);      // (the row in the lane offset: gather_rate.hip)
         ST(5)                                   // issue of the next plane's loads
     }
 #ifdef STAMPS
