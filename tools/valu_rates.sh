@@ -8,7 +8,7 @@ set -u
 cd "$GRAFT_REPO_ROOT/tools/microbench"
 out="$GRAFT_REPO_ROOT/gpurun_out/valu_rate.txt"
 mkdir -p "$GRAFT_REPO_ROOT/gpurun_out"
-for t in clock_probe valu_rate cex_rate issue_rate gather_rate; do
+for t in clock_probe valu_rate cex_rate issue_rate gather_rate scatter_rate; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $t.hip -o /tmp/$t 2>/dev/null || { echo "build of $t failed"; exit 1; }
 done
 {
@@ -17,5 +17,6 @@ done
   echo; echo "# cex_rate: compare-exchange forms, the packed 16-bit classes, the three-input boolean forms"; /tmp/cex_rate
   echo; echo "# issue_rate: v_bitop3_b32 by waves per SIMD and independent chains per lane"; /tmp/issue_rate
   echo; echo "# gather_rate: whole rows through a buffer resource, 25 per round, by load width and waves per SIMD"; /tmp/gather_rate
+  echo; echo "# scatter_rate: a dword wave-load by the number of distinct 128-byte lines its lanes touch (L2-resident table)"; /tmp/scatter_rate
 } > "$out" 2>&1
 cat "$out"
