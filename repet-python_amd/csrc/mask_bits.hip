@@ -77,9 +77,13 @@ __global__ __launch_bounds__(256) void mask_sim_bits_kernel(MaskArgs a, const in
     __shared__ uint4 xch[4][2][64];                        // per wave and lane: the digits of its count, "one of my entries has a zero"
     __shared__ unsigned dec[2][64];                        // the leader's verdicts of this plane
     __shared__ unsigned lu[2][NP][64];                     // the code images of the lower and the upper median
+    // Workgroup b lands on XCD b % 8: every XCD takes ONE contiguous run of frames instead of every eighth frame (0.215 ->
+    // 0.204 ms in tools/microbench/bitslice_select.hip with the bench clip's lists; runs of frames sorted by their lists'
+    // earliest entry, so that the frames of one repetition share an L2, 0.195 -- less than the sort would cost)
     const int64_t t_end = a.frame_end > 0 ? a.frame_end : a.T;
-    const int64_t t = a.frame0 + blockIdx.x;
-    if (t >= t_end) return;
+    const int64_t per_xcd = (t_end - a.frame0 + 7) >> 3;
+    const int64_t t = a.frame0 + (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || t >= t_end) return;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = count[t];
     const int* list = idx + t * (int64_t)idx_pitch + w * H;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void mask_from_codes_kernel(MaskArgs a, const 
 template <int H>
 hipError_t launch_bits_h(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count, unsigned n_launch, int bpc_shift,
                          hipStream_t s) {
-#define REPET_BITS_CASE(NP) case NP: hipLaunchKernelGGL((mask_sim_bits_kernel<H, NP>), dim3(n_launch), dim3(256), 0, s, m, idx, idx_pitch, count, bpc_shift); break;
+#define REPET_BITS_CASE(NP) case NP: hipLaunchKernelGGL((mask_sim_bits_kernel<H, NP>), dim3(8 * ((n_launch + 7) / 8)), dim3(256), 0, s, m, idx, idx_pitch, count, bpc_shift); break;
     switch (m.n_planes) {
         REPET_BITS_CASE(11) REPET_BITS_CASE(12) REPET_BITS_CASE(13) REPET_BITS_CASE(14) REPET_BITS_CASE(15)
         default: return hipErrorInvalidValue;
