@@ -6,6 +6,13 @@ clip) of a clip that is already resident in HBM: STFT -> cosine self-similarity 
 median mask -> iSTFT, all on the engine's HIP stream (repet_ctx_execute). With N ranks every rank owns
 its own clip (seed = rank): independent units, no data-path collective, weak scaling.
 
+The other BASELINE configs keep the partitioning BASELINE.json states for them:
+  --config 3  repet.extended on ONE 600-s clip; with N ranks its 119 segments are split into N contiguous ranges, every
+              rank keeps only its range's samples resident, runs them, and the partial sums at the N-1 shard borders move to
+              their owners over RCCL point-to-point (repet/parallel.py ExtendedShard): total work fixed, "strong" scaling;
+              after the timed region the root gathers the result and compares it with its own single-GPU separation.
+  --config 5  repet.simonline on 64 30-s clips, 64/N per rank, batched through every stage: total work fixed, "strong".
+
     python bench.py                       # 1 GPU, finishes in a few minutes (incl. the CPU baseline)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -45,24 +52,25 @@ DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, f
               "simonline": "f32 (similarity band: f16x3 split of the fp32 unit rows, fp32 accumulate)"}
 
 
-def cpu_baseline(fs, channels, seconds):
+def cpu_baseline(fs, channels, seconds, algo="sim", n_clips=1):
     """Time the float64 NumPy oracle (CPU port of the reference) on a bounded sample of the workload."""
     import numpy as np
     from oracle import repet_oracle as orc
     from repet_synth import synth
-    x = synth(seconds, fs, channels, 0)
+    xs = [synth(seconds, fs, channels, k) for k in range(n_clips)]
     t0 = time.perf_counter()
-    orc.sim(x, fs)
+    for x in xs:
+        orc.ALGORITHMS[algo](x, fs)
     dt = time.perf_counter() - t0
     try:
         from threadpoolctl import threadpool_info
         blas = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:  # noqa: BLE001
         blas = os.cpu_count() or 1
-    return {"value": round(seconds / dt, 4), "unit": "audio-seconds/sec", "cores": int(blas), "kind": "port",
-            "sample": f"oracle.sim (NumPy float64 port of repet.py) on one {seconds:g}-s {fs} Hz {channels}-ch synth clip "
-                      f"(the bench workload itself when 180 s), {dt:.1f} s wall; single-threaded except the similarity "
-                      f"matmul ({blas} BLAS threads); host has {os.cpu_count()} logical cores"}
+    return {"value": round(seconds * n_clips / dt, 4), "unit": "audio-seconds/sec", "cores": int(blas), "kind": "port",
+            "sample": f"oracle.{algo} (NumPy float64 port of repet.py) on {n_clips} x {seconds:g}-s {fs} Hz {channels}-ch synth clip "
+                      f"(the bench workload itself when 180 s), {dt:.1f} s wall; single-threaded except the "
+                      f"matrix products ({blas} BLAS threads); host has {os.cpu_count()} logical cores"}
 
 
 def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, seconds, n_clips):
@@ -75,12 +83,15 @@ def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, second
     from repet import parallel
     from repet_synth import synth
     clips = [synth(seconds, fs, channels, seed=s) for s in range(n_clips)] if rank == 0 else None
+    shared_gpu = dist is not None and dist.get_backend() == "gloo"
+    timings = {}
 
     def one_round():
         if dist is None:                     # one process, one GPU: the root's own share is everything
             repet.set_device(local_rank)
             return [getattr(repet, algo)(c, fs) for c in clips]
-        return parallel.separate_clips(algo, clips, fs, device=local_rank)
+        timings.clear()
+        return parallel.separate_clips(algo, clips, fs, device=local_rank, stage_device=local_rank if shared_gpu else None, timings=timings)
 
     one_round()
     if dist is not None:
@@ -88,13 +99,26 @@ def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, second
     t0 = time.perf_counter()
     out = one_round()
     dt = time.perf_counter() - t0
+    per_rank = None
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {k: round(v, 2) if isinstance(v, float) else v for k, v in timings.items()})
     if rank != 0:
         return None
-    assert len(out) == n_clips and all(o.shape == c.shape and np.all(np.isfinite(o)) for o, c in zip(out, clips))
-    return {"value": round(seconds * n_clips / dt, 1), "unit": "audio-seconds/sec", "ms": round(dt * 1e3, 2), "clips": n_clips,
-            "note": f"{n_clips} x {seconds:g}-s clips in the root's host RAM (float64) -> scattered as fp32 over "
-                    f"{'RCCL point-to-point' if dist is not None else 'PCIe only (one GPU)'} -> repet.{algo} on {world} GPU(s) -> "
-                    "gathered back into the root's host RAM (float64); wall time on the root, second round"}
+    # every gathered clip against the root's OWN single-GPU separation of the same array: bit for bit (sim's float64 decisions
+    # travel with the remainder plane; the worker's device-resident ingest is the same fp32 samples the root would upload)
+    repet.set_device(local_rank)
+    differing = [i for i, (o, c) in enumerate(zip(out, clips)) if not (o.shape == c.shape and np.array_equal(o, getattr(repet, algo)(c, fs)))]
+    entry = {"value": round(seconds * n_clips / dt, 1), "unit": "audio-seconds/sec", "ms": round(dt * 1e3, 2), "clips": n_clips,
+             "verified": len(out) == n_clips and not differing,
+             "verified_how": "every gathered clip == the root's own single-GPU repet.%s of the same float64 array, bit for bit" % algo,
+             "per_rank": per_rank,
+             "note": f"{n_clips} x {seconds:g}-s clips in the root's host RAM (float64) -> scattered as fp32 (+ remainder planes) over "
+                     f"{('gloo, ranks sharing GPUs (dry run)' if shared_gpu else 'RCCL point-to-point') if dist is not None else 'PCIe only (one GPU)'} -> repet.{algo} on {world} rank(s) -> "
+                     "gathered back into the root's host RAM (float64); wall time on the root, second round"}
+    if differing:
+        entry["clips_that_differ"] = differing
+    return entry
 
 
 def main():
@@ -133,7 +157,7 @@ def main():
         import subprocess
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (os.environ.get("REPET_BENCH_BACKEND") == "gloo" and have >= 1):
             raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s)")
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
@@ -175,6 +199,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the REPET engine has no CPU fallback")
+    # REPET_BENCH_BACKEND=gloo (test switch): the N ranks talk over gloo and may SHARE GPUs (rank r on device r mod visible),
+    # so that the multi-rank partitionings, the border exchange and the verification run on a one-GPU box. The line says so
+    # ("backend": "gloo", "ranks_share_gpus": true) and is not a scaling measurement.
+    backend = os.environ.get("REPET_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("REPET_BENCH_BACKEND must be nccl or gloo")
+    visible = torch.cuda.device_count()
+    ranks_share_gpus = backend == "gloo" and visible < world
+    if ranks_share_gpus:
+        local_rank = local_rank % visible
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or (os.environ.get("REPET_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ):   # the switch: 1-rank check of the RCCL path
@@ -182,19 +216,36 @@ def main():
             os.environ["NCCL_DEBUG"] = "WARN"        # RCCL prints its version banner on stdout: keep stdout to the one JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")    # ... and its warnings (topology, iommu) on stderr
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"RCCL communicator of {dist.get_world_size()} rank(s) for --gpus {args.gpus}")
+            raise SystemExit(f"{backend} communicator of {dist.get_world_size()} rank(s) for --gpus {args.gpus}")
 
     fs, channels = args.fs, args.channels
     params = repet.derive_params(fs)
     ctxs = []
     batched = args.clips > 1 and args.algo == "simonline" and not args.no_batch       # equal-shape clips: every stage once over all of them
     clips = []
-    for k in range(args.clips):           # inputs resident in HBM (fp32, interleaved) before timing starts
+    # config 3 on N > 1 ranks: ONE clip, its segments in N contiguous ranges (BASELINE.json configs[2]); total work is fixed
+    sharded = args.config == 3 and world > 1
+    strong = sharded or (args.config == 5 and world > 1)
+    shard = None
+    if sharded:
+        from repet import parallel
+        clip = synth(args.duration, fs, channels, seed=0)          # every rank synthesises the clip and keeps only its window
+        _, _, windows_ = parallel.ExtendedShard.plan(len(clip), params.seg_len_samples, params.seg_step_samples, world)
+        lo_, hi_ = windows_[rank]
+        shard = parallel.ExtendedShard(clip[lo_:hi_] if hi_ > lo_ else None, fs, len(clip), channels, device=local_rank)
+        clips = [clip]
+        args.clips = 1
+    for k in range(args.clips if not sharded else 0):           # inputs resident in HBM (fp32, interleaved) before timing starts
         clip = example_clip if example_clip is not None else synth(args.duration, fs, channels, seed=rank * args.clips + k)
         clips.append(clip)
-    if batched:
+    if sharded:
+        pass
+    elif batched:
         ctx = repet.Context(local_rank)
         ctx.upload_batch(np.stack(clips))
         ctxs.append(ctx)
@@ -219,10 +270,16 @@ def main():
         for _ in range(4):
             barrier()
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+    if sharded:
+        # (the pre-warm's length must not depend on a rank's own clock: the border exchange pairs the ranks' steps one to one)
+        n_pre = max(1, int(args.prewarm_ms / 1.2))
+        for _ in range(n_pre + args.warmup):
+            shard.step()
+        shard.synchronize()
+    while not sharded and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
         for ctx in ctxs:
             ctx.execute(args.algo, params)
-    for _ in range(args.warmup):
+    for _ in range(args.warmup if not sharded else 0):
         for ctx in ctxs:
             ctx.execute(args.algo, params)
     # The K steps are enqueued back to back on the context's stream, as a job that separates one clip after another would:
@@ -230,6 +287,7 @@ def main():
     # Every step still records its own per-stage HIP events on that stream (timing series): the stage times below are
     # the means over exactly the K steps of the series that is reported.
     series = len(ctxs) == 1 and not args.sync_steps and 1 <= args.steps <= 4096      # (the series holds 17 events per step)
+    per_rank_ms = []
 
     def timed_region():
         """Exactly K steps between two barriers; returns (elapsed seconds, per-stage totals, per-stage metadata)."""
@@ -239,7 +297,9 @@ def main():
         if series:
             ctxs[0].timing_series_begin(args.steps)
         for _ in range(args.steps):
-            if series:
+            if sharded:
+                shard.step()                     # this rank's segments + the border exchange, enqueued; nothing waits on the host
+            elif series:
                 ctxs[0].execute_async(args.algo, params)
             elif len(ctxs) == 1:
                 tm = ctxs[0].execute(args.algo, params, timing=True)     # blocks until the stream is idle
@@ -253,6 +313,9 @@ def main():
                     ctx.synchronize()
         if series:
             ctxs[0].synchronize()
+        if sharded:
+            shard.synchronize()
+        own = time.perf_counter() - t0           # this rank's own K steps (before the closing barrier)
         barrier()
         dt = time.perf_counter() - t0
         if series:
@@ -261,29 +324,67 @@ def main():
             for s in tm["stages"]:
                 st_ms[s["name"]] = s["ms"] * args.steps
                 st_meta[s["name"]] = s
-        if dist is not None:                        # the slowest rank's time
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if dist is not None:                        # the slowest rank's time; every rank's own time beside it
+            t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            each = [None] * world
+            dist.all_gather_object(each, round(own / max(args.steps, 1) * 1e3, 4))
+            per_rank_ms.append(each)
         return dt, st_ms, st_meta
 
     regions = [timed_region() for _ in range(max(args.series, 1))]
     all_elapsed = [r[0] for r in regions]
-    elapsed, stage_ms, stage_meta = sorted(regions, key=lambda r: r[0])[(len(regions) - 1) // 2]      # the median series
+    median_at = sorted(range(len(regions)), key=lambda i: regions[i][0])[(len(regions) - 1) // 2]
+    elapsed, stage_ms, stage_meta = regions[median_at]                                               # the median series
     if len(ctxs) > 1:                           # per-stage device times of one clip, outside the timed region
         for _ in range(args.steps):
             tm = ctxs[0].execute(args.algo, params, timing=True)
             for s in tm["stages"]:
                 stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
                 stage_meta[s["name"]] = s
-    out = ctxs[-1].download()
-    assert out.shape[-2:] == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
+    verified = None
+    if sharded:
+        # per-stage device times of rank 0's range (outside the timed region; what the steps add on top is the border exchange)
+        if shard.ctx is not None and rank == 0:
+            for _ in range(args.steps):
+                tm = shard.ctx.execute_extended_range(params, shard.first, shard.count, timing=True)
+                for s in tm["stages"]:
+                    stage_ms[s["name"]] = stage_ms.get(s["name"], 0.0) + s["ms"]
+                    stage_meta[s["name"]] = s
+        # the sharded result, gathered on the root, against the root's own single-GPU separation of the whole clip
+        shard.step()
+        got = shard.gather(0)
+        if rank == 0:
+            ref = repet.Context(local_rank)
+            ref.upload(clip)
+            ref.execute("extended", params)
+            want = ref.download()
+            ref.close()
+            worst = float(np.max(np.abs(got - want)))
+            verified = {"ok": bool(np.all(np.isfinite(got)) and worst <= 2e-6), "max_abs_difference": worst, "tolerance": 2e-6,
+                        "how": "all ranks' owned samples gathered on the root vs the root's own single-GPU repet.extended of the whole clip "
+                               "(a border sample is the fp32 sum of two ranks' rounded products where one GPU uses a fused multiply-add)"}
+        ctx = shard.ctx
+    else:
+        out = ctxs[-1].download()
+        assert out.shape[-2:] == clip.shape and np.all(np.isfinite(out)), "separation produced non-finite samples"
+        if dist is not None:
+            # every rank checks one of its own clips against a fresh single call on its device: bit for bit
+            probe = ctxs[-1]
+            one = out if out.ndim == 2 else out[-1]
+            repet.set_device(local_rank)
+            same = bool(np.array_equal(one, getattr(repet, args.algo)(clips[-1], fs)))
+            flags = [None] * world
+            dist.all_gather_object(flags, same)
+            verified = {"ok": all(flags), "per_rank": flags,
+                        "how": "the last resident clip of every rank == repet.%s of the same array on that rank's GPU, bit for bit" % args.algo}
     want_scatter = not args.no_scatter and args.config == 2 and example_clip is None
     line = None
 
     if rank == 0:
         steps = max(args.steps, 1)                   # stage figures are per clip
-        T, F, C = int(ctx.last_frame_count()), params.window_length // 2 + 1, channels
+        T, F, C = int(ctx.last_frame_count()) if ctx is not None else 0, params.window_length // 2 + 1, channels
         rank_path = any("rank_columns" in name for name in stage_ms)
         sim_like = args.algo in ("sim", "simonline")
         k_mean = net_size = net_instr = None
@@ -414,23 +515,34 @@ def main():
                 roof[extra] = dom[extra]
         line = {
             "metric": f"audio-seconds/sec (x real-time) for repet.{args.algo}, {fs / 1000:g} kHz {'stereo' if channels == 2 else str(channels) + '-ch'}",
-            "value": round(args.duration * args.clips * args.steps * world / elapsed, 2),
+            "value": round(args.duration * args.clips * args.steps * (1 if sharded else world) / elapsed, 2),
             "unit": "audio-seconds/sec",
-            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None and backend == "nccl" else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "series_ms_per_step": [round(e / max(args.steps, 1) * 1e3, 3) for e in all_elapsed],
             "ms_per_step_min": round(min(all_elapsed) / max(args.steps, 1) * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "backend": (backend if dist is not None else None), "ranks_share_gpus": bool(ranks_share_gpus),
+            "per_rank_ms_per_step": (per_rank_ms[median_at] if per_rank_ms else None),
             "dtype": DTYPE_NOTE.get(args.algo, "f32"), "data": "synthetic" if example_clip is None else "the reference's example clip (audio_file.wav, read in place)",
-            "config": {"workload": f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
-                                   f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM",
-                       "clips_per_step": world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
-                       "frames": int(ctx.last_frame_count()), "prewarm_ms": args.prewarm_ms,
-                       "series": f"{len(all_elapsed)} timed regions of {args.steps} steps; value and ms_per_step are the median region", "parallelism": f"clip-parallel x{world}, no collective" + (", clips batched through every stage" if batched else "")},
+            "config": {"workload": (f"repet.extended on ONE {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch synthetic clip, its {shard.n_segments} segments in {world} contiguous ranges "
+                                    f"(BASELINE.json configs[2]), every rank's window resident in HBM" if sharded else
+                                    f"repet.{args.algo} on {args.clips} x {args.duration:g}-s {fs / 1000:g} kHz {channels}-ch {'synthetic' if example_clip is None else 'example'} clip(s) per GPU "
+                                    f"(BASELINE.json configs[{args.config - 1}]), clips resident in HBM"),
+                       "clips_per_step": 1 if sharded else world * args.clips, "samples_per_clip": int(clip.shape[0]), "channels": channels,
+                       "frames": T, "prewarm_ms": args.prewarm_ms,
+                       "series": f"{len(all_elapsed)} timed regions of {args.steps} steps; value and ms_per_step are the median region",
+                       "parallelism": (f"segment ranges {shard.ranges} over {world} ranks; per step {len(shard.moves)} border exchange(s) of "
+                                       f"{[hi - lo for _, _, lo, hi in shard.moves][:1]} samples x {channels} ch fp32, point-to-point" if sharded else
+                                       f"clip-parallel x{world}, no collective" + (", clips batched through every stage" if batched else ""))},
             "roofline": roof,
             "stages": stages,
             "device_ms_per_step": round(sum(s["ms"] for s in stages), 4),
         }
+        if verified is not None:
+            line["verified"] = verified
+        if sharded:
+            line["stages_note"] = "stage times are rank 0's range alone (outside the timed region); ms_per_step minus their sum is the border exchange + enqueue"
         if sim_like:
             ex = ctxs[0].last_exact_stats()
             line["peak_picking_second_level"] = {
@@ -482,8 +594,11 @@ def main():
                                              "note": "REPET_GRAM=f32: v_mfma_f32_32x32x2_f32, exact fp32 k-ordered accumulation (gram.hip)"}
             except Exception as exc:  # noqa: BLE001 -- a variant figure must never cost the headline
                 line["fp32_gemm_variant"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fs, channels, args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline and example_clip is None:
+            # a bounded sample of the same workload: the whole clip for configs 2, 3 and 4 (10-30 s of host time each), 8 of the 64
+            # clips of config 5
+            sample_s = args.cpu_seconds if args.config == 2 else args.duration
+            line["cpu_baseline"] = cpu_baseline(fs, channels, min(sample_s, args.duration), args.algo, 8 if args.config == 5 else 1)
 
     # The multi-GPU data path (scatter -> separate -> gather over RCCL point-to-point) runs LAST and under a watchdog: the
     # headline above must reach stdout whatever that leg does on a node it has never run on. A time-out or an exception on
@@ -531,6 +646,12 @@ def main():
         sys.stdout.flush()
         sys.stdout.write("\n" + json.dumps(line) + "\n")    # the ONE line, on a line of its own whatever a library left unfinished
         sys.stdout.flush()
+        # a multi-rank result that does not equal the single-GPU one must not look like success
+        bad = [k for k in ("verified", "scatter_gather") if isinstance(line.get(k), dict) and
+               (line[k].get("ok") is False or line[k].get("verified") is False)]
+        if bad:
+            sys.stderr.write(f"[bench] verification failed: {bad}\n")
+            raise SystemExit(1)
 
 
 if __name__ == "__main__":

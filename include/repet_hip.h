@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REPET_ABI_VERSION 2
+#define REPET_ABI_VERSION 3
 
 typedef enum repet_status {
     REPET_OK = 0,
@@ -135,6 +135,18 @@ int repet_ctx_upload_device(repet_ctx* ctx, const float* dev_audio, int64_t n_sa
 int repet_ctx_upload_device_split(repet_ctx* ctx, const float* dev_audio, const float* dev_audio_lo, int64_t n_samples,
                                   int32_t n_channels, int32_t n_clips);
 int repet_ctx_download_device(repet_ctx* ctx, float* dev_out);
+/* (ABI 3) Borrowed views for a host that keeps the exchange on the device (one process per GPU, torch.distributed over
+ * RCCL: repet/parallel.py). The pointers stay valid until the next upload of this context (a larger clip may move the
+ * buffers); what a run writes into the result is ordered on the context's stream, which repet_ctx_stream hands out so that
+ * the host can enqueue its sends, receives and adds BEHIND the run instead of waiting for it on the CPU.
+ * repet_ctx_result_view : the fp32 result [n_clips][n_samples][n_channels] of the last run (what repet_ctx_download widens)
+ * repet_ctx_input_view  : the resident fp32 samples and, when a float64 upload left any, their fp32 remainders (else NULL)
+ * repet_ctx_download_from: n_values fp32 values from ANY device buffer of this context's device widened into a host float64
+ *                         array through the context's pinned ring (the gather side of a scatter: results received from peers) */
+int repet_ctx_stream(repet_ctx* ctx, void** hip_stream);
+int repet_ctx_result_view(repet_ctx* ctx, float** dev_out, int64_t* n_values /* nullable */);
+int repet_ctx_input_view(repet_ctx* ctx, float** dev_audio, float** dev_audio_lo /* nullable */, int64_t* n_values /* nullable */);
+int repet_ctx_download_from(repet_ctx* ctx, const float* dev_src, int64_t n_values, double* out);
 /* Declare the resident samples to be [sample0, sample0 + n_samples) of a clip of n_total samples, for
  * repet_ctx_execute_extended_range: a rank of a multi-GPU `extended` then holds (and returns) only the samples its own
  * segments cover -- (count + 1) segment steps instead of the whole clip (repet.py:306-414 touches nothing else).
@@ -200,6 +212,8 @@ int repet_ctx_spectrogram(repet_ctx* ctx, int which, int32_t window_length, floa
 int64_t repet_extended_segment_count(int64_t n_samples, const repet_params* p);
 int repet_ctx_execute_extended_range(repet_ctx* ctx, const repet_params* p, int64_t first, int64_t n_segments,
                                      repet_timing* timing /* nullable */);
+/* (ABI 3) The same enqueued on the context's stream without waiting for it (see repet_ctx_execute_async). */
+int repet_ctx_execute_extended_range_async(repet_ctx* ctx, const repet_params* p, int64_t first, int64_t n_segments);
 
 /* ---- one-shot drop-in: replaces repet.<algo>(audio_signal, fs) (repet.py:67,205,422,571,712) -- */
 /* Measurement aid (bench.py's roofline): the median of a list of at most list_bound values is a compare-exchange

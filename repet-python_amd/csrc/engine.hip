@@ -674,6 +674,9 @@ int repet_ctx_upload_device_split(repet_ctx* c, const float* dev_audio, const fl
     const int64_t count = n * ch * n_clips;
     HIP_TRY(c->audio.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
     HIP_TRY(c->out.ensure(std::max<size_t>((size_t)count * sizeof(float), 256)));
+    // a float64 host upload of this context may still have its remainder plane on the way into audio_lo (copy stream): what
+    // is written below must land after it, not under it
+    if (c->ring.lo_in_flight) HIP_TRY(hipStreamWaitEvent(c->stream, c->ring.lo_done, 0));
     // device -> device (peer memory works as well); the sources may be reused when this returns
     HIP_TRY(hipMemcpyAsync(c->audio.p, dev_audio, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     c->has_lo = false;
@@ -685,6 +688,7 @@ int repet_ctx_upload_device_split(repet_ctx* c, const float* dev_audio, const fl
         c->has_lo = true;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ring.lo_in_flight = false;              // (the stream waited for it above and is idle now)
     c->n_samples = n; c->n_channels = ch; c->n_clips = n_clips; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
     return REPET_OK;
@@ -701,6 +705,42 @@ int repet_ctx_download_device(repet_ctx* c, float* dev_out) {
     if (count == 0) return REPET_OK;
     HIP_TRY(hipMemcpyAsync(dev_out, c->out.p, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+int repet_ctx_stream(repet_ctx* c, void** hip_stream) {
+    if (!c || !hip_stream) return fail(REPET_ERR_BAD_ARG, "null argument");
+    *hip_stream = reinterpret_cast<void*>(c->stream);
+    return REPET_OK;
+}
+
+int repet_ctx_result_view(repet_ctx* c, float** dev_out, int64_t* n_values) {
+    if (!c || !dev_out) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    *dev_out = c->out.as<float>();
+    if (n_values) *n_values = c->n_samples * c->n_channels * c->n_clips;
+    return REPET_OK;
+}
+
+int repet_ctx_input_view(repet_ctx* c, float** dev_audio, float** dev_audio_lo, int64_t* n_values) {
+    if (!c || !dev_audio) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    DeviceGuard guard(c->device);
+    // the remainder plane of a float64 upload follows the samples on the copy stream: a reader on the context's stream
+    // (or behind an event recorded on it) finds both planes complete
+    if (c->has_lo && c->ring.lo_in_flight) HIP_TRY(hipStreamWaitEvent(c->stream, c->ring.lo_done, 0));
+    *dev_audio = c->audio.as<float>();
+    if (dev_audio_lo) *dev_audio_lo = c->has_lo ? c->audio_lo.as<float>() : nullptr;
+    if (n_values) *n_values = c->n_samples * c->n_channels * c->n_clips;
+    return REPET_OK;
+}
+
+int repet_ctx_download_from(repet_ctx* c, const float* dev_src, int64_t n_values, double* out) {
+    if (!c || (n_values > 0 && (!dev_src || !out))) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (n_values < 0) return fail(REPET_ERR_BAD_ARG, "negative count");
+    if (n_values == 0) return REPET_OK;
+    DeviceGuard guard(c->device);
+    HIP_TRY(staged_download(c->ring, dev_src, out, (size_t)n_values, c->stream));
     return REPET_OK;
 }
 
@@ -871,6 +911,19 @@ int repet_ctx_execute_extended_range(repet_ctx* c, const repet_params* p, int64_
     if (rc == REPET_OK) end_timing(c);
     c->timing = nullptr;
     return rc;
+}
+
+int repet_ctx_execute_extended_range_async(repet_ctx* c, const repet_params* p, int64_t first, int64_t n_seg) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    RP_TRY(check_params(p));
+    if (c->n_channels < 1) return fail(REPET_ERR_BAD_ARG, "no clip uploaded");
+    if (n_seg < 0) return fail(REPET_ERR_BAD_ARG, "negative segment count");
+    if (c->n_clips > 1) return fail(REPET_ERR_BAD_ARG, "segment ranges apply to a single resident clip, not to a batch context");
+    DeviceGuard guard(c->device);
+    c->timing = nullptr;
+    c->last_algo = REPET_EXTENDED;
+    c->last_n_periods = 0;
+    return exec_extended(c, p, first, n_seg);
 }
 
 int repet_ctx_download(repet_ctx* c, double* out) {

@@ -17,6 +17,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <chrono>
+#include <sched.h>
 #include <cstring>
 #include <cmath>
 #include <functional>
@@ -66,14 +68,28 @@ public:
     void finish(const std::function<void(int, int)>& fn) {
         fn(0, n_threads_);
         for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
-            if (spins < 20000) cpu_relax(); else std::this_thread::yield();
+            if (spin_ok_ && spins < 20000) cpu_relax(); else std::this_thread::yield();
         }
         fn_ = nullptr;
         job_mutex_.unlock();
     }
 
 private:
-    static void cpu_relax() { __builtin_ia32_pause(); }
+    static void cpu_relax() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    // CPUs this process may run on (its affinity mask / container quota as the scheduler reports it)
+    static int usable_cpus() {
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) return std::max(1, CPU_COUNT(&set));
+#endif
+        return std::max(1u, std::thread::hardware_concurrency());
+    }
     HostWorkers() {
         const char* e = getenv("REPET_HOST_THREADS");
         int n = e ? atoi(e) : 0;
@@ -84,16 +100,23 @@ private:
             n = hw >= 32 ? 8 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
         }
         n_threads_ = std::min(n, 32);
+        // more threads than CPUs (REPET_HOST_THREADS above a container's share): spinners would take the CPU from the thread
+        // that converts part 0 -- hand over through the condition variable then
+        spin_ok_ = n_threads_ <= usable_cpus();
         for (int k = 1; k < n_threads_; ++k) std::thread([this, k] { loop(k); }).detach();
     }
     void loop(int part) {
         unsigned seen = 0;
         for (;;) {
-            // the next job: spin for about 200 us (the gaps between the chunks of one copy), then sleep
-            bool have = false;
-            for (int spins = 0; spins < 40000; ++spins) {
-                if (generation_.load(std::memory_order_acquire) != seen) { have = true; break; }
-                cpu_relax();
+            // the next job: spin for about 200 us of WALL time (the gaps between the chunks of one copy), then sleep
+            bool have = generation_.load(std::memory_order_acquire) != seen;
+            if (!have && spin_ok_) {
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+                for (int spins = 0; !have; ++spins) {
+                    if (generation_.load(std::memory_order_acquire) != seen) { have = true; break; }
+                    if ((spins & 255) == 255 && std::chrono::steady_clock::now() >= until) break;
+                    cpu_relax();
+                }
             }
             if (!have) {
                 std::unique_lock<std::mutex> lk(m_);
@@ -108,6 +131,7 @@ private:
         }
     }
     int n_threads_ = 1;
+    bool spin_ok_ = true;
     std::mutex job_mutex_, m_;
     std::condition_variable cv_;
     const std::function<void(int, int)>* fn_ = nullptr;
@@ -117,7 +141,7 @@ private:
 
 // The conversion loops are compiled three times (baseline x86-64, AVX2, AVX-512) and picked at load time: at two doubles per
 // instruction the narrowing of a 127-MB clip was instruction-bound on the eight threads (1.7 ms for a copy that takes 1.15).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)
 #define REPET_HOST_CLONES
 #else
 #define REPET_HOST_CLONES __attribute__((target_clones("default", "avx2", "avx512f")))

@@ -353,6 +353,18 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        // A frame whose squares leave fp32's range at the bottom (every mean magnitude below 2^-40: ss underflows, or its
+        // reciprocal root overflows) is normalised from the row scaled by 2^90 -- wave-uniform and almost never taken; the
+        // float64 reference gives such a frame finite unit values, and so does magnitude() (common.h) for its bins.
+        float pre = 1.0f;
+        if (ss < 0x1p-80f) {
+            pre = 0x1p90f;
+            ss = 0.f;
+#pragma unroll
+            for (int s = 0; s < 17; ++s) if (s < 16 || lane == 0) ss += (acc[s] * pre) * (acc[s] * pre);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        }
         const float norm = sqrtf(ss);        // 0 for a silent frame: 0/0 = NaN like repet.py:1220
         // (the row times the correctly rounded reciprocal: seventeen IEEE divisions were 180 instructions per frame in a
         // kernel bound by instruction issue; a silent frame gives 0 * inf = NaN, as 0 / 0 did)
@@ -371,15 +383,16 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         for (int s = 0; s < 16; ++s) {
             const int k = lane + 64 * s;
             if (Vm) Vm[k] = acc[s];
-            if (Vn) Vn[k] = acc[s] * inv_norm;
-            if (Vh) store_split_f16_at(vh_lane + 128 * s, acc[s] * inv_norm);
+            const float unit = (acc[s] * pre) * inv_norm;
+            if (Vn) Vn[k] = unit;
+            if (Vh) store_split_f16_at(vh_lane + 128 * s, unit);
             if (P) P[k] = acc[s] * acc[s];
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (lane == 0) {
             if (Vm) Vm[N] = acc[16];
-            if (Vn) Vn[N] = acc[16] * inv_norm;
-            if (Vh) store_split_f16(Vh, row + N, acc[16] * inv_norm);
+            if (Vn) Vn[N] = (acc[16] * pre) * inv_norm;
+            if (Vh) store_split_f16(Vh, row + N, (acc[16] * pre) * inv_norm);
             if (P) P[N] = acc[16] * acc[16];
         }
         if (lane < a.FS - (N + 1)) {

@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPET_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "librepet_hip.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ORIGINAL, EXTENDED, ADAPTIVE, SIM, SIMONLINE = range(5)
 ALGO_IDS = {"original": ORIGINAL, "extended": EXTENDED, "adaptive": ADAPTIVE, "sim": SIM, "simonline": SIMONLINE}
 F32, F64, I16 = 0, 1, 2
@@ -73,6 +73,11 @@ _SIGNATURES = {
     "repet_last_batch_info": (C.c_int, [C.POINTER(C.c_int64)]),
     "repet_ctx_download_input": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32)]),
     "repet_ctx_set_window": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "repet_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "repet_ctx_result_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "repet_ctx_input_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "repet_ctx_download_from": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "repet_ctx_execute_extended_range_async": (C.c_int, [_P, C.POINTER(Params), C.c_int64, C.c_int64]),
     "repet_wav_parse": (C.c_int, [_P, C.c_int64, C.POINTER(WavInfo)]),
     "repet_ctx_upload_wav": (C.c_int, [_P, _P, C.c_int64, C.POINTER(WavInfo)]),
     "repet_ctx_result_wav": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -283,6 +288,36 @@ class Context:
         """The result as fp32 interleaved samples into device memory of at least ``prod(self.shape)`` floats."""
         check(lib().repet_ctx_download_device(self._h, C.c_void_p(int(data_ptr))))
 
+    def stream(self):
+        """The context's HIP stream as an integer handle (``torch.cuda.ExternalStream(ctx.stream())`` orders torch's
+        sends, receives and adds behind a run without a host wait)."""
+        h = C.c_void_p()
+        check(lib().repet_ctx_stream(self._h, C.byref(h)))
+        return int(h.value or 0)
+
+    def result_view(self):
+        """(device pointer, number of fp32 values) of the last run's result inside the context: borrowed, valid until the
+        next upload; writes to it are ordered on ``stream()``."""
+        ptr_, n = C.c_void_p(), C.c_int64()
+        check(lib().repet_ctx_result_view(self._h, C.byref(ptr_), C.byref(n)))
+        return int(ptr_.value or 0), int(n.value)
+
+    def input_view(self):
+        """(pointer to the resident fp32 samples, pointer to their fp32 remainders or None, number of values)."""
+        hi, lo, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(lib().repet_ctx_input_view(self._h, C.byref(hi), C.byref(lo), C.byref(n)))
+        return int(hi.value or 0), (int(lo.value) if lo.value else None), int(n.value)
+
+    def download_from(self, data_ptr, shape):
+        """fp32 values in device memory (e.g. a result received from a peer) widened into a fresh float64 host array through
+        the context's pinned ring."""
+        out = result_array(shape)
+        check(lib().repet_ctx_download_from(self._h, C.c_void_p(int(data_ptr)), int(np.prod(shape)), ptr(out)))
+        return out
+
+    def execute_extended_range_async(self, params, first, n_segments):
+        check(lib().repet_ctx_execute_extended_range_async(self._h, C.byref(params), int(first), int(n_segments)))
+
     def set_window(self, number_samples_total, first_sample):
         """The resident samples are ``[first_sample, first_sample + N)`` of a clip of ``number_samples_total`` samples
         (for ``execute_extended_range`` on a rank that holds only its own segments' samples)."""
@@ -333,8 +368,10 @@ class Context:
         d["steps"] = int(n.value)
         return d
 
-    def execute_extended_range(self, params, first, n_segments):
-        check(lib().repet_ctx_execute_extended_range(self._h, C.byref(params), int(first), int(n_segments), None))
+    def execute_extended_range(self, params, first, n_segments, timing=False):
+        t = Timing() if timing else None
+        check(lib().repet_ctx_execute_extended_range(self._h, C.byref(params), int(first), int(n_segments), C.byref(t) if timing else None))
+        return t.as_dict() if timing else None
 
     def download(self):
         out = result_array(self.shape)

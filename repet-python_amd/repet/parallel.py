@@ -74,11 +74,12 @@ def split_float64(x):
 _contexts = {}
 
 
-def _context(device):
+def _context(key):
+    """One engine context per device (``key`` = device index) and role (``key`` = (role, device index))."""
     import repet
-    ctx = _contexts.get(device)
+    ctx = _contexts.get(key)
     if ctx is None:
-        ctx = _contexts[device] = repet.Context(device)
+        ctx = _contexts[key] = repet.Context(key[1] if isinstance(key, tuple) else key)
     return ctx
 
 
@@ -133,6 +134,47 @@ def _engine_extended_range(device):
     return run
 
 
+# ---- device memory the engine owns, as tensors ----------------------------------------------------------------------
+class _DeviceSpan:
+    """Borrowed fp32 device memory behind ``__cuda_array_interface__`` (``torch.as_tensor`` wraps it without a copy)."""
+
+    def __init__(self, pointer, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(d) for d in shape), "typestr": "<f4", "data": (int(pointer), False),
+                                         "version": 2, "strides": None}
+
+
+def tensor_view(pointer, shape, device):
+    """fp32 tensor over ``prod(shape)`` floats at ``pointer`` on ``device`` (no copy, no ownership: the context that
+    owns the memory must outlive the tensor)."""
+    import torch
+    return torch.as_tensor(_DeviceSpan(pointer, shape), device=torch.device("cuda", device))
+
+
+def _accepts_remainders(fn):
+    """Whether ``fn(x, fs, remainders)`` can be called: a third positional parameter, ``*args`` or a ``remainders`` keyword."""
+    import inspect
+    try:
+        params = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return True
+    positional = [q for q in params if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)]
+    return len(positional) >= 3 or any(q.kind == q.VAR_POSITIONAL for q in params) or any(q.name == "remainders" for q in params)
+
+
+def _call_separate(fn, x, fs, lo):
+    """``fn`` on a received clip. A two-argument ``separate_fn`` (the documented signature before float64 clips travelled as
+    two planes) gets the planes folded back into one float64 waveform -- the same rebuild ``_engine_separate`` does for host
+    arrays -- instead of a TypeError on the worker ranks only."""
+    if lo is None:
+        return fn(x, fs)
+    if _accepts_remainders(fn):
+        return fn(x, fs, lo)
+    import torch
+    if isinstance(x, torch.Tensor):
+        return fn(x.double() + lo.double(), fs)
+    return fn(np.asarray(x, dtype=np.float64) + np.asarray(lo, dtype=np.float64), fs)
+
+
 # ---- transport ------------------------------------------------------------------------------------------------------
 def _wire(array, dtype, dev):
     """A host array as a tensor of the wire dtype on the communication device."""
@@ -144,19 +186,32 @@ def _host(t):
     return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
 
 
-def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=None, root=0, wire_dtype=np.float32):
+def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=None, root=0, wire_dtype=np.float32,
+                   stage_device=None, timings=None):
     """Collective over the default process group. ``clips`` (list of (N_i, C_i) float arrays) is read on
     ``root`` only; every rank separates its share; ``root`` returns the list of background signals (float64) in
     the original order, the other ranks return None. Samples travel as ``wire_dtype`` (fp32: what the engine computes
     in; a float64 clip whose fp32 remainders are not all zero sends them as a second plane and ``separate_fn`` is called
-    with them as a third argument); on the RCCL backend a worker rank's clips never leave the device."""
+    with them as a third argument -- or, when it takes two, with the planes folded back into one float64 waveform); on the
+    RCCL backend a worker rank's clips never leave the device, and the ROOT's side of the wire goes through the engine's
+    pinned ring (``repet_ctx_upload`` narrows and splits with the host worker threads, ``repet_ctx_download_from`` widens what
+    comes back) instead of through pageable NumPy copies. ``stage_device``: under gloo, move what a worker received onto that
+    GPU before calling the engine (the device-resident ingest of the RCCL path on a box whose ranks share one GPU).
+    ``timings``: a dict that receives this rank's wall times (``compute_ms``: its own separations, ``total_ms``)."""
+    import time
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = dist.get_backend() != "gloo"
     dev = torch.device("cuda", device if device is not None else rank) if on_gpu else torch.device("cpu")
-    fn = separate_fn or _engine_separate(algo, dev.index or 0)
+    stage = torch.device("cuda", stage_device) if (stage_device is not None and not on_gpu) else None
+    engine_device = dev.index or 0 if on_gpu else (stage_device if stage_device is not None else (device or 0))
+    fn = separate_fn or _engine_separate(algo, engine_device)
     tdtype = torch.float32 if np.dtype(wire_dtype) == np.float32 else torch.float64
+    t_start = time.perf_counter()
+    compute_s = 0.0
+    # the root's end of an fp32 RCCL wire: a staging context of the engine (pinned ring + host worker threads)
+    io = _context(("io", dev.index)) if (on_gpu and separate_fn is None and np.dtype(wire_dtype) == np.float32) else None
 
     shares_of = lambda shapes_: deal_clips([s[0] for s in shapes_], world)
     planes = {}
@@ -168,7 +223,7 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
             for r, ids in enumerate(shares_of(shapes)):
                 if r != root:
                     for i in ids:
-                        planes[i] = split_float64(clips[i])
+                        planes[i] = _split_on_device(io, clips[i], dev) if io is not None else split_float64(clips[i])
                         with_lo[i] = planes[i][1] is not None
         meta = [(shapes, with_lo)]
     dist.broadcast_object_list(meta, src=root)
@@ -182,14 +237,16 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
                 for i in ids:
                     if i in planes:
                         hi, lo = planes.pop(i)
-                        pending.append(dist.isend(_wire(hi, wire_dtype, dev), dst=r))
+                        pending.append(dist.isend(hi if isinstance(hi, torch.Tensor) else _wire(hi, wire_dtype, dev), dst=r))
                         if lo is not None:
-                            pending.append(dist.isend(_wire(lo, wire_dtype, dev), dst=r))
+                            pending.append(dist.isend(lo if isinstance(lo, torch.Tensor) else _wire(lo, wire_dtype, dev), dst=r))
                     else:
                         pending.append(dist.isend(_wire(clips[i], wire_dtype, dev), dst=r))
         out = [None] * len(shapes)
+        t_c = time.perf_counter()
         for i in shares[root]:
             out[i] = np.ascontiguousarray(_host(fn(np.asarray(clips[i]), sampling_frequency)), dtype=np.float64)
+        compute_s = time.perf_counter() - t_c
         for req in pending:
             req.wait()
         for r, ids in enumerate(shares):
@@ -197,7 +254,13 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
                 for i in ids:
                     t = torch.empty(shapes[i], dtype=tdtype, device=dev)
                     dist.recv(t, src=r)
-                    out[i] = _host(t).astype(np.float64)
+                    if io is not None:
+                        torch.cuda.current_stream(dev).synchronize()       # the receive has landed
+                        out[i] = io.download_from(t.data_ptr(), shapes[i])
+                    else:
+                        out[i] = _host(t).astype(np.float64)
+        if timings is not None:
+            timings.update(compute_ms=compute_s * 1e3, total_ms=(time.perf_counter() - t_start) * 1e3, clips=len(shares[root]))
         return out
 
     received = []
@@ -210,14 +273,35 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
             dist.recv(lo, src=root)
         received.append((t, lo))
     for t, lo in received:
-        if lo is None:
-            y = fn(t if on_gpu else t.numpy(), sampling_frequency)
-        else:
-            y = fn(t if on_gpu else t.numpy(), sampling_frequency, lo if on_gpu else lo.numpy())
+        if stage is not None:                                  # (gloo wire, engine on a GPU: the worker's device-resident path)
+            t, lo = t.to(stage), (lo.to(stage) if lo is not None else None)
+        as_arg = (lambda v: v) if (on_gpu or stage is not None) else (lambda v: v.numpy())
+        t_c = time.perf_counter()
+        y = _call_separate(fn, as_arg(t), sampling_frequency, as_arg(lo) if lo is not None else None)
+        compute_s += time.perf_counter() - t_c
+        if isinstance(y, torch.Tensor) and not on_gpu:
+            y = y.cpu()
         if not isinstance(y, torch.Tensor):
             y = _wire(y, wire_dtype, dev)
         dist.send(y.to(tdtype), dst=root)
+    if timings is not None:
+        timings.update(compute_ms=compute_s * 1e3, total_ms=(time.perf_counter() - t_start) * 1e3, clips=len(shares[rank]))
     return None
+
+
+def _split_on_device(io, clip, dev):
+    """(fp32 samples, fp32 remainders or None) of a host clip as device tensors, made by the engine's own upload (hostio.hip:
+    worker threads narrow into the pinned ring, the remainder plane follows on a copy stream) and copied out of the staging
+    context's buffers on its stream -- the next upload may overwrite them."""
+    import torch
+    io.upload(np.asarray(clip))
+    hi_ptr, lo_ptr, count = io.input_view()
+    shape = tuple(int(d) for d in np.shape(clip))
+    with torch.cuda.stream(torch.cuda.ExternalStream(io.stream(), device=dev)):
+        hi = tensor_view(hi_ptr, shape, dev.index).clone()
+        lo = tensor_view(lo_ptr, shape, dev.index).clone() if lo_ptr else None
+    io.synchronize()
+    return hi, lo
 
 
 def extended_sharded(audio_signal, sampling_frequency, segment_length, segment_step, range_fn=None, device=None, root=0,
@@ -286,3 +370,184 @@ def extended_sharded(audio_signal, sampling_frequency, segment_length, segment_s
             part = _wire(part, wire_dtype, dev)
         dist.send(part.to(tdtype), dst=root)
     return None
+
+
+# ---- `extended` with the clip RESIDENT across the GPUs ---------------------------------------------------------------
+def halo_plan(windows):
+    """Who owns which samples, and which partial sums have to move, when rank r holds the window ``windows[r] = (lo, hi)``
+    of its contiguous segment range: rank r OWNS ``[lo_r, lo_next)`` (``lo_next`` = the next non-empty window's start, the
+    clip's end for the last one); whatever its segments wrote beyond that belongs to later ranks and is sent to them.
+    Returns ``(owned, moves)``: ``owned[r] = (lo, hi)`` and ``moves = [(src, dst, lo, hi), ...]`` (absolute sample ranges,
+    ordered by destination, then source -- the order the destination adds them in). With the default 50 % overlap there is
+    exactly one move per shard border: one segment step from rank r to rank r + 1."""
+    live = [r for r, (lo, hi) in enumerate(windows) if hi > lo]
+    owned = [(0, 0)] * len(windows)
+    for k, r in enumerate(live):
+        lo, hi = windows[r]
+        owned[r] = (lo, windows[live[k + 1]][0] if k + 1 < len(live) else hi)
+    moves = []
+    for q in live:
+        for r in live:
+            if r >= q:
+                break
+            lo = max(owned[q][0], windows[r][0])
+            hi = min(owned[q][1], windows[r][1])
+            if hi > lo:
+                moves.append((r, q, lo, hi))
+    return owned, moves
+
+
+class ExtendedShard:
+    """This rank's share of ``repet.extended`` on ONE long clip that stays resident across the GPUs of the job (BASELINE
+    configs[2]: 10-min clip, 10-s segments sharded over 8 MI355X; repet.py:306-414).
+
+    Rank r keeps the samples its contiguous range of segments covers in its own HBM. ``step()`` enqueues -- on the engine's
+    stream, nothing waits on the host -- the rank's segments (``repet_ctx_execute_extended_range_async`` with the whole
+    clip's cross-fade weights) and then the only exchange the path has: at every shard border the earlier rank's partial sums
+    for the samples the later rank owns travel there (point-to-point over RCCL/xGMI; one segment step = 1.76 MB per border at
+    44.1 kHz stereo) and are added in place. Afterwards ``owned`` of every rank is final and the union is the clip.
+    ``gather(root)`` assembles it on the root (verification / the drop-in's return value), outside any timed region.
+
+    ``window`` is the rank's own window of the clip (host array, float32 or float64) or None for an empty range; use
+    ``ExtendedShard.plan`` to find it. Under gloo (ranks sharing a GPU, CPU wire) the same code runs with the wire bounced
+    through host memory."""
+
+    @staticmethod
+    def plan(number_samples, segment_length, segment_step, world):
+        n_segments, segments = extended_plan(number_samples, segment_length, segment_step)
+        ranges = segment_ranges(n_segments, world)
+        windows = [segment_window(segments, first, count) for first, count in ranges]
+        return n_segments, ranges, windows
+
+    def __init__(self, window, sampling_frequency, number_samples, channels, device=0, group=None, range_fn=None,
+                 segment_length=None, segment_step=None):
+        """``range_fn(window, fs, first, count, number_samples, first_sample) -> window's share`` replaces the HIP engine
+        (CPU tests of the plan and the exchange under gloo); ``segment_length`` / ``segment_step`` in samples default to the
+        module parameters (``repet.segment_length * fs``, repet.py:266-267)."""
+        import contextlib
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.on_gpu = dist.get_backend(group) != "gloo"
+        self.device = int(device)
+        self.fs = sampling_frequency
+        self.n, self.channels = int(number_samples), int(channels)
+        self.range_fn = range_fn
+        if range_fn is None:
+            import repet
+            self.params = repet.derive_params(sampling_frequency)
+            segment_length, segment_step = self.params.seg_len_samples, self.params.seg_step_samples
+        self.n_segments, self.ranges, self.windows = self.plan(self.n, segment_length, segment_step, self.world)
+        self.owned, self.moves = halo_plan(self.windows)
+        self.first, self.count = self.ranges[self.rank]
+        self.lo, self.hi = self.windows[self.rank]
+        self.ctx = None
+        self.view = None
+        self.inbox = {}
+        if self.hi <= self.lo:
+            return
+        if window is None or np.shape(window) != (self.hi - self.lo, self.channels):
+            raise ValueError(f"rank {self.rank} needs samples [{self.lo}, {self.hi}) of the clip as its window")
+        if range_fn is None:
+            import repet
+            self.ctx = repet.Context(self.device)
+            self.ctx.upload(np.asarray(window))
+            self.ctx.set_window(self.n, self.lo)
+            pointer, count = self.ctx.result_view()
+            assert count == (self.hi - self.lo) * self.channels
+            self.view = tensor_view(pointer, (self.hi - self.lo, self.channels), self.device)
+            self.stream = torch.cuda.ExternalStream(self.ctx.stream(), device=torch.device("cuda", self.device))
+            self.stream_scope = lambda: torch.cuda.stream(self.stream)
+        else:
+            self.host_window = np.array(window)
+            self.view = torch.zeros((self.hi - self.lo, self.channels), dtype=torch.float64)
+            self.stream_scope = contextlib.nullcontext
+        # receive buffers of the partial sums this rank is owed, one per incoming move (allocated once)
+        self.inbox = {(src, lo, hi): torch.empty((hi - lo, self.channels), dtype=self.view.dtype, device=self.view.device)
+                      for src, dst, lo, hi in self.moves if dst == self.rank}
+
+    def _piece(self, lo, hi):
+        return self.view[lo - self.lo:hi - self.lo]
+
+    def step(self):
+        """One pass: this rank's segments, then the border exchange. Returns at once (RCCL backend); ``synchronize()`` waits."""
+        import torch
+        if self.view is None:
+            return
+        dist = self.dist
+        with self.stream_scope():
+            if self.ctx is not None:
+                self.ctx.execute_extended_range_async(self.params, self.first, self.count)
+            else:
+                self.view.copy_(torch.from_numpy(np.asarray(self.range_fn(self.host_window, self.fs, self.first, self.count, self.n, self.lo),
+                                                            dtype=np.float64)))
+            mine = [m for m in self.moves if self.rank in (m[0], m[1])]
+            if not mine:
+                return
+            if self.on_gpu:
+                ops = []
+                for src, dst, lo, hi in mine:
+                    if src == self.rank:
+                        ops.append(dist.P2POp(dist.isend, self._piece(lo, hi), dst, self.group))
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, self.inbox[(src, lo, hi)], src, self.group))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()                                  # (orders the stream behind the transfer; no host wait)
+            else:
+                # gloo: CPU wire. Sends first (non-blocking), then the receives in the plan's order.
+                self.synchronize()
+                pending = [dist.isend(self._piece(lo, hi).cpu().contiguous(), dst, self.group) for src, dst, lo, hi in mine if src == self.rank]
+                for src, dst, lo, hi in mine:
+                    if dst == self.rank:
+                        box = torch.empty((hi - lo, self.channels), dtype=self.view.dtype)
+                        dist.recv(box, src, self.group)
+                        self.inbox[(src, lo, hi)].copy_(box)
+                for req in pending:
+                    req.wait()
+            for src, dst, lo, hi in mine:                       # the plan's order: the sums do not depend on arrival times
+                if dst == self.rank:
+                    self._piece(lo, hi).add_(self.inbox[(src, lo, hi)])
+
+    def synchronize(self):
+        if self.ctx is not None:
+            self.ctx.synchronize()
+
+    def owned_result(self):
+        """fp32 tensor (view) of the samples this rank owns, final after ``step()`` + ``synchronize()``."""
+        if self.view is None:
+            return None
+        lo, hi = self.owned[self.rank]
+        return self._piece(lo, hi)
+
+    def gather(self, root=0):
+        """The whole background on ``root`` as a float64 array (None elsewhere): every rank's owned samples, in place."""
+        import torch
+        dist = self.dist
+        self.synchronize()
+        mine = self.owned_result()
+        wire = (lambda t: t) if self.on_gpu else (lambda t: t.cpu())
+        if self.rank != root:
+            if mine is not None and mine.shape[0] > 0:
+                dist.send(wire(mine).contiguous(), root, self.group)
+            return None
+        out = np.zeros((self.n, self.channels), dtype=np.float64)
+        for r in range(self.world):
+            lo, hi = self.owned[r]
+            if hi <= lo:
+                continue
+            if r == root:
+                part = mine
+            else:
+                part = torch.empty((hi - lo, self.channels), dtype=self.view.dtype if self.view is not None else torch.float32,
+                                   device=self.view.device if (self.on_gpu and self.view is not None) else "cpu")
+                dist.recv(part, r, self.group)
+            out[lo:hi] = part.cpu().numpy()
+        return out
+
+    def close(self):
+        self.view = None
+        self.inbox = {}
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None

@@ -109,6 +109,81 @@ def _case_extended(rank, world):
     return out if rank == 0 else None
 
 
+def _two_argument_original(x, fs):
+    """The documented two-argument ``separate_fn``: must keep working when float64 clips travel as two planes."""
+    return orc.original(np.asarray(x, dtype=np.float64), fs)
+
+
+def _case_two_argument_fn(rank, world):
+    clips = _clips() if rank == 0 else None
+    timings = {}
+    got = parallel.separate_clips("original", clips, FS, separate_fn=_two_argument_original, wire_dtype=np.float32, timings=timings)
+    assert timings["clips"] >= 2 and timings["total_ms"] >= timings["compute_ms"] > 0
+    return {f"clip{i}": y for i, y in enumerate(got)} if rank == 0 else None
+
+
+def _case_resident_extended(rank, world):
+    """ExtendedShard under gloo with the oracle as the engine: every rank holds its window, runs its segments, the borders'
+    partial sums move to their owners, the root gathers the owned samples."""
+    out = {}
+    x = synth(27.0, FS, 2, 31)                       # (every rank synthesises the clip: its window is resident from the start)
+    for name, (length, step) in (("default", (10, 5)), ("short_step", (8, 2)), ("gaps", (10, 7.5))):
+        p = orc.Params(segment_length=length, segment_step=step)
+        fn = lambda w, fs, first, count, n, s0, p=p: _window_range(w, fs, first, count, n, s0, p)
+        n_seg, ranges, windows = parallel.ExtendedShard.plan(len(x), round(length * FS), round(step * FS), world)
+        lo, hi = windows[rank]
+        shard = parallel.ExtendedShard(x[lo:hi] if hi > lo else None, FS, len(x), 2, range_fn=fn,
+                                       segment_length=round(length * FS), segment_step=round(step * FS))
+        for _ in range(2):                            # a second step must not add the borders twice
+            shard.step()
+        got = shard.gather(0)
+        if rank == 0:
+            out[name] = got
+        shard.close()
+    return out if rank == 0 else None
+
+
+def test_halo_plan_owners_and_moves():
+    """Every sample has exactly one owner; a move carries what an earlier rank's segments wrote into a later rank's samples."""
+    n_seg, ranges, windows = parallel.ExtendedShard.plan(26460000, 441000, 220500, 8)         # cfg 3 on 8 GPUs
+    owned, moves = parallel.halo_plan(windows)
+    assert n_seg == 119 and owned[0] == (0, 15 * 220500) and owned[7] == (105 * 220500, 26460000)
+    assert [hi - lo for lo, hi in owned[:7]] == [15 * 220500] * 7
+    assert moves == [(r, r + 1, (15 * (r + 1)) * 220500, (15 * (r + 1) + 1) * 220500) for r in range(7)]   # one step per border
+    # more ranks than segments: the empty ranks own nothing and move nothing
+    n_seg, ranges, windows = parallel.ExtendedShard.plan(27 * FS, 10 * FS, 5 * FS, 6)
+    owned, moves = parallel.halo_plan(windows)
+    assert n_seg == 4 and windows[4] == (0, 0) and owned[4] == (0, 0) and owned[3][1] == 27 * FS
+    assert all(src < 4 and dst < 4 for src, dst, _, _ in moves)
+    # a step of a quarter segment: a rank's last segment reaches over several later ranks' samples
+    n_seg, ranges, windows = parallel.ExtendedShard.plan(27 * FS, 8 * FS, 2 * FS, 5)
+    owned, moves = parallel.halo_plan(windows)
+    covered = np.zeros(27 * FS, dtype=int)
+    for lo, hi in owned:
+        covered[lo:hi] += 1
+    assert np.all(covered == 1)
+    assert any(dst - src >= 2 for src, dst, _, _ in moves)
+    for src, dst, lo, hi in moves:
+        assert windows[src][0] <= lo < hi <= windows[src][1] and owned[dst][0] <= lo < hi <= owned[dst][1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_resident_extended_shards_exchange_their_borders(tmp_path, world):
+    got = _run("_case_resident_extended", tmp_path, world=world)
+    x = synth(27.0, FS, 2, 31)
+    for name, (length, step) in (("default", (10, 5)), ("short_step", (8, 2)), ("gaps", (10, 7.5))):
+        want = orc.extended(x, FS, orc.Params(segment_length=length, segment_step=step))
+        assert np.max(np.abs(got[name] - want)) < 1e-12, name
+
+
+def test_two_argument_separate_fn_still_works(tmp_path):
+    got = _run("_case_two_argument_fn", tmp_path)
+    for i, x in enumerate(_clips()):
+        assert np.max(np.abs(got[f"clip{i}"] - orc.original(x, FS))) < 1e-5
+    assert parallel._accepts_remainders(_original_from_planes) and not parallel._accepts_remainders(_two_argument_original)
+    assert parallel._accepts_remainders(lambda *a: None) and parallel._accepts_remainders(lambda x, fs, remainders=None: None)
+
+
 def test_deal_clips_longest_first_round_robin():
     shares = parallel.deal_clips([10, 50, 30, 50, 20], 2)
     assert shares == [[1, 2, 0], [3, 4]]
