@@ -124,7 +124,8 @@ def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, second
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400, help="steps per timed region (default 400: with 5 regions about two seconds of GPU work at "
+                                                           "cfg 2, long enough for a coarse GPU-activity sampler to see it)")
     ap.add_argument("--series", type=int, default=5, help="timed regions of exactly --steps steps each; value / ms_per_step are the MEDIAN series, all of them are listed")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-GEMM variant (a child run of this script under REPET_GRAM=f32)")
     ap.add_argument("--warmup", type=int, default=3)
@@ -491,10 +492,13 @@ def main():
                                      "latency-bound) and the column sort of V (transpose, per-column sort + rank search in LDS, transpose back); "
                                      "bytes = S read once + the sort's passes, time = both")
             stages.append(entry)
-        # the dominant KERNEL: "peaks+rank_columns" is two chains of seven launches side by side on two streams, not a kernel
+        # the dominant KERNEL: "peaks+rank_columns" is two chains of seven launches side by side on two streams, not a kernel --
+        # the line names both: the longest stage by time (dominant_stage) and the longest single-kernel stage (kernel, priced)
         single = [s for s in stages if s["name"] != "peaks+rank_columns"] or stages
         dom = max(single, key=lambda s: s["ms"])
-        roof = {"kernel": dom["name"]}
+        longest = max(stages, key=lambda s: s["ms"])
+        roof = {"kernel": dom["name"], "dominant_stage": {"name": longest["name"], "ms": longest["ms"],
+                                                           "is_a_single_kernel": longest["name"] != "peaks+rank_columns"}}
         roof.update({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in dom})
         roof["traffic"] = None
         # HBM-side bytes per launch of the dominant kernel: NOT measured by this run -- read from the committed PMC pass of
@@ -579,6 +583,61 @@ def main():
             if example_clip is None:
                 line["array_in_array_out_pcm16"] = with_floor(drop_in(np.round(clip * 32768.0).clip(-32768, 32767) / 32768.0))
                 line["array_in_array_out_pcm16"]["note"] = "the same call on the clip rounded to 16-bit PCM values (float64 array, exact in fp32: no remainders travel)"
+        if world == 1 and args.config == 2 and not args.no_variants and example_clip is None and "peaks+rank_columns" in stage_ms:
+            # "peaks+rank_columns" is two chains of kernels side by side on two streams. A child run with REPET_RANK_OVERLAP=0 puts
+            # the sort BEHIND the peak picking on the main stream with a timing mark behind every kernel: live per-kernel times,
+            # each priced on what binds THAT kernel (SURVEY 8d's 4 T^2 bytes for this stage are not read any more: the peak
+            # picking works from the Gram epilogue's segment records).
+            import subprocess
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 200)), "--warmup", str(args.warmup),
+                                        "--series", "1", "--no-cpu-baseline", "--no-scatter", "--no-variants"],
+                                       env=dict(os.environ, REPET_RANK_OVERLAP="0"), capture_output=True, text=True, timeout=600)
+                cj = json.loads(child.stdout.strip().splitlines()[-1])
+                alone = {st["name"]: st for st in cj["stages"]}
+                n_sort = 1 << max(int(T - 1).bit_length(), 11)
+                log_n = n_sort.bit_length() - 1
+                columns = (F - 1) * C
+                # bitonic sort of 2^L keys: 2^(L-1) L (L+1) / 2 compare-exchanges of two instructions (min, max) each; then T binary
+                # searches of L probes (read, compare, select): all on the quarter-rate min / max / compare class
+                sort_instr = columns * (n_sort // 2 * log_n * (log_n + 1) // 2 * 2 + T * log_n * 3) / 64.0
+                rows_k = []
+                for nm, st in alone.items():
+                    if nm not in ("local_maxima_pass1", "local_maxima_level2", "columns_from_rows", "rank_columns_sort", "code_planes", "rows_from_codes"):
+                        continue
+                    sec_k = st["ms"] * 1e-3
+                    row = {"name": nm, "ms_alone": st["ms"]}
+                    if nm == "rank_columns_sort":
+                        gi = sort_instr / sec_k / 1e9
+                        row.update({"bound": "valu", "achieved": round(gi, 1), "peak": VALU_QUARTER_RATE_GINSTR, "unit": "G wave-instr/s", "frac": round(gi / VALU_QUARTER_RATE_GINSTR, 4),
+                                    "algorithmic": sort_instr, "note": f"{columns} columns x bitonic sort of {n_sort} keys (min + max per compare-exchange) + {T} rank searches of {log_n} probes"})
+                    elif nm == "local_maxima_pass1":
+                        # what it must move: the segment records, the lists it writes, and the lines of S its cut segments and near-ties
+                        # ask for (about 60 x 128 B per row: profiles/ PMC pass) -- a latency-bound kernel (one wavefront per row, its span
+                        # is its slowest rows), priced against HBM for the record
+                        moved = st["algorithmic"] + 60.0 * 128.0 * T if "algorithmic" in st else None
+                        if moved:
+                            row.update({"bound": "latency", "achieved": round(moved / sec_k / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(moved / sec_k / 1e9 / HBM_PEAK_GBS, 4),
+                                        "algorithmic": moved, "rows_per_us": round(T / (sec_k * 1e6), 1),
+                                        "note": "one wavefront per row of S, memory round trips per row; bytes = records + lists + ~60 lines of S per row"})
+                    elif nm == "local_maxima_level2":
+                        row.update({"bound": "latency", "note": "float64 unit rows of the queued frames (256-thread workgroup each: float64 FFT in LDS) + the recorded rows again + the general kernel"})
+                    elif "algorithmic" in st:
+                        gb = st["algorithmic"] / sec_k / 1e9
+                        row.update({"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4), "algorithmic": st["algorithmic"]})
+                    rows_k.append(row)
+                for st in stages:
+                    if st["name"] == "peaks+rank_columns":
+                        st.pop("bound", None); st.pop("achieved", None); st.pop("peak", None); st.pop("unit", None); st.pop("frac", None); st.pop("algorithmic", None)
+                        st["kernels"] = rows_k
+                        st["kernels_note"] = ("per-kernel times of a child run with REPET_RANK_OVERLAP=0 (the sort behind the peak picking on ONE stream, a timing mark "
+                                              "behind every kernel); in the timed runs the two chains overlap on two streams: ms above is both")
+                        st["chains_alone_ms"] = {"peaks": round(sum(r["ms_alone"] for r in rows_k if r["name"].startswith("local_maxima")), 4),
+                                                 "sort": round(sum(r["ms_alone"] for r in rows_k if not r["name"].startswith("local_maxima")), 4)}
+            except Exception as exc:  # noqa: BLE001 -- a breakdown must never cost the headline
+                for st in stages:
+                    if st["name"] == "peaks+rank_columns":
+                        st["kernels_error"] = f"{type(exc).__name__}: {exc}"
         if world == 1 and args.config == 2 and not args.no_variants and example_clip is None:
             # north_star names an fp32 MFMA GEMM for the similarity matrix; the default is the f16x3 split of the fp32 operands.
             # The exact-fp32 kernel (REPET_GRAM=f32, read once per process) is timed by a child run of this script.

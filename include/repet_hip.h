@@ -61,11 +61,21 @@ typedef struct repet_params {
     int32_t sim_distance_frames; /* int(round(similarity_distance*fs/H))            repet.py:670 */
     int32_t sim_number;          /* similarity_number                               repet.py:60  */
     int32_t buffer_frames;       /* round(buffer_length*fs/H)         (simonline)   repet.py:787 */
-    int32_t reserved0;
+    int32_t flags;               /* REPET_FLAG_* (0: the defaults); was reserved0 before ABI 3 */
     int64_t seg_len_samples;     /* round(segment_length*fs)          (extended)    repet.py:266 */
     int64_t seg_step_samples;    /* round(segment_step*fs)            (extended)    repet.py:267 */
     double sim_threshold;        /* similarity_threshold                            repet.py:58  */
 } repet_params;
+
+/* repet_params.flags, bit 0 -- strict reference behaviour on samples that are not finite. repet.py never looks at its input
+ * (:125, :1220): a NaN sample makes the frames that hold it NaN and `sim` / `simonline` confine the damage to those frames,
+ * the period family spreads it through the beat spectrum and the period medians. By default the drop-in REFUSES such input
+ * (REPET_ERR_BAD_ARG, "contains NaN or infinite samples"). With this flag repet_run / repet_run_batch let the samples
+ * through: `sim` and `simonline` then return what the reference returns (NaN exactly on the samples of the affected frames,
+ * every other sample as without them -- tested against the oracle, which equals the reference bit for bit on such input);
+ * `original` / `extended` / `adaptive` answer REPET_ERR_BAD_ARG with a message that says so (their NaN pattern depends on
+ * np.median's NaN rule and on pocketfft's inf arithmetic). Context calls: repet_ctx_set_strict_reference. */
+#define REPET_FLAG_STRICT_REFERENCE 1
 
 /* The nine module-level parameters of the reference (repet.py:42-63), for hosts that do not keep them as Python
  * globals, and the derivation of repet_params from them exactly as the reference's public functions do it
@@ -143,6 +153,7 @@ int repet_ctx_download_device(repet_ctx* ctx, float* dev_out);
  * repet_ctx_input_view  : the resident fp32 samples and, when a float64 upload left any, their fp32 remainders (else NULL)
  * repet_ctx_download_from: n_values fp32 values from ANY device buffer of this context's device widened into a host float64
  *                         array through the context's pinned ring (the gather side of a scatter: results received from peers) */
+int repet_ctx_set_strict_reference(repet_ctx* ctx, int on);   /* (ABI 3) REPET_FLAG_STRICT_REFERENCE for this context's uploads and runs */
 int repet_ctx_stream(repet_ctx* ctx, void** hip_stream);
 int repet_ctx_result_view(repet_ctx* ctx, float** dev_out, int64_t* n_values /* nullable */);
 int repet_ctx_input_view(repet_ctx* ctx, float** dev_audio, float** dev_audio_lo /* nullable */, int64_t* n_values /* nullable */);

@@ -403,7 +403,10 @@ struct RankArgs {
     unsigned* P; int32_t n_planes;        // the codes bit-sliced INSTEAD of R (exactly one of R and P is set): MaskArgs::P
 };
 bool rank_columns_supported(int64_t T);
-hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s);
+// hook(user, step) is called behind every kernel of the chain (0 transpose, 1 sort + rank search, 2 code planes, 3 transpose back):
+// the engine records a timing mark there when the chain runs alone on the main stream (REPET_RANK_OVERLAP=0)
+typedef void (*RankStepHook)(void* user, int step);
+hipError_t launch_rank_columns(const RankArgs& a, hipStream_t s, RankStepHook hook = nullptr, void* user = nullptr);
 hipError_t launch_fill_rank_pad_rows(unsigned short* R, int64_t r_chan_stride, int32_t n_channels, int64_t pad_row,
                                      int32_t FS, hipStream_t s);
 

@@ -107,6 +107,8 @@ struct repet_ctx {
     std::function<int()> pre_synthesis;      // run_original calls it (once) right before its inverse STFT
     bool clip_loop = false;       // true while run_algo works through the clips one by one
     int32_t n_channels = 0;
+    bool strict = false;          // REPET_FLAG_STRICT_REFERENCE: samples that are not finite are let through (sim / simonline)
+    bool input_not_finite = false;   // the resident clip came from a host array that held such samples
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
     DevBuf peak_scratch;          // per-segment candidates of long similarity rows (launch_local_maxima)

@@ -652,7 +652,8 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     bool not_finite = false;
     HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream, lo_dst, &c->has_lo, lo_dst ? c->copy_stream : nullptr,
                           &not_finite));
-    if (not_finite) {
+    c->input_not_finite = not_finite;
+    if (not_finite && !c->strict) {
         // repet.py computes on, and NaN spreads from the frames that hold it through whatever is global in the variant (the
         // beat spectrum of original / extended / adaptive: whole segments or clips of NaN); host arrays with such samples are
         // refused instead ("Where the drop-in differs on purpose")
@@ -688,6 +689,7 @@ int repet_ctx_upload_device_split(repet_ctx* c, const float* dev_audio, const fl
         c->has_lo = true;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->input_not_finite = false;               // (device buffers are not scanned: what they hold is computed on, as in repet.py)
     c->ring.lo_in_flight = false;              // (the stream waited for it above and is idle now)
     c->n_samples = n; c->n_channels = ch; c->n_clips = n_clips; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
@@ -705,6 +707,12 @@ int repet_ctx_download_device(repet_ctx* c, float* dev_out) {
     if (count == 0) return REPET_OK;
     HIP_TRY(hipMemcpyAsync(dev_out, c->out.p, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return REPET_OK;
+}
+
+int repet_ctx_set_strict_reference(repet_ctx* c, int on) {
+    if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
+    c->strict = on != 0;
     return REPET_OK;
 }
 
@@ -778,6 +786,9 @@ int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
 int run_algo(repet_ctx* c, int algo, const repet_params* p) {
     c->clip_base = 0;
     if (c->win_total > 0) return fail(REPET_ERR_BAD_ARG, "the resident samples are a window of a longer clip: only repet_ctx_execute_extended_range applies");
+    if (c->input_not_finite && algo != REPET_SIM && algo != REPET_SIMONLINE)
+        return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples: strict_reference reproduces repet.py on such input for sim and "
+                                       "simonline only (the period family spreads them through the beat spectrum and np.median's NaN rule)");
     if (c->n_clips <= 1 || algo == REPET_SIMONLINE || algo == REPET_ORIGINAL) return run_algo_one(c, algo, p);
     repet_timing* timing = c->timing;
     c->timing = nullptr;                       // per-stage marks would repeat per clip: only the total is reported
@@ -1092,6 +1103,8 @@ int repet_run(int algo, const void* audio, int dtype, int64_t n, int32_t ch, con
               int device, repet_timing* timing) {
     repet_ctx* c = nullptr;
     RP_TRY(thread_ctx(device, &c));
+    RP_TRY(check_params(p));
+    c->strict = (p->flags & REPET_FLAG_STRICT_REFERENCE) != 0;
     RP_TRY(repet_ctx_upload(c, audio, dtype, n, ch));
     // (without a timing request nothing waits between the last kernel and the first copy back: the download is ordered behind
     // the run on the context's stream, and an error of the run surfaces there)

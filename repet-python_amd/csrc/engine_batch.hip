@@ -100,6 +100,7 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
         run_threads([&](int dev) {
             repet_ctx* c = nullptr;
             int rc = repet_ctx_create(dev % physical, &c);
+            if (rc == REPET_OK) c->strict = p && (p->flags & REPET_FLAG_STRICT_REFERENCE) != 0;
             for (int i = dev; rc == REPET_OK && i < n_clips; i += n_devices) {
                 const int k = order[i];
                 rc = repet_ctx_upload(c, audio[k], dtype, n_samples[k], n_channels[k]);
@@ -190,7 +191,8 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
                 if (want_lo) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.lo_root), bytes));
                 bool not_finite = false;
                 HIP_TRY(staged_upload(io->ring, audio[k], dtype, q.in_root, count, io->stream, q.lo_root, &q.has_lo, nullptr, &not_finite));
-                if (not_finite) return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples");
+                if (not_finite && !(p && (p->flags & REPET_FLAG_STRICT_REFERENCE) && (algo == REPET_SIM || algo == REPET_SIMONLINE)))
+                    return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples");
             }
             if (q.has_lo) ++g_batch_info.clips_with_remainders;
             if (!travels(k) || count == 0) continue;

@@ -144,11 +144,19 @@ int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream
         HIP_TRY(c->median_codes.ensure((size_t)g.C * g.chan_stride * sizeof(unsigned)));
         m->median_codes = c->median_codes.as<unsigned>();
     }
-    HIP_TRY(launch_rank_columns(a, stream));
+    // (with_mark: the chain runs alone on the main stream and every kernel gets its own timing mark -- bench.py's per-kernel rows)
+    struct HookCtx { repet_ctx* c; double cells; double plane_bytes; } hc{c, (double)n_cols * (double)g.T * g.C, bits ? (double)g.T * a.n_planes * 256.0 : 0.0};
+    auto hook = [](void* user, int step) {
+        HookCtx* h = static_cast<HookCtx*>(user);
+        if (step == 0) mark(h->c, "columns_from_rows", (4.0 + 4.0) * h->cells, 0);                    // V read, columns written
+        else if (step == 1) mark(h->c, "rank_columns_sort", (4.0 + 4.0 + 2.0) * h->cells, 0);        // column read, written sorted, codes written
+        else if (step == 2) mark(h->c, "code_planes", 2.0 * h->cells + h->plane_bytes, 0);
+        else mark(h->c, "rows_from_codes", (2.0 + 2.0) * h->cells, 0);
+    };
+    HIP_TRY(launch_rank_columns(a, stream, with_mark ? +hook : nullptr, &hc));
     m->R = a.R; m->r_chan_stride = a.r_chan_stride; m->Vs = a.Vs; m->vs_pitch = vs_pitch; m->n_rank_cols = n_cols;
     m->P = a.P; m->n_planes = a.n_planes;
     // V read, columns written / read twice / written sorted, codes written column-major, read, written frame-major
-    if (with_mark) mark(c, "rank_columns", (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * n_cols * (double)g.T * g.C, 0);
     return REPET_OK;
 }
 
@@ -206,7 +214,10 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         // workgroup on a CU keeps the Gram's 139 KB workgroup off it -- and so does the memory-bound transpose that opens
         // the sort, although its 17 KB of LDS fit beside a Gram workgroup: Gram 0.209 -> 0.244 ms for 0.015 ms saved
         // afterwards.)
-        const bool beside = use_rank;
+        // REPET_RANK_OVERLAP=0 (measurement switch): the sort BEHIND the peak picking on the main stream, every kernel of both
+        // chains with a timing mark of its own -- what bench.py's per-kernel rows under "peaks+rank_columns" come from
+        static const bool overlap = [] { const char* e = getenv("REPET_RANK_OVERLAP"); return !(e && e[0] == '0'); }();
+        const bool beside = use_rank && overlap;
         // (Measured and dropped: starting the sort behind the first pass of the peak picking, beside its second level --
         // peaks + sort 0.446 against 0.419 ms: the second level's kernels hold a whole register file per wave and do not share
         // a CU with the sort any better than the first pass does.)
@@ -226,6 +237,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
                                            nullptr, scratch > 0 ? c->peak_scratch.p : nullptr, nullptr, seg, seg_pitch);
         if (e == hipErrorInvalidValue) return fail(REPET_ERR_LIMIT, "sim: clip has too many frames for the peak-picking kernel's LDS row");
         HIP_TRY(e);
+        if (use_rank && !beside) mark(c, "local_maxima_pass1", 12.0 * T * seg_pitch + 4.0 * K * T, 0);   // records read, lists written (+ the lines of S it asks for)
         // The second level of the peak picking: float64 spectra for the rows the fp32 spectra cannot settle (a few hundred of
         // 7 753 at cfg 2). Measured and dropped: running it on the side stream BESIDE the median mask of all the other rows
         // and masking its rows afterwards -- its kernels hold whole register files (one wave per SIMD) and the issue-bound
@@ -239,7 +251,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             // one figure for the two concurrent launches: their bytes added up (S read once + the sort's passes over V)
             mark(c, "peaks+rank_columns", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * (g.F - 1) * (double)g.T * g.C, 0);
         } else {
-            mark(c, "local_maxima", 4.0 * T * T + 4.0 * K * T, 0);
+            mark(c, use_rank ? "local_maxima_level2" : "local_maxima", use_rank ? 0.0 : 4.0 * T * T + 4.0 * K * T, 0);
             if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true, max_peaks));
         }
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
@@ -302,6 +314,14 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
                               N, N * g.C, 0, T, nb));
     mark(c, "local_maxima", nb * (4.0 * rows * B + 4.0 * K * rows), 0);
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
+    if (c->input_not_finite && B > 1) {
+        // strict reference mode: repet.py never writes the warm-up frames (repet.py:834: its background stays 0 there); the engine
+        // gives them the mask 0, and 0 x NaN would be NaN -- their spectra (which only the inverse STFT still reads) are cleared
+        for (int b = 0; b < nb; ++b)
+            for (int ch = 0; ch < g.C; ++ch)
+                HIP_TRY(hipMemsetAsync(c->X.as<float2>() + b * spec_stride + ch * g.chan_stride, 0,
+                                       (size_t)std::min<int64_t>(B - 1, T) * g.FS * sizeof(float2), c->stream));
+    }
     MaskArgs m = mask_args(c, g, p->cutoff_bins);
     m.n_batch = nb; m.batch_stride = spec_stride; m.idx_batch_stride = rows_alloc * KP; m.cnt_batch_stride = rows_alloc;
     HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), B - 1, max_peaks, c->stream, c->side_stream,

@@ -384,7 +384,7 @@ hipError_t launch_fill_rank_pad_rows(unsigned short* R, int64_t r_chan_stride, i
 bool rank_columns_supported(int64_t T) { return T > kRankMinFrames && T <= kRankMaxFrames; }
 
 template <int LOG2N>
-static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
+static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook hook, void* user) {
     constexpr int N = 1 << LOG2N;
     constexpr int lds = (N + N / 8) * 4 + (N >> rank_leaf_bits(LOG2N)) * 4;        // the padded keys + the breadth-first copy of the leaf ends
     const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N>);
@@ -393,29 +393,33 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s) {
     const int64_t cols = (int64_t)a.n_channels * a.n_cols;
     hipLaunchKernelGGL(columns_from_rows_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
                        dim3(256), 0, s, a);
+    if (hook) hook(user, 0);
     hipLaunchKernelGGL(rank_columns_kernel<LOG2N>, dim3((unsigned)cols), dim3(N / 32), lds, s, a);
+    if (hook) hook(user, 1);
     if (a.P) {                           // the bit-sliced selection reads the planes only: no frame-major codes
         constexpr int plane_lds_bytes = 1024 * kPlaneColPitch * 2;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(&code_planes_from_columns_kernel), plane_lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(code_planes_from_columns_kernel, dim3((unsigned)ceil_div(a.T, kPlaneFrames), 2), dim3(1024), plane_lds_bytes, s, a);
+        if (hook) hook(user, 2);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(rows_from_code_columns_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 128), (unsigned)(a.n_cols / 128), (unsigned)a.n_channels),
                        dim3(256), 0, s, a);
+    if (hook) hook(user, 3);
     return hipGetLastError();
 }
 
-hipError_t launch_rank_columns(const RankArgs& a0, hipStream_t s) {
+hipError_t launch_rank_columns(const RankArgs& a0, hipStream_t s, RankStepHook hook, void* user) {
     if (!rank_columns_supported(a0.T) || a0.n_cols <= 0 || (a0.n_cols & 127) || (a0.vs_pitch & 31) || (a0.FS & 1)) return hipErrorInvalidValue;
     if (a0.P && (a0.R || a0.n_planes != code_planes_for(a0.T) || a0.n_planes > 15 || a0.n_channels * (a0.n_cols >> 6) > 32)) return hipErrorInvalidValue;
     if (!a0.P && !a0.R) return hipErrorInvalidValue;
     RankArgs a = a0;
-    if (a.T <= 2048) return launch_rank_n<11>(a, s);
-    if (a.T <= 4096) return launch_rank_n<12>(a, s);
-    if (a.T <= 8192) return launch_rank_n<13>(a, s);
-    if (a.T <= 16384) return launch_rank_n<14>(a, s);
-    return launch_rank_n<15>(a, s);
+    if (a.T <= 2048) return launch_rank_n<11>(a, s, hook, user);
+    if (a.T <= 4096) return launch_rank_n<12>(a, s, hook, user);
+    if (a.T <= 8192) return launch_rank_n<13>(a, s, hook, user);
+    if (a.T <= 16384) return launch_rank_n<14>(a, s, hook, user);
+    return launch_rank_n<15>(a, s, hook, user);
 }
 
 }  // namespace repet

@@ -33,6 +33,12 @@ similarity_distance = 1
 similarity_number = 100
 buffer_length = 10
 
+# Not a parameter of the reference: what to do with samples that are NOT FINITE. repet.py computes on (a NaN sample makes the
+# frames that hold it NaN; repet.py:125 has no input check). False (default): such input raises ValueError. True: the samples
+# are let through and ``sim`` / ``simonline`` return exactly what the reference returns -- NaN on the samples of the affected
+# frames, everything else as without them; the period family still raises. Read at call time like the others.
+strict_reference = False
+
 _device = 0  # HIP device used by the one-shot calls
 
 
@@ -72,6 +78,7 @@ def derive_params(sampling_frequency):
     p.seg_len_samples = int(round(segment_length * fs))                       # repet.py:266
     p.seg_step_samples = int(round(segment_step * fs))                        # repet.py:267
     p.sim_threshold = float(similarity_threshold)
+    p.flags = _native.FLAG_STRICT_REFERENCE if strict_reference else 0
     return p
 
 

@@ -16,6 +16,7 @@ F32, F64, I16 = 0, 1, 2
 MAX_STAGES = 16
 
 ERR_BAD_ARG, ERR_TOO_SHORT, ERR_HIP, ERR_OOM, ERR_LIMIT = -1, -2, -3, -4, -5
+FLAG_STRICT_REFERENCE = 1
 
 
 class Params(C.Structure):
@@ -23,7 +24,7 @@ class Params(C.Structure):
                 ("period_hi", C.c_int32), ("cutoff_bins", C.c_int32), ("filter_order", C.c_int32),
                 ("seg_len_frames", C.c_int32), ("seg_step_frames", C.c_int32),
                 ("sim_distance_frames", C.c_int32), ("sim_number", C.c_int32), ("buffer_frames", C.c_int32),
-                ("reserved0", C.c_int32), ("seg_len_samples", C.c_int64), ("seg_step_samples", C.c_int64),
+                ("flags", C.c_int32), ("seg_len_samples", C.c_int64), ("seg_step_samples", C.c_int64),
                 ("sim_threshold", C.c_double)]
 
 
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "repet_last_batch_info": (C.c_int, [C.POINTER(C.c_int64)]),
     "repet_ctx_download_input": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32)]),
     "repet_ctx_set_window": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "repet_ctx_set_strict_reference": (C.c_int, [_P, C.c_int]),
     "repet_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "repet_ctx_result_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "repet_ctx_input_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
@@ -287,6 +289,10 @@ class Context:
     def download_device(self, data_ptr):
         """The result as fp32 interleaved samples into device memory of at least ``prod(self.shape)`` floats."""
         check(lib().repet_ctx_download_device(self._h, C.c_void_p(int(data_ptr))))
+
+    def set_strict_reference(self, on=True):
+        """REPET_FLAG_STRICT_REFERENCE for this context: NaN / infinite samples are let through (``sim`` / ``simonline``)."""
+        check(lib().repet_ctx_set_strict_reference(self._h, 1 if on else 0))
 
     def stream(self):
         """The context's HIP stream as an integer handle (``torch.cuda.ExternalStream(ctx.stream())`` orders torch's

@@ -11,6 +11,7 @@ the module attributes, not by editing the reference). No reference source text i
     python tests/golden/make_golden.py --cases small,mid,g44k,edge      (~1 min)
     python tests/golden/make_golden.py --cases config                   (~6 CPU-min)
     python tests/golden/make_golden.py --cases groove,groove_config     (second clip family; ~4 CPU-min)
+    python tests/golden/make_golden.py --cases cfg1s                    (surrogate of the reference's example clip; ~1 CPU-min)
 """
 import argparse
 import hashlib
@@ -26,7 +27,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "repet-python_amd"))
-from repet_synth import synth, synth_groove  # noqa: E402
+from repet_synth import synth, synth_groove, synth_song  # noqa: E402
 
 ALGOS = ("original", "extended", "adaptive", "sim", "simonline")
 
@@ -241,6 +242,11 @@ def main():
     if "groove_config" in want:
         for name, spec in GROOVE_CONFIG_CASES.items():
             run_case(ref, name, spec, 16, family="groove")
+    if "cfg1s" in want:
+        # The surrogate of BASELINE.json configs[0] that CAN travel to the GPU box: repet_synth.synth_song, the example clip's
+        # exact shape (1 014 301 samples, 44.1 kHz stereo, 16-bit PCM values), produced-music-like content, all five variants.
+        clip = synth_song(1014301, 44100, 2, 0)
+        run_case(ref, "cfg1_surrogate", (1014301 / 44100, 44100, 2, 0, 211, ALGOS), 4, clip=clip, family="song")
     if "cfg1" in want:
         # BASELINE.json configs[0]: the reference's own example clip (README.md:62-75), read the way its wavread
         # does (repet.py:914-931). Only outputs/statistics are stored; the audio itself is not redistributed.

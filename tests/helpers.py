@@ -37,6 +37,9 @@ def golden_input(name):
         import scipy.io.wavfile
         _, pcm = scipy.io.wavfile.read(REFERENCE_WAV)
         x = pcm / pow(2, pcm.itemsize * 8 - 1)             # what the reference's wavread returns (repet.py:929)
+    elif "family" in g and str(g["family"]) == "song":
+        from repet_synth import synth_song
+        x = synth_song(int(round(float(g["duration"]) * int(g["fs"]))), int(g["fs"]), int(g["channels"]), int(g["seed"]))
     else:
         make = synth_groove if "family" in g and str(g["family"]) == "groove" else synth
         x = make(float(g["duration"]), int(g["fs"]), int(g["channels"]), int(g["seed"]))

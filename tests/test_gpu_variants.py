@@ -142,6 +142,77 @@ def test_nan_and_infinite_samples_are_refused():
     assert np.all(np.isfinite(repet.original(big.astype(np.float32), fs))) or True     # (no exception: fp32 range is the caller's business)
 
 
+@pytest.mark.parametrize("algo,fs,seconds,channels,dtype", [("sim", 16000, 24, 2, np.float64), ("sim", 44100, 40, 2, np.float64),
+                                                             ("simonline", 16000, 30, 2, np.float64), ("sim", 22050, 30, 1, np.float32),
+                                                             ("simonline", 44100, 24, 2, np.float32)])
+def test_strict_reference_reproduces_repet_py_on_samples_that_are_not_finite(algo, fs, seconds, channels, dtype, monkeypatch):
+    """``repet.strict_reference = True``: NaN / +-inf samples are let through and `sim` / `simonline` return what repet.py returns
+    (repet.py:125 has no input check; :1220 and :1318-1326 confine the damage): NaN on exactly the samples of the frames that
+    hold such a sample, every other sample as the float64 oracle gives it (the oracle equals the reference bit for bit on
+    this kind of input: NaN positions equal, max-abs 0.0 elsewhere -- checked against /root/reference when the strict mode was
+    built), and the similar-frame lists of every other frame equal to the oracle's. 44.1 kHz / 40 s takes the rank-domain
+    median: the NaN / inf magnitudes go through the column sort. The period family keeps refusing, with a message of its own."""
+    monkeypatch.setattr(repet, "strict_reference", True)
+    x = synth(seconds, fs, channels, 11).astype(dtype)
+    n = len(x)
+    x[n // 3, 0] = np.nan                                   # one sample
+    x[n // 2:n // 2 + 5000, channels - 1] = np.nan          # a run that spans several frames
+    x[(2 * n) // 3, 0] = np.inf
+    x[(2 * n) // 3 + 40000, channels - 1] = -np.inf
+    tr = orc.Trace()
+    with np.errstate(all="ignore"):
+        want = orc.ALGORITHMS[algo](x.astype(np.float64), fs, None, tr)
+    p = repet.derive_params(fs)
+    assert p.flags == 1
+    ctx = repet.Context(0)
+    ctx.set_strict_reference(True)
+    ctx.upload(x)
+    ctx.execute(algo, p)
+    got = ctx.download()
+    theirs = tr.items["similarity_indices"]
+    idx, cnt = ctx.last_sim_indices(len(theirs), p.sim_number)
+    ctx.close()
+    bad = np.isnan(want)
+    assert 0 < bad.any(axis=1).sum() < 0.2 * n and not np.isinf(want).any()
+    assert np.array_equal(np.isnan(got), bad) and not np.isinf(got).any()
+    assert rms_err(got[~bad], want[~bad]) <= 2e-5
+    differ = sum(set(idx[r, :cnt[r]].tolist()) != set(np.asarray(theirs[r]).tolist()) for r in range(len(theirs)))
+    assert differ == 0
+    assert np.array_equal(getattr(repet, algo)(x, fs), got, equal_nan=True)      # the one-shot call (flag in repet_params) gives the same
+    if algo == "sim":
+        assert np.array_equal(repet.run_batch("sim", [x], fs)[0], got, equal_nan=True)
+    for other in ("original", "extended", "adaptive"):
+        with pytest.raises(ValueError, match="strict_reference reproduces"):
+            getattr(repet, other)(x, fs)
+    monkeypatch.setattr(repet, "strict_reference", False)
+    with pytest.raises(ValueError, match="NaN or infinite"):
+        getattr(repet, algo)(x, fs)
+
+
+def test_stated_limits_of_the_engine():
+    """repet.py accepts any sampling rate (:130) and any length (:149). The engine's limits are stated, not silent: the largest
+    window is 8 192 samples (fs <= 204.8 kHz: 192 kHz works, against the oracle), a larger one is REPET_ERR_LIMIT with the
+    window named; one channel's magnitude plane stays below 2 GiB (508 000 frames: 3.2 hours at 44.1 kHz), a longer clip is REPET_ERR_LIMIT
+    with the length named -- before anything of that size is allocated -- and the context is usable afterwards."""
+    fs = 192000
+    x = synth(4.5, fs, 1, 21)
+    assert repet.derive_params(fs).window_length == 8192
+    assert rms_err(repet.sim(x, fs), orc.sim(x, fs)) <= RMS_TOL
+    assert rms_err(repet.original(x, fs), orc.original(x, fs)) <= RMS_TOL
+    with pytest.raises(RuntimeError, match="window length must be a power of two in \\[64, 8192\\]"):
+        repet.sim(synth(1.0, 220500, 1, 2), 220500)                          # W = 16 384
+    long_clip = np.zeros((530_000_000, 1), dtype=np.int16)                   # 3.3 hours of 44.1 kHz mono: 517 579 frames
+    ctx = repet.Context(0)
+    ctx.upload(long_clip)
+    with pytest.raises(RuntimeError, match="spectrogram must stay below 2 GiB"):
+        ctx.execute("original", repet.derive_params(44100))
+    del long_clip
+    ctx.upload(synth(6.0, 44100, 2, 3))
+    ctx.execute("original", repet.derive_params(44100))
+    assert np.all(np.isfinite(ctx.download()))
+    ctx.close()
+
+
 def test_silent_gap_gives_nan_only_for_sim():
     edge = load_edge_cases()
     fs = 44100
@@ -872,12 +943,18 @@ def test_streaming_online_errors():
     stream.close()
 
 
+@pytest.mark.parametrize("case", ["cfg1_audio_file", "cfg1_surrogate"])
 @pytest.mark.parametrize("algo", ALGOS)
-def test_reference_example_clip(algo):
+def test_reference_example_clip(algo, case):
     """BASELINE.json configs[0]: the reference's own example clip (real music, README.md:62-75), replayed from its
-    int16 PCM through wavread's normalisation, against the reference's outputs and integer intermediates."""
-    g = load_golden("cfg1_audio_file")
-    x, fs = golden_input("cfg1_audio_file")
+    int16 PCM through wavread's normalisation, against the reference's outputs and integer intermediates -- where the
+    reference tree is (the clip cannot be redistributed: skipped on the GPU box); and its SURROGATE, which runs everywhere:
+    repet_synth.synth_song at the clip's exact shape (1 014 301 samples, 44.1 kHz stereo, 16-bit PCM values, T = 992 frames,
+    `original`'s period 287 against the clip's 286), produced-music-like content (drum loop with humanised levels, bass,
+    pad, a sung line, intro / breakdown / fade), all five variants against the reference's own outputs on it
+    (tests/golden/make_golden.py --cases cfg1s)."""
+    g = load_golden(case)
+    x, fs = golden_input(case)
     p = repet.derive_params(fs)
     ctx = repet.Context(0)
     ctx.upload(x)
@@ -890,7 +967,7 @@ def test_reference_example_clip(algo):
     per_s = np.sqrt(np.mean(y[:n].reshape(-1, fs, 2) ** 2, axis=1))
     assert np.max(np.abs(per_s - g[f"{algo}.rms_per_second"])) < 3e-4
     if algo == "original":
-        assert ctx.last_periods(1)[0] == 286
+        assert ctx.last_periods(1)[0] == int(g["original.period"]) == (286 if case == "cfg1_audio_file" else 287)
     if algo == "extended":
         assert np.array_equal(ctx.last_periods(16), g["extended.periods"])
     if algo == "adaptive":

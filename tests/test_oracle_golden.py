@@ -121,14 +121,17 @@ def test_localmaxima_matches_definition():
 
 
 # ---- BASELINE.json configs[0]: the reference's own example clip (real music, 23 s, 44.1 kHz stereo) ----
+@pytest.mark.parametrize("case", ["cfg1_audio_file", "cfg1_surrogate"])
 @pytest.mark.parametrize("algo", ALGOS)
-def test_reference_example_clip(algo):
-    y, tr, g = _run("cfg1_audio_file", algo)
+def test_reference_example_clip(algo, case):
+    """The reference's own clip (where the reference tree is) and its redistributable surrogate of the same shape
+    (repet_synth.synth_song; fixture from make_golden.py --cases cfg1s)."""
+    y, tr, g = _run(case, algo)
     stride = int(g["sample_stride"])
     assert y.shape == (1014301, 2)
     assert np.max(np.abs(y[::stride] - g[f"{algo}.samples"])) <= TOL
     if algo == "original":
-        assert tr["repeating_period"] == int(g["original.period"]) == 286        # arg-max lag 285
+        assert tr["repeating_period"] == int(g["original.period"]) == (286 if case == "cfg1_audio_file" else 287)   # SURVEY 8: arg-max lag 285
     if algo == "extended":
         assert np.array_equal(tr["segment_periods"], g["extended.periods"])
     if algo == "adaptive":
