@@ -577,11 +577,16 @@ def main():
                 entry["pcie_floor_ms"] = round(floor_ms, 2)
                 entry["frac_of_pcie_floor"] = round(floor_ms / entry["ms_min"], 3)
                 return entry
+            # (where the call's host work runs matters on a two-socket host: started under `taskset -c <the GPU node's CPUs>` the
+            # same call took 3.84-3.94 ms PCM-exact / 4.7-5.2 ms float64 on the box of profiles/r05_dropin_numa.txt)
+            line["host_cpus_near_gpu"] = len(repet.device_host_cpus(local_rank))
+            line["host_affinity_cpus"] = len(os.sched_getaffinity(0))
             line["array_in_array_out"] = with_floor(drop_in(clip))
             line["array_in_array_out"]["note"] = ("repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads "
                                                   "narrow/widen through a pinned ring; fp32 samples over PCIe, their fp32 remainders behind them beside the computation)" % args.algo)
             if example_clip is None:
-                line["array_in_array_out_pcm16"] = with_floor(drop_in(np.round(clip * 32768.0).clip(-32768, 32767) / 32768.0))
+                pcm_clip = np.round(clip * 32768.0).clip(-32768, 32767) / 32768.0
+                line["array_in_array_out_pcm16"] = with_floor(drop_in(pcm_clip))
                 line["array_in_array_out_pcm16"]["note"] = "the same call on the clip rounded to 16-bit PCM values (float64 array, exact in fp32: no remainders travel)"
         if world == 1 and args.config == 2 and not args.no_variants and example_clip is None and "peaks+rank_columns" in stage_ms:
             # "peaks+rank_columns" is two chains of kernels side by side on two streams. A child run with REPET_RANK_OVERLAP=0 puts

@@ -112,6 +112,13 @@ typedef struct repet_ctx repet_ctx;
 /* ---- library --------------------------------------------------------------------------------- */
 int repet_abi_version(void);
 int repet_device_count(void);
+/* (ABI 3) The CPUs of the NUMA node `device` hangs off, among those this process may run on (from the device's PCI address in
+ * sysfs; *n_cpus = 0: unknown, or the machine has one node). On a two-socket host the drop-in call -- whose cost is host
+ * threads narrowing the caller's array into pinned memory and two PCIe copies -- takes 3.9 ms when the calling process runs
+ * on the GPU's node and 4.3 .. 5.9 ms elsewhere (180-s stereo clip): a host binds itself with
+ * sched_setaffinity to these CPUs (repet.bind_host_to_device). The library pins only its OWN worker threads
+ * (REPET_HOST_NUMA=0: not even those). */
+int repet_device_host_cpus(int device, int32_t* cpus, int32_t capacity, int32_t* n_cpus);
 const char* repet_last_error(void); /* thread-local text of the last failure on this thread */
 
 /* ---- context: one per (host thread, device); owns a stream, workspaces, twiddle tables ------- */

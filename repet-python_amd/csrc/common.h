@@ -403,6 +403,8 @@ struct RankArgs {
     unsigned* P; int32_t n_planes;        // the codes bit-sliced INSTEAD of R (exactly one of R and P is set): MaskArgs::P
 };
 bool rank_columns_supported(int64_t T);
+// CPUs of the NUMA node device `dev` hangs off that this process may run on (hostio.hip; empty: unknown or nothing to choose)
+std::vector<int> host_cpus_near_device(int dev);
 // hook(user, step) is called behind every kernel of the chain (0 transpose, 1 sort + rank search, 2 code planes, 3 transpose back):
 // the engine records a timing mark there when the chain runs alone on the main stream (REPET_RANK_OVERLAP=0)
 typedef void (*RankStepHook)(void* user, int step);

@@ -710,6 +710,15 @@ int repet_ctx_download_device(repet_ctx* c, float* dev_out) {
     return REPET_OK;
 }
 
+int repet_device_host_cpus(int device, int32_t* cpus, int32_t capacity, int32_t* n_cpus) {
+    if (!n_cpus || capacity < 0 || (capacity > 0 && !cpus)) return fail(REPET_ERR_BAD_ARG, "null argument");
+    if (device < 0 || device >= repet_device_count()) return fail(REPET_ERR_BAD_ARG, "no such device");
+    const std::vector<int> near = host_cpus_near_device(device);
+    *n_cpus = (int32_t)near.size();
+    for (int i = 0; i < capacity && i < (int)near.size(); ++i) cpus[i] = near[i];
+    return REPET_OK;
+}
+
 int repet_ctx_set_strict_reference(repet_ctx* c, int on) {
     if (!c) return fail(REPET_ERR_BAD_ARG, "ctx is null");
     c->strict = on != 0;

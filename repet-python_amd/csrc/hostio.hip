@@ -17,7 +17,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <cctype>
 #include <chrono>
+#include <cstdio>
 #include <sched.h>
 #include <cstring>
 #include <cmath>
@@ -25,6 +27,7 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -32,6 +35,44 @@
 namespace repet {
 
 // ---- worker pool -----------------------------------------------------------------------------------------------
+// The CPUs of the NUMA node the current GPU hangs off, as far as this process may use them (empty: unknown, one node only,
+// or REPET_HOST_NUMA=0). Measured on the 2-socket MI355X host (tools/dropin_probe.py under taskset): with the conversion
+// threads on the GPU's node a 180-s clip goes up in 1.50 ms and the drop-in call takes 3.84 ms; on the other node 1.86 and
+// 4.95; left to the scheduler 1.78 and 4.33. The pool's own threads are therefore kept on that node -- the caller's thread
+// (which converts one part in eight and issues the copies) is the caller's business and is left where it is.
+std::vector<int> host_cpus_near_device(int dev) {
+    std::vector<int> out;
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, dev) != hipSuccess) return out;
+    for (char* q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    auto read_line = [](const std::string& path) -> std::string {
+        std::string line;
+        if (FILE* f = fopen(path.c_str(), "r")) { char buf[4096]; if (fgets(buf, sizeof(buf), f)) line = buf; fclose(f); }
+        while (!line.empty() && (line.back() == '\n' || line.back() == ' ')) line.pop_back();
+        return line;
+    };
+    const std::string node = read_line(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
+    if (node.empty() || node[0] == '-') return out;
+    const std::string list = read_line("/sys/devices/system/node/node" + node + "/cpulist");
+    cpu_set_t allowed;
+    if (list.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+    size_t i = 0;
+    while (i < list.size()) {                                   // "64-127,192-255"
+        size_t j = list.find(',', i);
+        if (j == std::string::npos) j = list.size();
+        const std::string part = list.substr(i, j - i);
+        const size_t dash = part.find('-');
+        const int a = atoi(part.substr(0, dash).c_str());
+        const int b = dash == std::string::npos ? a : atoi(part.substr(dash + 1).c_str());
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) out.push_back(c);
+        i = j + 1;
+    }
+    if ((int)out.size() == CPU_COUNT(&allowed)) out.clear();    // (the whole mask: nothing to choose)
+#endif
+    return out;
+}
+
 namespace {
 
 class HostWorkers {
@@ -82,6 +123,13 @@ private:
         std::this_thread::yield();
 #endif
     }
+    static std::vector<int> gpu_node_cpus() {
+        const char* off = getenv("REPET_HOST_NUMA");
+        if (off && off[0] == '0') return {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return {};
+        return host_cpus_near_device(dev);
+    }
     // CPUs this process may run on (its affinity mask / container quota as the scheduler reports it)
     static int usable_cpus() {
 #if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
@@ -100,12 +148,22 @@ private:
             n = hw >= 32 ? 8 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
         }
         n_threads_ = std::min(n, 32);
+        near_cpus_ = gpu_node_cpus();
+        if ((int)near_cpus_.size() < n_threads_) near_cpus_.clear();
         // more threads than CPUs (REPET_HOST_THREADS above a container's share): spinners would take the CPU from the thread
         // that converts part 0 -- hand over through the condition variable then
         spin_ok_ = n_threads_ <= usable_cpus();
         for (int k = 1; k < n_threads_; ++k) std::thread([this, k] { loop(k); }).detach();
     }
     void loop(int part) {
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+        if (!near_cpus_.empty()) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int c : near_cpus_) CPU_SET(c, &set);
+            (void)sched_setaffinity(0, sizeof(set), &set);          // (this worker only: tid 0 = the calling thread)
+        }
+#endif
         unsigned seen = 0;
         for (;;) {
             // the next job: spin for about 200 us of WALL time (the gaps between the chunks of one copy), then sleep
@@ -132,6 +190,7 @@ private:
     }
     int n_threads_ = 1;
     bool spin_ok_ = true;
+    std::vector<int> near_cpus_;
     std::mutex job_mutex_, m_;
     std::condition_variable cv_;
     const std::function<void(int, int)>* fn_ = nullptr;

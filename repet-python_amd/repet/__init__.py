@@ -48,6 +48,30 @@ def set_device(index):
     _device = int(index)
 
 
+def device_host_cpus(device=None):
+    """CPUs of the NUMA node the device hangs off, among those this process may use ([] when unknown or nothing to choose)."""
+    import ctypes as C
+    dev = _device if device is None else int(device)
+    n = C.c_int32()
+    buf = (C.c_int32 * 4096)()
+    _native.check(_native.lib().repet_device_host_cpus(dev, buf, 4096, C.byref(n)))
+    return [int(buf[i]) for i in range(min(n.value, 4096))]
+
+
+def bind_host_to_device(device=None):
+    """Bind the calling process (thread) to the CPUs of the device's NUMA node -- what ``numactl --cpunodebind`` would do for a
+    GPU job. Arrays first touched afterwards live there too. Returns the previous affinity mask (``os.sched_setaffinity(0,
+    previous)`` undoes it), or None when there is nothing to choose. Not done implicitly: the affinity of the caller's
+    threads is the caller's business (the library pins only its own conversion threads)."""
+    import os
+    cpus = device_host_cpus(device)
+    if not cpus:
+        return None
+    previous = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, cpus)
+    return previous
+
+
 # ---- sizes derived exactly as the reference derives them ---------------------------------------------------
 def _window_length(sampling_frequency):
     return pow(2, int(np.ceil(np.log2(0.04 * sampling_frequency))))  # repet.py:130

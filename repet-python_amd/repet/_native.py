@@ -59,6 +59,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     "repet_abi_version": (C.c_int, []),
     "repet_device_count": (C.c_int, []),
+    "repet_device_host_cpus": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     "repet_last_error": (C.c_char_p, []),
     "repet_default_settings": (None, [C.POINTER(Settings)]),
     "repet_derive_params": (C.c_int, [C.POINTER(Settings), C.c_double, C.POINTER(Params)]),
