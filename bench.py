@@ -45,7 +45,7 @@ VALU_FULL_RATE_GINSTR = 1024 * 2.4 / 2.0
 # rows gathered from a table that an XCD's L2 holds: 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, 'Indexed rows'); the
 # vector memory path of the CUs caps the same traffic at 256 CUs x 64 B/clk x 2.4 GHz = 39 TB/s, which it never reaches
 L2_GATHER_PEAK_GBS = 17800.0
-PMC_FILE = "r04_pmc_traffic.json"
+PMC_FILE = "r05_pmc_traffic.json"
 # arithmetic type of the path: fp32 end to end, except that the similarity GEMM of sim / simonline runs on the f16 matrix
 # cores as a three-product split of the fp32 operands (22 significant bits per product, fp32 accumulate; gram_f16.hip)
 DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on bit-sliced rank codes)",
@@ -71,6 +71,31 @@ def cpu_baseline(fs, channels, seconds, algo="sim", n_clips=1):
             "sample": f"oracle.{algo} (NumPy float64 port of repet.py) on {n_clips} x {seconds:g}-s {fs} Hz {channels}-ch synth clip "
                       f"(the bench workload itself when 180 s), {dt:.1f} s wall; single-threaded except the "
                       f"matrix products ({blas} BLAS threads); host has {os.cpu_count()} logical cores"}
+
+
+def bind_to_gpu_node(local_rank):
+    """Before anything of this process touches the GPU: put the process on the CPUs of the NUMA node its GPU hangs off -- what
+    `numactl --cpunodebind` does for a GPU job. The device times do not care; the drop-in call (host threads narrowing the array
+    into pinned memory, two PCIe copies) takes 3.8-3.9 ms from there against 4.3-5.9 elsewhere on a two-socket host
+    (profiles/r05_dropin_numa.txt), and only a process that STARTS there gets it (the HIP runtime's own threads and pinned
+    staging stay where they were created). The node is asked of a child process (the library reads the device's PCI address),
+    so that this process is bound before it creates a single thread. REPET_BENCH_NUMA=0: leave the process where it is.
+    Returns (all CPUs it was allowed, the CPUs it is bound to) or None."""
+    if os.environ.get("REPET_BENCH_NUMA") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    import subprocess
+    allowed = sorted(os.sched_getaffinity(0))
+    code = ("import sys; sys.path[:0] = [%r]; import repet; from repet import _native; n = _native.lib().repet_device_count(); "
+            "print(' '.join(str(c) for c in repet.device_host_cpus(int(sys.argv[1]) %% max(n, 1))) if n > 0 else '')") % os.path.join(ROOT, "repet-python_amd")
+    try:
+        out = subprocess.run([sys.executable, "-c", code, str(local_rank)], capture_output=True, text=True, timeout=180)
+        cpus = sorted(int(tok) for tok in out.stdout.split())
+    except Exception:  # noqa: BLE001 -- binding is an optimisation of the host side, never a reason to fail
+        return None
+    if not cpus or len(cpus) >= len(allowed):
+        return None
+    os.sched_setaffinity(0, cpus)
+    return allowed, cpus
 
 
 def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, seconds, n_clips):
@@ -187,6 +212,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the CPU baseline FIRST, while this process may still use every CPU it was given (its BLAS threads are created here, unbound);
+    # then the process binds itself to the GPU's NUMA node, before torch / the library create a thread or pin a page
+    cpu_line = None
+    if world == 1 and not args.no_cpu_baseline and example_clip is None:
+        # a bounded sample of the same workload: the whole clip for configs 2, 3 and 4 (10-30 s of host time each), 8 of the 64
+        # clips of config 5
+        sample_s = args.cpu_seconds if args.config == 2 else args.duration
+        cpu_line = cpu_baseline(args.fs, args.channels, min(sample_s, args.duration), args.algo, 8 if args.config == 5 else 1)
+    numa = bind_to_gpu_node(local_rank)
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE {world}: the two must agree "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}, or plain python bench.py --gpus {args.gpus})")
@@ -506,10 +540,16 @@ def main():
         try:
             if args.config == 2 and args.algo == "sim" and args.duration == 180.0:
                 with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
-                    pmc = json.load(fh)["stages"][dom["name"].replace("_f16x3", "")]
+                    doc = json.load(fh)
+                pmc = doc["stages"][dom["name"].replace("_f16x3", "")]
+                import hashlib
+                with open(_native.LIB_PATH, "rb") as fh:
+                    lib_sha = hashlib.sha256(fh.read()).hexdigest()
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
                 roof["traffic_source"] = f"profiles/{PMC_FILE} (committed rocprofv3 --pmc pass of this workload; static, not measured in this run); " \
                                          "FETCH_SIZE*1024*k + WRITE_SIZE*1024 per launch, fetch correction " + pmc["fetch_correction"]
+                roof["traffic_library_sha256"] = doc.get("library_sha256")
+                roof["traffic_is_of_this_library"] = doc.get("library_sha256") == lib_sha
         except (OSError, KeyError, ValueError):
             pass
         roof["ms_per_launch"] = dom["ms"]
@@ -579,8 +619,10 @@ def main():
                 return entry
             # (where the call's host work runs matters on a two-socket host: started under `taskset -c <the GPU node's CPUs>` the
             # same call took 3.84-3.94 ms PCM-exact / 4.7-5.2 ms float64 on the box of profiles/r05_dropin_numa.txt)
-            line["host_cpus_near_gpu"] = len(repet.device_host_cpus(local_rank))
-            line["host_affinity_cpus"] = len(os.sched_getaffinity(0))
+            line["host_affinity"] = ({"bound_to_gpu_numa_node": True, "cpus": len(numa[1]), "of": len(numa[0]),
+                                      "note": "bench.py binds itself to the CPUs of its GPU's NUMA node before it touches the GPU (numactl --cpunodebind "
+                                              "for a GPU job; REPET_BENCH_NUMA=0 turns it off); the CPU baseline ran before that, on every CPU the process was given"}
+                                     if numa else {"bound_to_gpu_numa_node": False, "cpus": len(os.sched_getaffinity(0))})
             line["array_in_array_out"] = with_floor(drop_in(clip))
             line["array_in_array_out"]["note"] = ("repet.%s(audio_signal, fs) wall time: float64 NumPy in host RAM -> float64 NumPy out (host threads "
                                                   "narrow/widen through a pinned ring; fp32 samples over PCIe, their fp32 remainders behind them beside the computation)" % args.algo)
@@ -597,7 +639,7 @@ def main():
             try:
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 200)), "--warmup", str(args.warmup),
                                         "--series", "1", "--no-cpu-baseline", "--no-scatter", "--no-variants"],
-                                       env=dict(os.environ, REPET_RANK_OVERLAP="0"), capture_output=True, text=True, timeout=600)
+                                       env=dict(os.environ, REPET_RANK_OVERLAP="0", REPET_BENCH_NUMA="0"), capture_output=True, text=True, timeout=600)
                 cj = json.loads(child.stdout.strip().splitlines()[-1])
                 alone = {st["name"]: st for st in cj["stages"]}
                 n_sort = 1 << max(int(T - 1).bit_length(), 11)
@@ -650,7 +692,7 @@ def main():
             try:
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
                                         "--series", "1", "--no-cpu-baseline", "--no-scatter", "--no-variants"],     # (one timed region: a few seconds)
-                                       env=dict(os.environ, REPET_GRAM="f32"), capture_output=True, text=True, timeout=600)
+                                       env=dict(os.environ, REPET_GRAM="f32", REPET_BENCH_NUMA="0"), capture_output=True, text=True, timeout=600)
                 cj = json.loads(child.stdout.strip().splitlines()[-1])
                 gemm = [st for st in cj["stages"] if st["name"].startswith("similarity_gemm")][0]
                 line["fp32_gemm_variant"] = {"ms_per_step": cj["ms_per_step"], "gemm_ms": gemm["ms"], "gemm_TFLOP/s_fp32": gemm.get("achieved"),
@@ -658,11 +700,8 @@ def main():
                                              "note": "REPET_GRAM=f32: v_mfma_f32_32x32x2_f32, exact fp32 k-ordered accumulation (gram.hip)"}
             except Exception as exc:  # noqa: BLE001 -- a variant figure must never cost the headline
                 line["fp32_gemm_variant"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if world == 1 and not args.no_cpu_baseline and example_clip is None:
-            # a bounded sample of the same workload: the whole clip for configs 2, 3 and 4 (10-30 s of host time each), 8 of the 64
-            # clips of config 5
-            sample_s = args.cpu_seconds if args.config == 2 else args.duration
-            line["cpu_baseline"] = cpu_baseline(fs, channels, min(sample_s, args.duration), args.algo, 8 if args.config == 5 else 1)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
 
     # The multi-GPU data path (scatter -> separate -> gather over RCCL point-to-point) runs LAST and under a watchdog: the
     # headline above must reach stdout whatever that leg does on a node it has never run on. A time-out or an exception on

@@ -12,11 +12,15 @@ step() { echo "== $*"; "$@"; }
 # the diagnostic build travels with the snapshot (make -C repet-python_amd/csrc stamps, in the build container): an older one
 # than the library lacks its newest entry points, and the step that loads it would fail after everything else has run
 [ build_diag/lib_stamps.so -nt repet-python_amd/lib/librepet_hip.so ] || { echo "build_diag/lib_stamps.so is older than the library: run 'make -C repet-python_amd/csrc stamps' first"; exit 1; }
-step timeout 1800 bash tools/round_profile.sh > gpurun_out/round/round.log 2>&1
+# the PMC passes FIRST: the bench lines written afterwards carry roofline.traffic from THIS call's counters (the file they read,
+# profiles/<tag>_pmc_traffic.json, is written here on the box; it records the sha256 of the library it was measured on, and so
+# does the bench line)
 step timeout 1200 bash tools/pmc_profile.sh "gpurun_out/pmc_$tag" > "gpurun_out/pmc_$tag/pmc.log" 2>&1
 step timeout 120 python3 tools/pmc_traffic.py "gpurun_out/pmc_$tag" gpurun_out/round/pmc_traffic.json > gpurun_out/round/pmc_traffic.log 2>&1
+cp gpurun_out/round/pmc_traffic.json "profiles/${tag}_pmc_traffic.json"
 step timeout 120 python3 tools/pmc_summary.py "gpurun_out/pmc_$tag" > gpurun_out/round/pmc_summary.txt 2>&1
 find "gpurun_out/pmc_$tag" -name "*.csv" -size +2M -delete
+step timeout 1800 bash tools/round_profile.sh > gpurun_out/round/round.log 2>&1
 step timeout 300 python3 tools/stream_bench.py > gpurun_out/round/stream_latency.json 2> gpurun_out/round/stream.err
 step timeout 300 bash tools/valu_rates.sh > gpurun_out/round/valu_rate.log 2>&1
 cp gpurun_out/valu_rate.txt gpurun_out/round/valu_rate.txt

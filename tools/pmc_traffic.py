@@ -65,6 +65,8 @@ doc = {"_about": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tool
                  "(repet.sim, 180 s, 44.1 kHz stereo), mean per launch. Bytes = WRITE_SIZE*1024 + FETCH_SIZE*1024*k, k = 2 for kernels whose "
                  "reads are 16-byte-per-lane streams (gfx950 counts those at one half), k = 1 (uncalibrated) for narrower loads and gathers. "
                  "Infinity-Cache hits are included in FETCH_SIZE (MI355X_MICROARCH.md), so this is an upper bound on HBM traffic.",
+       "library_sha256": __import__("hashlib").sha256(open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
+                                                                                   "repet-python_amd", "lib", "librepet_hip.so"), "rb").read()).hexdigest(),
        "stages": stages}
 for stage, need in COMPULSORY.items():
     if stage in stages:

@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 900 python3 bench.py > "$out/bench_cfg2.json" 2> "$out/bench_cfg2.err"
 for cfg in 3 4 5; do
-  timeout 600 python3 bench.py --config $cfg --no-cpu-baseline > "$out/bench_cfg$cfg.json" 2> "$out/bench_cfg$cfg.err"
+  timeout 900 python3 bench.py --config $cfg > "$out/bench_cfg$cfg.json" 2> "$out/bench_cfg$cfg.err"
 done
 for cfg in 2 3 4 5; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_cfg$cfg" -- python3 bench.py --config $cfg --steps 20 --warmup 5 --series 1 --no-cpu-baseline --no-scatter --no-variants > "$out/prof_cfg$cfg.log" 2>&1
