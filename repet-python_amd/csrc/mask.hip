@@ -132,6 +132,8 @@ static void dispatch_net(int max_n, Fn&& fn) {
     if (max_n <= 2) fn(std::integral_constant<int, 2>{});
     else if (max_n <= 4) fn(std::integral_constant<int, 4>{});
     else if (max_n <= 8) fn(std::integral_constant<int, 8>{});
+    else if (max_n <= 10) fn(std::integral_constant<int, 10>{});      // `simonline`'s default: a 10-s buffer holds ten peaks 1 s apart
+    else if (max_n <= 12) fn(std::integral_constant<int, 12>{});      // (45 / 52 min-max instructions against the 16-wire network's 82)
     else if (max_n <= 16) fn(std::integral_constant<int, 16>{});
     else if (max_n <= 24) fn(std::integral_constant<int, 24>{});
     else if (max_n <= 32) fn(std::integral_constant<int, 32>{});
@@ -260,6 +262,106 @@ __global__ __launch_bounds__(256) void mask_sim_kernel(MaskArgs a, const int* __
             if (a.X) a.X[o] = make_float2(x_own.x * m, x_own.y * m);
         }
     }
+}
+
+// The same selection with FOUR bins per lane and a RUN of frames per workgroup (round 5; lists of at most 16 entries:
+// `simonline`'s ten, short clips of `sim`). With one workgroup per frame the stage was bound by neither bytes (0.42 of HBM at
+// cfg 5) nor instructions nor the gather path (16-byte gathers alone: -6 %), but by dependent round trips at the occupancy
+// the registers allow: launch -> the frame's list -> its gathers -> the store, three latencies per workgroup that lives 4 us,
+// twenty waves per CU. Here a workgroup walks kRun consecutive frames of one (clip, channel): the NEXT frame's list is
+// fetched while the current frame's gathers are in flight, so a frame costs one round trip, and a lane owns bins
+// 4 l .. 4 l + 3 of a 256-bin block -- every slot ONE 16-byte load per lane, four networks on the four components.
+// The same values through the same networks: bit-identical to mask_sim_kernel (test_wide_mask_kernel_gives_the_same_bits).
+// Measured at cfg 5 (64 x 30 s, ten-entry lists), stage ms: one bin per lane, 16-wire network 0.567; four bins per lane 0.537;
+// + runs of frames with the list prefetched 0.511; + the 10-wire network (45 instructions against 82) 0.47 (0.50 on the
+// one-bin kernel). Tried and dropped: XCD-ordered units (a clip's frames on ONE XCD: 0.557 -- the gathers' locality is not the
+// bound: all of them from one row, 0.495); a second register set with the next frame's gathers in flight under the networks
+// (0.489: three waves per SIMD instead of four). Without its stores the stage takes 0.40: it is the min / max issue rate and
+// 0.68 GB of mask plane, in sum rather than in overlap.
+constexpr int kWideRun = 16;
+template <int NET>
+__global__ __launch_bounds__(256) void mask_sim_wide_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
+                                                            const int* __restrict__ count, int64_t first_frame, unsigned n_frames) {
+    static_assert(NET >= 2 && NET <= 64, "wide selection: short lists only");
+    const int c = blockIdx.y;
+    a.V += blockIdx.z * a.batch_stride;
+    if (a.X) a.X += blockIdx.z * a.batch_stride;
+    if (a.mask) a.mask += blockIdx.z * a.batch_stride;
+    idx += blockIdx.z * a.idx_batch_stride;
+    count += blockIdx.z * a.cnt_batch_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nbins = a.F - 1;                         // a multiple of 256 (launch_mask_sim); the Nyquist bin: mask_sim_nyquist_kernel
+    const int nfb = nbins >> 8;
+    const float* Vc = a.V + c * a.chan_stride;
+    const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = channel_rsrc(Vc, a.chan_stride);
+    const unsigned f_begin = blockIdx.x * kWideRun, f_end = min(f_begin + kWideRun, n_frames);
+    // the list of a frame, as the gathers need it: its length (wave-uniform) and entry `lane` (rows of idx hold >= 128 entries)
+    auto fetch_list = [&](int64_t t, int& n, int& e) {
+        if (t < first_frame) { n = -1; e = 0; return; }                         // warm-up frame: nothing to gather
+        const int64_t r = t - first_frame;
+        n = count[r];
+        e = idx[r * (int64_t)idx_pitch + lane];
+    };
+    for (int fb = wave; fb < nfb; fb += 4) {
+        const int f0 = (fb << 8) + 4 * lane;
+        const int bin_bytes = f0 * 4;
+        int n_next, e_next;
+        fetch_list(a.frame0 + f_begin, n_next, e_next);
+        for (unsigned fr = f_begin; fr < f_end; ++fr) {
+            const int64_t t = a.frame0 + fr;
+            const int n = __builtin_amdgcn_readfirstlane(n_next), e = e_next;
+            if (fr + 1 < f_end) fetch_list(t + 1, n_next, e_next);              // in flight beside this frame's gathers
+            const int64_t o = c * a.chan_stride + t * a.FS + f0;
+            if (n < 0) {                                                        // online warm-up frames contribute nothing (repet.py:834)
+                if (a.mask) *reinterpret_cast<float4*>(a.mask + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.X) {
+                    float4 x01 = *reinterpret_cast<const float4*>(a.X + o), x23 = *reinterpret_cast<const float4*>(a.X + o + 2);
+                    *reinterpret_cast<float4*>(a.X + o) = make_float4(x01.x * 0.f, x01.y * 0.f, x01.z * 0.f, x01.w * 0.f);
+                    *reinterpret_cast<float4*>(a.X + o + 2) = make_float4(x23.x * 0.f, x23.y * 0.f, x23.z * 0.f, x23.w * 0.f);
+                }
+                continue;
+            }
+            // byte offset of slot `lane`'s row: the list entry, or the low / high pad row past the list's end (SlotOffsets)
+            const int low_pads = (NET - n) >> 1;
+            int off = lane < n ? e * row_bytes : pad_bytes + ((lane - n < low_pads) ? 0 : row_bytes);
+            asm volatile("" : "+v"(off));
+            const float4 v_own = *reinterpret_cast<const float4*>(Vc + t * a.FS + f0);
+            float4 x01 = make_float4(0.f, 0.f, 0.f, 0.f), x23 = x01;
+            if (a.X) { x01 = *reinterpret_cast<const float4*>(a.X + o); x23 = *reinterpret_cast<const float4*>(a.X + o + 2); }
+            float4 w[NET];
+#pragma unroll
+            for (int q = 0; q < NET; ++q) {
+                const int k = MedianNet<NET>::kLoadOrder[q];
+                w[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bin_bytes, __builtin_amdgcn_readlane(off, k), 0));
+            }
+            float med[4];
+            if (n == 0) { med[0] = med[1] = med[2] = med[3] = __uint_as_float(0x7fc00000u); }      // np.median of an empty slice
+            else {
+                med[0] = median_network<NET>(n, [&](int k) { return w[k].x; });
+                med[1] = median_network<NET>(n, [&](int k) { return w[k].y; });
+                med[2] = median_network<NET>(n, [&](int k) { return w[k].z; });
+                med[3] = median_network<NET>(n, [&](int k) { return w[k].w; });
+            }
+            const float m0 = soft_mask(v_own.x, med[0], f0, a.cutoff), m1 = soft_mask(v_own.y, med[1], f0 + 1, a.cutoff);
+            const float m2 = soft_mask(v_own.z, med[2], f0 + 2, a.cutoff), m3 = soft_mask(v_own.w, med[3], f0 + 3, a.cutoff);
+            if (a.mask) *reinterpret_cast<float4*>(a.mask + o) = make_float4(m0, m1, m2, m3);
+            if (a.X) {
+                *reinterpret_cast<float4*>(a.X + o) = make_float4(x01.x * m0, x01.y * m0, x01.z * m1, x01.w * m1);
+                *reinterpret_cast<float4*>(a.X + o + 2) = make_float4(x23.x * m2, x23.y * m2, x23.z * m3, x23.w * m3);
+            }
+        }
+    }
+    // (the Nyquist bin of a warm-up frame: mask_sim_kernel's emit(0) wrote all F bins; here bin F - 1 of frames < first_frame)
+    if (first_frame > a.frame0 + f_begin && threadIdx.x < kWideRun) {
+        const int64_t t = a.frame0 + f_begin + threadIdx.x;
+        if (t < first_frame && f_begin + threadIdx.x < f_end) emit(a, c, t, a.F - 1, 0.f);
+    }
+}
+// REPET_MASK_WIDE=0: the one-bin-per-lane kernel for every list length (agreement test / A-B)
+static bool mask_wide_enabled() {
+    static const bool on = [] { const char* e = getenv("REPET_MASK_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // Rank-domain form of the kernel above (rank.hip): a wave owns 128 bins of a frame, two per lane. The gather reads one
@@ -426,6 +528,10 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                         const int combos = m.n_channels * ((m.F - 1) >> 7);
                         hipLaunchKernelGGL(mask_sim_rank_kernel<NET>, dim3((unsigned)(8 * ceil_div(combos, 8) * n_quads)), dim3(256), 0, s,
                                            m, idx, idx_pitch, count, n_quads);
+                    } else if (NET <= 16 && ((m.F - 1) & 255) == 0 && (m.FS & 3) == 0 && mask_wide_enabled()) {
+                        if constexpr (NET <= 16)
+                            hipLaunchKernelGGL(mask_sim_wide_kernel<NET>, dim3((unsigned)ceil_div(n_launch, kWideRun), (unsigned)m.n_channels, nb), dim3(256), 0, s,
+                                               m, idx, idx_pitch, count, first_frame, n_launch);
                     } else
                         hipLaunchKernelGGL((mask_sim_kernel<NET, true>), dim3(n_launch, (unsigned)m.n_channels, nb), dim3(256), 0, s,
                                            m, idx, idx_pitch, count, first_frame);

@@ -651,6 +651,34 @@ def test_fft_paths_agree():
     assert rms_err(outs[0], outs[2]) < 2e-6
 
 
+def test_wide_mask_kernel_gives_the_same_bits():
+    """Lists of at most 32 similar frames (`simonline`, short clips of `sim`) go through mask_sim_wide_kernel: four bins per lane,
+    one 16-byte gather per list slot. REPET_MASK_WIDE=0 keeps the one-bin-per-lane kernel: the same values through the same
+    selection networks, so every output must be IDENTICAL -- in place and with the mask as a plane, a batch context included."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth, synth_groove; "
+            "x = synth(31, 44100, 2, 3); outs = [repet.simonline(x, 44100), repet.sim(x[:20 * 44100], 44100)]; "
+            "g = synth_groove(26, 16000, 2, 2); outs += [repet.simonline(g, 16000), repet.sim(g, 16000)]; "
+            "m = synth(14, 22050, 1, 8); outs += [repet.sim(m, 22050)]; "
+            "c = repet.Context(0); c.upload_batch(np.stack([synth(13, 16000, 2, s) for s in range(3)])); c.execute('simonline', repet.derive_params(16000)); "
+            "outs.append(c.download()); np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+    outs = []
+    for wide, plane in (("1", ""), ("0", ""), ("1", "0"), ("0", "0")):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_wide_{wide}{plane}_{os.getpid()}.npy")
+        env = dict(os.environ, REPET_MASK_WIDE=wide)
+        if plane:
+            env["REPET_MASK_PLANE"] = plane
+        subprocess.check_call([sys.executable, "-c", code, out], env=env)
+        outs.append(np.load(out))
+        os.remove(out)
+    for other in outs[1:]:
+        assert np.array_equal(outs[0], other, equal_nan=True)
+
+
 def test_mask_plane_gives_the_same_bits():
     """Three ways to apply the soft mask, one result. (a) multiplied into the spectrum in place (REPET_MASK_PLANE=0);
     (b) kept as a plane of its own and applied by the inverse STFT while it fetches the spectrum (REPET_MASK_PLANE=p);

@@ -16,7 +16,7 @@ import os
 import random
 import sys
 
-SIZES = (2, 4, 8, 16, 24, 32, 48, 64, 80, 100, 128)
+SIZES = (2, 4, 8, 10, 12, 16, 24, 32, 48, 64, 80, 100, 128)
 
 
 def batcher(n):
