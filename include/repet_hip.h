@@ -68,13 +68,15 @@ typedef struct repet_params {
 } repet_params;
 
 /* repet_params.flags, bit 0 -- strict reference behaviour on samples that are not finite. repet.py never looks at its input
- * (:125, :1220): a NaN sample makes the frames that hold it NaN and `sim` / `simonline` confine the damage to those frames,
- * the period family spreads it through the beat spectrum and the period medians. By default the drop-in REFUSES such input
- * (REPET_ERR_BAD_ARG, "contains NaN or infinite samples"). With this flag repet_run / repet_run_batch let the samples
- * through: `sim` and `simonline` then return what the reference returns (NaN exactly on the samples of the affected frames,
- * every other sample as without them -- tested against the oracle, which equals the reference bit for bit on such input);
- * `original` / `extended` / `adaptive` answer REPET_ERR_BAD_ARG with a message that says so (their NaN pattern depends on
- * np.median's NaN rule and on pocketfft's inf arithmetic). Context calls: repet_ctx_set_strict_reference. */
+ * (:125, :1220): a NaN sample makes the frames that hold it NaN; `sim` / `simonline` confine the damage to those frames; the
+ * period family turns the beat spectrum of the clip / segment / windows NaN (period = period_range[0] + 1 there) and, through
+ * np.median's NaN rule, marks the same position of EVERY period. By default the drop-in REFUSES such input (REPET_ERR_BAD_ARG,
+ * "contains NaN or infinite samples"). With this flag repet_run / repet_run_batch let the samples through and all five variants
+ * return what the reference returns for NaN samples: NaN positions equal, every other sample within the usual bar, periods and
+ * similar-frame lists equal (tested against the oracle, which equals the reference bit for bit on such input). An INFINITE
+ * sample is treated as a NaN sample: for `sim` / `simonline` that is the reference's result; for the period family the
+ * reference's own result depends on where pocketfft's butterflies meet inf - inf, and the engine's NaN samples
+ * are a superset of the reference's. Context calls: repet_ctx_set_strict_reference. */
 #define REPET_FLAG_STRICT_REFERENCE 1
 
 /* The nine module-level parameters of the reference (repet.py:42-63), for hosts that do not keep them as Python

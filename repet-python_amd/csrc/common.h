@@ -45,6 +45,8 @@ struct StftArgs {
     int64_t batch_mean_stride;                    // elements between clips in Vm/Vn/P (= Tpad*FS)
 };
 hipError_t launch_stft(const StftArgs& a, hipStream_t s);
+// strict reference mode: X and |X| = NaN in every bin of the frames that hold an infinite sample (stft.hip)
+hipError_t launch_infinite_frames_fix(const StftArgs& a, hipStream_t s);
 
 // Cross-fade weight of sample n of a segment of `extended` (repet.py:380-414). The reference fades IN PLACE: every
 // segment after the first multiplies what has been accumulated under its first `overlap` samples by the falling

@@ -351,6 +351,7 @@ int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64
     a.n_batch = B; a.batch_sample_stride = batch_sample_stride; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
     a.batch_mean_stride = g.Tpad * g.FS;
     HIP_TRY(launch_stft(a, c->stream));
+    if (c->input_not_finite) HIP_TRY(launch_infinite_frames_fix(a, c->stream));      // (strict reference mode only: see the kernel)
     const double in_b = 4.0 * n * g.C, spec_b = (8.0 + 4.0) * g.F * g.T * g.C, mean_b = 4.0 * g.F * g.T;
     mark(c, "stft", B * (in_b + spec_b + mean_b), 0);
     return REPET_OK;
@@ -795,9 +796,7 @@ int run_algo_one(repet_ctx* c, int algo, const repet_params* p) {
 int run_algo(repet_ctx* c, int algo, const repet_params* p) {
     c->clip_base = 0;
     if (c->win_total > 0) return fail(REPET_ERR_BAD_ARG, "the resident samples are a window of a longer clip: only repet_ctx_execute_extended_range applies");
-    if (c->input_not_finite && algo != REPET_SIM && algo != REPET_SIMONLINE)
-        return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples: strict_reference reproduces repet.py on such input for sim and "
-                                       "simonline only (the period family spreads them through the beat spectrum and np.median's NaN rule)");
+
     if (c->n_clips <= 1 || algo == REPET_SIMONLINE || algo == REPET_ORIGINAL) return run_algo_one(c, algo, p);
     repet_timing* timing = c->timing;
     c->timing = nullptr;                       // per-stage marks would repeat per clip: only the total is reported

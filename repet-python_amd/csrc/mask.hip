@@ -59,12 +59,22 @@ __device__ __forceinline__ void gather_in_network_order(float (&a)[N], Load load
     ((a[MedianNet<N>::kLoadOrder[Q]] = load((int)MedianNet<N>::kLoadOrder[Q])), ...);
 }
 
-template <int N, class Load>
+// NANS: np.median's rule -- a NaN among the values makes the median NaN (the min / max instructions of the network drop a
+// NaN operand). The values are magnitudes (>= 0, possibly +inf) and the pads -1 / +inf, so their plain sum is NaN exactly when
+// one of them is: N - 1 additions. The period family asks for it (a NaN frame -- strict reference mode -- marks its position in
+// every period, as in repet.py); the lists of `sim` never hold a NaN frame.
+template <int N, bool NANS = false, class Load>
 __device__ __forceinline__ float median_network(int n, Load load) {
     float a[N];
     gather_in_network_order<N>(a, load, std::make_index_sequence<N>{});
+    float total = 0.f;
+    if constexpr (NANS) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) total += a[k];
+    }
     MedianNet<N>::run(a);
-    return (n & 1) ? a[N / 2 - 1] : 0.5f * (a[N / 2 - 1] + a[N / 2]);
+    const float med = (n & 1) ? a[N / 2 - 1] : 0.5f * (a[N / 2 - 1] + a[N / 2]);
+    return (NANS && total != total) ? total : med;
 }
 
 // Order statistics by bisection over the (non-negative) float bit patterns (lists longer than 128).
@@ -93,11 +103,17 @@ __device__ __forceinline__ float median_bisect(int n, Load load) {
 
 // NET = network size compiled into the kernel (0 = bisection). One instantiation per size keeps the
 // register allocation of the small networks small (occupancy) instead of the maximum over all sizes.
-template <int NET, class Load>
+template <int NET, bool NANS = false, class Load>
 __device__ __forceinline__ float median_of(int n, Load load) {
     if (n <= 0) return __uint_as_float(0x7fc00000u);     // np.median of an empty slice
-    if constexpr (NET == 0) return median_bisect(n, load);
-    else return median_network<NET>(n, load);
+    if constexpr (NET == 0) {
+        if constexpr (NANS) {
+            float total = 0.f;
+            for (int q = 0; q < n; ++q) total += load(q);
+            if (total != total) return total;
+        }
+        return median_bisect(n, load);
+    } else return median_network<NET, NANS>(n, load);
 }
 
 // Row gather through a buffer resource: one shared per-lane VGPR offset (the bin) plus a wave-uniform
@@ -582,7 +598,7 @@ __global__ __launch_bounds__(256) void mask_adaptive_kernel(MaskArgs a, const in
         const float v_own = Vc[t * a.FS + fc];
         float2 x_own = make_float2(0.f, 0.f);
         if (a.X) x_own = a.X[o];
-        const float med = median_of<NET>(n_it, [&](int k) {
+        const float med = median_of<NET, true>(n_it, [&](int k) {
             return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
         if (active) {
             const float m = soft_mask(v_own, med, f, a.cutoff);
@@ -616,7 +632,7 @@ __device__ __forceinline__ float period_median(int n, const RowGather& g, int ba
     // opaque copy: keeps the per-slot row-offset selection (scalar ALU) inside the caller's loop
     int n_it = n;
     asm volatile("" : "+s"(n_it));
-    return median_of<NET>(n_it, [&](int k) {
+    return median_of<NET, true>(n_it, [&](int k) {
         return g(k < n_it ? base_bytes + k * step_bytes : pad_offset<NET>(k, n_it, pad_bytes, row_bytes)); });
 }
 

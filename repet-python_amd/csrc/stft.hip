@@ -1235,6 +1235,47 @@ static bool use_wave_kernels() {
 constexpr int kStftFramesPerWg = 8;
 constexpr int kOlaWaveRun = 15;      // + the frame before = 16 frames per workgroup
 
+// Strict reference mode (REPET_FLAG_STRICT_REFERENCE): a frame that holds an INFINITE sample. What repet.py makes of it is
+// decided inside pocketfft: every bin has a component at +-inf by the transform's definition, np.abs of (inf, NaN) is inf, and
+// an inf magnitude is an ordinary, largest member of a median -- but where the butterflies meet inf - inf BOTH components turn
+// NaN, and that depends on the sample's position in the frame (measured, 24-s clip, `original`: -inf at one position gives NaN
+// in its own three frames only, +inf at another gives NaN at that position of all 23 periods, exactly like a NaN sample). The
+// butterflies here meet inf - inf elsewhere. Instead of one arbitrary mix for another, an infinite sample is TREATED AS NaN:
+// this pass, run behind the forward kernel only when the uploaded host array held samples that are not finite, makes the
+// spectrum and the magnitudes of such a frame NaN in every bin. For `sim` / `simonline` that is the reference's result (NaN on
+// the frame's samples, nothing else changes); for the period family it is the reference's result where pocketfft produced NaN
+// bins and a superset of its NaN samples where it did not. One wavefront per frame and channel.
+__global__ __launch_bounds__(64) void infinite_frames_kernel(StftArgs a) {
+    const int64_t t = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x, C = a.n_channels, F = a.W / 2 + 1;
+    const int64_t start = t * a.H - (a.centred ? a.W / 2 : 0);
+    const float* clip = a.audio + (a.sample_offset + b * a.batch_sample_stride) * C;
+    for (int c = 0; c < C; ++c) {
+        bool has_nan = false, has_inf = false;
+        for (int i = lane; i < a.W; i += 64) {
+            const int64_t sidx = start + i;
+            if (sidx < 0 || sidx >= a.n_samples) continue;
+            const float x = clip[sidx * C + c];
+            has_nan |= x != x;
+            has_inf |= fabsf(x) == INFINITY;
+        }
+        const bool any_nan = __ballot(has_nan) != 0, any_inf = __ballot(has_inf) != 0;
+        if (any_nan || !any_inf) continue;                   // (a NaN sample has made every bin NaN already)
+        float2* Xrow = a.X + b * a.batch_spec_stride + c * a.chan_stride + t * a.FS;
+        float* Vrow = a.V + b * a.batch_spec_stride + c * a.chan_stride + t * a.FS;
+        const float nanf_ = __uint_as_float(0x7fc00000u);
+        for (int f = lane; f < a.FS; f += 64) {
+            Vrow[f] = f < F ? nanf_ : 0.f;
+            Xrow[f] = f < F ? make_float2(nanf_, nanf_) : make_float2(0.f, 0.f);
+        }
+    }
+}
+hipError_t launch_infinite_frames_fix(const StftArgs& a, hipStream_t s) {
+    if (a.T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(infinite_frames_kernel, dim3((unsigned)a.T, (unsigned)(a.n_batch > 0 ? a.n_batch : 1)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_stft(const StftArgs& a, hipStream_t s) {
     if (a.T <= 0) return hipSuccess;
     // (also for the handful of frames of a streaming push: the stream's output must equal the offline result bit for bit)

@@ -35,8 +35,9 @@ buffer_length = 10
 
 # Not a parameter of the reference: what to do with samples that are NOT FINITE. repet.py computes on (a NaN sample makes the
 # frames that hold it NaN; repet.py:125 has no input check). False (default): such input raises ValueError. True: the samples
-# are let through and ``sim`` / ``simonline`` return exactly what the reference returns -- NaN on the samples of the affected
-# frames, everything else as without them; the period family still raises. Read at call time like the others.
+# are let through and every variant returns what the reference returns for NaN samples (``sim`` / ``simonline``: NaN on the
+# samples of the affected frames only; the period family: also at the same position of every period, and the period
+# ``period_range[0] + 1``); an infinite sample is treated as NaN. Read at call time like the others.
 strict_reference = False
 
 _device = 0  # HIP device used by the one-shot calls

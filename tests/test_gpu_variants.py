@@ -151,7 +151,7 @@ def test_strict_reference_reproduces_repet_py_on_samples_that_are_not_finite(alg
     hold such a sample, every other sample as the float64 oracle gives it (the oracle equals the reference bit for bit on
     this kind of input: NaN positions equal, max-abs 0.0 elsewhere -- checked against /root/reference when the strict mode was
     built), and the similar-frame lists of every other frame equal to the oracle's. 44.1 kHz / 40 s takes the rank-domain
-    median: the NaN / inf magnitudes go through the column sort. The period family keeps refusing, with a message of its own."""
+    median: the NaN / inf magnitudes go through the column sort. (The period family: the next test.)"""
     monkeypatch.setattr(repet, "strict_reference", True)
     x = synth(seconds, fs, channels, 11).astype(dtype)
     n = len(x)
@@ -181,12 +181,60 @@ def test_strict_reference_reproduces_repet_py_on_samples_that_are_not_finite(alg
     assert np.array_equal(getattr(repet, algo)(x, fs), got, equal_nan=True)      # the one-shot call (flag in repet_params) gives the same
     if algo == "sim":
         assert np.array_equal(repet.run_batch("sim", [x], fs)[0], got, equal_nan=True)
-    for other in ("original", "extended", "adaptive"):
-        with pytest.raises(ValueError, match="strict_reference reproduces"):
-            getattr(repet, other)(x, fs)
     monkeypatch.setattr(repet, "strict_reference", False)
     with pytest.raises(ValueError, match="NaN or infinite"):
         getattr(repet, algo)(x, fs)
+
+
+@pytest.mark.parametrize("algo", ["original", "extended", "adaptive"])
+@pytest.mark.parametrize("kind", ["nan", "inf"])
+def test_strict_reference_period_family(algo, kind, monkeypatch):
+    """The period family on samples that are not finite, as repet.py has it (measured against the unmodified reference: the
+    oracle equals it bit for bit on these inputs). A NaN sample makes its frames NaN, the beat spectrum of its clip / segment /
+    windows NaN at every lag (the autocorrelation goes through an FFT over time: repet.py:1108-1139), hence the period
+    `period_range[0] + 1` there, and -- np.median's NaN rule -- NaN at the SAME position of every period (`original`: 23 runs of
+    three hops on a 24-s clip, one per period). kind = nan: NaN positions equal, every other sample within the bar, every
+    period equal. An INFINITE sample is treated as NaN (what the reference makes of one is pocketfft's butterfly order: of the
+    two below, one marks every period and the other only its own frames): the result equals the engine's result for the same
+    clip with NaN in those places, the periods still equal the reference's, and the reference's NaN samples are among the
+    engine's."""
+    monkeypatch.setattr(repet, "strict_reference", True)
+    fs = 16000
+    x = synth(24 if algo != "extended" else 36, fs, 2, 3)
+    n = len(x)
+    places = [(n // 3, 0)] if kind == "nan" else [((2 * n) // 3 + 777, 1), ((5 * n) // 6, 0)]
+    for k, (at, ch) in enumerate(places):
+        x[at, ch] = np.nan if kind == "nan" else (np.inf if k == 0 else -np.inf)
+    tr = orc.Trace()
+    with np.errstate(all="ignore"):
+        want = orc.ALGORITHMS[algo](x, fs, None, tr)
+    p = repet.derive_params(fs)
+    ctx = repet.Context(0)
+    ctx.set_strict_reference(True)
+    ctx.upload(x)
+    ctx.execute(algo, p)
+    got = ctx.download()
+    if algo == "original":
+        assert ctx.last_periods(1)[0] == tr.items["repeating_period"] == p.period_lo + 1
+    elif algo == "extended":
+        assert np.array_equal(ctx.last_periods(64), tr.items["segment_periods"])
+    else:
+        assert np.array_equal(ctx.last_periods(ctx.last_frame_count()), tr.items["repeating_periods"])
+    bad = np.isnan(want)
+    assert bad.any() and not bad.all() and not np.isinf(want).any() and not np.isinf(got).any()
+    if kind == "nan":
+        assert np.array_equal(np.isnan(got), bad)
+        assert rms_err(got[~bad], want[~bad]) <= 2e-5
+    else:
+        as_nan = np.where(np.isinf(x), np.nan, x)
+        ctx.upload(as_nan)
+        ctx.execute(algo, p)
+        assert np.array_equal(ctx.download(), got, equal_nan=True)
+        assert not np.any(bad & ~np.isnan(got))                  # the reference's NaN samples are among the engine's
+        both = ~bad & ~np.isnan(got)
+        assert rms_err(got[both], want[both]) <= 2e-5
+    ctx.close()
+    assert np.array_equal(getattr(repet, algo)(x, fs), got, equal_nan=True)
 
 
 def test_stated_limits_of_the_engine():
