@@ -205,7 +205,10 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     on_gpu = dist.get_backend() != "gloo"
     dev = torch.device("cuda", device if device is not None else rank) if on_gpu else torch.device("cpu")
     stage = torch.device("cuda", stage_device) if (stage_device is not None and not on_gpu) else None
-    engine_device = dev.index or 0 if on_gpu else (stage_device if stage_device is not None else (device or 0))
+    if on_gpu:
+        engine_device = dev.index or 0
+    else:
+        engine_device = stage_device if stage_device is not None else (device or 0)
     fn = separate_fn or _engine_separate(algo, engine_device)
     tdtype = torch.float32 if np.dtype(wire_dtype) == np.float32 else torch.float64
     t_start = time.perf_counter()
