@@ -380,14 +380,13 @@ __global__ __launch_bounds__(64) void periods_kernel(const float* __restrict__ b
     const float* b = beat + (int64_t)c * pitch;
     float best = -INFINITY;
     int arg = 0x7fffffff;
-    bool has_nan = false;
     int nan_at = 0x7fffffff;
     for (int l = lo + lane; l < hi; l += 64) {
         const float v = b[l];
         // a value that is not finite: repet.py's autocorrelation goes through an FFT over time (:1108-1139), so ONE such power
         // spectrum makes every lag NaN and np.argmax returns index 0 -- here the sums of the lags that pair the frame are inf or
         // NaN, the others finite (none of those inside the searched range): any non-finite value means "first lag"
-        if (!(fabsf(v) <= 3.4028234664e38f)) { has_nan = true; nan_at = lo; continue; }
+        if (!(fabsf(v) <= 3.4028234664e38f)) { nan_at = lo; continue; }
         if (v > best) { best = v; arg = l; }
     }
     for (int off = 32; off > 0; off >>= 1) {
