@@ -444,20 +444,35 @@ struct UnitRowsArgs {
 // while 256 threads hold ONE radix-4 butterfly each per pass of a 1024-point transform: loads in one round trip (a stereo
 // frame's samples and remainders as one 16-byte load per thread and point pair, both channels at once), five in-place
 // Stockham passes in LDS with two barriers each, the split pass and the magnitude sums in registers (a thread owns bins
-// tid + 256 q), block-wide norm. LDS: twiddles exp(-2 pi i m / M) [M] and the transform [M]: 32 KB at W = 2048.
+// tid + 256 q), block-wide norm. LDS at W <= 2048 (round 5): twiddles exp(-2 pi i m / M) [M / 2] and TWO transforms [2][M] --
+// the channels of a stereo frame go through the passes together -- 40 KB, 125 VGPRs: four workgroups per CU as before,
+// the chain of passes walked once per frame instead of once per channel (peaks + sort at cfg 2: 0.244 -> 0.237 ms, same bits).
 // KQ: radix-4 butterflies per thread and pass = ceil(M / 1024): 1 for W <= 2048 (few registers: four workgroups per CU), 4 up to W = 8192
 template <int KQ>
-__global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
+__global__ __launch_bounds__(256, KQ == 1 ? 4 : 1) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
     constexpr int kWgQ = KQ;
+    constexpr int kCP = KQ == 1 ? 2 : 1;        // channels per pass (two transforms of up to 1 024 points fit the LDS beside the twiddles)
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
-    __shared__ double red[4];
     const ExactSource& s = x.src;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = s.W, M = W >> 1, F = s.F, C = s.n_channels;
     if (x.stats[11] >= x.stats[10]) return;
-    double2* tw = reinterpret_cast<double2*>(wg_smem);
-    double2* Z = tw + M;
-    for (int k = tid; k < M; k += 256) tw[k] = s.twiddle64[2 * k];
+    // twiddles exp(-2 pi i m / M): the first half only where two transforms share the LDS (w^(m + M/2) = -w^m, exact), so that
+    // a workgroup takes 8 + 2 x 16 KB = a quarter of the CU's LDS and four of them -- every queued frame of a clip at once --
+    // fit (the block sum at the end borrows the transform's space)
+    constexpr bool kHalfTw = KQ == 1;
+    const int n_tw = kHalfTw ? M >> 1 : M;
+    double2* tw_lds = reinterpret_cast<double2*>(wg_smem);
+    double2* Z = tw_lds + n_tw;
+    double* red = reinterpret_cast<double*>(Z);
+    for (int k = tid; k < n_tw; k += 256) tw_lds[k] = s.twiddle64[2 * k];
+    auto tw = [&](int m) -> double2 {
+        if constexpr (!kHalfTw) return tw_lds[m];
+        else {
+            const double2 v = tw_lds[m & ((M >> 1) - 1)];
+            return (m & (M >> 1)) ? make_double2(-v.x, -v.y) : v;
+        }
+    };
     const unsigned int n_frames = x.stats[10];
     const int nq = (M + 255) >> 8;            // point pairs per thread (1 .. 16 for M = 4096: loops below run over q < nq)
     // (frames dealt by position: a shared cursor hands out about 88 slots per microsecond, and the 1 024 workgroups' first
@@ -483,17 +498,26 @@ __global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
         double acc[kWgQ * 4 + 1];
 #pragma unroll
         for (int q = 0; q < kWgQ * 4 + 1; ++q) acc[q] = 0.0;
-        for (int c = 0; c < C; ++c) {
-            // this channel's windowed points, natural order (no branch around a load; positions frame-relative, 32-bit)
+        // Channels in PAIRS (windows up to 2048: two transforms fit the LDS): a transform is a chain of dependent passes with two
+        // barriers each, and a workgroup's life IS that chain (all queued frames run at once, one per workgroup) -- with the two
+        // channels of a stereo frame in the same passes the chain is walked once instead of twice (round 5: 33 -> 19 us alone).
+        // The butterflies, their order and the order in which the channels' magnitudes are added are unchanged: the same bits.
+        for (int c0 = 0; c0 < C; c0 += kCP) {
+            const int nc = min(kCP, C - c0);
+            // the channels' windowed points, natural order (no branch around a load; positions frame-relative, 32-bit)
             for (int q0 = 0; q0 < nq; q0 += 4) {
-                float h0[4], h1[4], l0[4], l1[4];
+                float h0[kCP][4], h1[kCP][4], l0[kCP][4], l1[kCP][4];
                 double2 w[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = min(tid + 256 * (q0 + u), M - 1);
                     const int a0 = min(max(2 * r, rel_lo), rel_hi - 1), a1 = min(max(2 * r + 1, rel_lo), rel_hi - 1);
-                    h0[u] = frame_hi[a0 * C + c]; h1[u] = frame_hi[a1 * C + c];
-                    l0[u] = frame_lo[a0 * C + c]; l1[u] = frame_lo[a1 * C + c];
+#pragma unroll
+                    for (int cc = 0; cc < kCP; ++cc) {
+                        const int c = min(c0 + cc, C - 1);
+                        h0[cc][u] = frame_hi[a0 * C + c]; h1[cc][u] = frame_hi[a1 * C + c];
+                        l0[cc][u] = frame_lo[a0 * C + c]; l1[cc][u] = frame_lo[a1 * C + c];
+                    }
                     w[u] = *reinterpret_cast<const double2*>(s.window64 + 2 * r);
                 }
 #pragma unroll
@@ -501,65 +525,79 @@ __global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
                     const int r = tid + 256 * (q0 + u);
                     const int p0 = 2 * r;
                     const bool in0 = !none && (whole || (p0 >= rel_lo && p0 < rel_hi)), in1 = !none && (whole || (p0 + 1 >= rel_lo && p0 + 1 < rel_hi));
-                    if (r < M) Z[r] = make_double2(in0 ? ((double)h0[u] + lo_scale * (double)l0[u]) * w[u].x : 0.0,
-                                                   in1 ? ((double)h1[u] + lo_scale * (double)l1[u]) * w[u].y : 0.0);
+#pragma unroll
+                    for (int cc = 0; cc < kCP; ++cc)
+                        if (r < M && cc < nc) Z[cc * M + r] = make_double2(in0 ? ((double)h0[cc][u] + lo_scale * (double)l0[cc][u]) * w[u].x : 0.0,
+                                                                          in1 ? ((double)h1[cc][u] + lo_scale * (double)l1[cc][u]) * w[u].y : 0.0);
                 }
             }
             __syncthreads();
             for (int p = 1; p < M;) {
                 if (M / p >= 4) {
                     const int tstep = M / (p * 4), quarter = M >> 2;
-                    double2 u[kWgQ][4];
+                    double2 u[kCP][kWgQ][4];
 #pragma unroll
-                    for (int b = 0; b < kWgQ; ++b) {
-                        const int i = min(tid + 256 * b, quarter - 1);
-                        u[b][0] = Z[i]; u[b][1] = Z[i + quarter]; u[b][2] = Z[i + 2 * quarter]; u[b][3] = Z[i + 3 * quarter];
-                    }
+                    for (int cc = 0; cc < kCP; ++cc)
+#pragma unroll
+                        for (int b = 0; b < kWgQ; ++b) {
+                            const int i = min(tid + 256 * b, quarter - 1);
+                            const double2* Zc = Z + (cc < nc ? cc : 0) * M;
+                            u[cc][b][0] = Zc[i]; u[cc][b][1] = Zc[i + quarter]; u[cc][b][2] = Zc[i + 2 * quarter]; u[cc][b][3] = Zc[i + 3 * quarter];
+                        }
                     __syncthreads();
 #pragma unroll
-                    for (int b = 0; b < kWgQ; ++b) {
-                        const int i = tid + 256 * b;
-                        if (i < quarter) {
-                            const int k = i & (p - 1);
-                            const int j = ((i - k) << 2) + k;
-                            double2 u0 = u[b][0], u1 = u[b][1], u2 = u[b][2], u3 = u[b][3];
-                            if (p > 1) {
-                                const double2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
-                                u1 = make_double2(u1.x * w1.x - u1.y * w1.y, u1.x * w1.y + u1.y * w1.x);
-                                u2 = make_double2(u2.x * w2.x - u2.y * w2.y, u2.x * w2.y + u2.y * w2.x);
-                                u3 = make_double2(u3.x * w3.x - u3.y * w3.y, u3.x * w3.y + u3.y * w3.x);
+                    for (int cc = 0; cc < kCP; ++cc)
+#pragma unroll
+                        for (int b = 0; b < kWgQ; ++b) {
+                            const int i = tid + 256 * b;
+                            if (i < quarter && cc < nc) {
+                                double2* Zc = Z + cc * M;
+                                const int k = i & (p - 1);
+                                const int j = ((i - k) << 2) + k;
+                                double2 u0 = u[cc][b][0], u1 = u[cc][b][1], u2 = u[cc][b][2], u3 = u[cc][b][3];
+                                if (p > 1) {
+                                    const double2 w1 = tw(k * tstep), w2 = tw(2 * k * tstep), w3 = tw(3 * k * tstep);
+                                    u1 = make_double2(u1.x * w1.x - u1.y * w1.y, u1.x * w1.y + u1.y * w1.x);
+                                    u2 = make_double2(u2.x * w2.x - u2.y * w2.y, u2.x * w2.y + u2.y * w2.x);
+                                    u3 = make_double2(u3.x * w3.x - u3.y * w3.y, u3.x * w3.y + u3.y * w3.x);
+                                }
+                                const double2 t0 = make_double2(u0.x + u2.x, u0.y + u2.y), t1 = make_double2(u0.x - u2.x, u0.y - u2.y);
+                                const double2 t2 = make_double2(u1.x + u3.x, u1.y + u3.y), d = make_double2(u1.x - u3.x, u1.y - u3.y);
+                                const double2 t3 = make_double2(d.y, -d.x);                       // -i d
+                                Zc[j] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                                Zc[j + p] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                                Zc[j + 2 * p] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                                Zc[j + 3 * p] = make_double2(t1.x - t3.x, t1.y - t3.y);
                             }
-                            const double2 t0 = make_double2(u0.x + u2.x, u0.y + u2.y), t1 = make_double2(u0.x - u2.x, u0.y - u2.y);
-                            const double2 t2 = make_double2(u1.x + u3.x, u1.y + u3.y), d = make_double2(u1.x - u3.x, u1.y - u3.y);
-                            const double2 t3 = make_double2(d.y, -d.x);                       // -i d
-                            Z[j] = make_double2(t0.x + t2.x, t0.y + t2.y);
-                            Z[j + p] = make_double2(t1.x + t3.x, t1.y + t3.y);
-                            Z[j + 2 * p] = make_double2(t0.x - t2.x, t0.y - t2.y);
-                            Z[j + 3 * p] = make_double2(t1.x - t3.x, t1.y - t3.y);
                         }
-                    }
                     p *= 4;
                 } else {
                     const int tstep = M / (p * 2), half = M >> 1;
-                    double2 u[2 * kWgQ][2];
+                    double2 u[kCP][2 * kWgQ][2];
 #pragma unroll
-                    for (int b = 0; b < 2 * kWgQ; ++b) {
-                        const int i = min(tid + 256 * b, half - 1);
-                        u[b][0] = Z[i]; u[b][1] = Z[i + half];
-                    }
+                    for (int cc = 0; cc < kCP; ++cc)
+#pragma unroll
+                        for (int b = 0; b < 2 * kWgQ; ++b) {
+                            const int i = min(tid + 256 * b, half - 1);
+                            const double2* Zc = Z + (cc < nc ? cc : 0) * M;
+                            u[cc][b][0] = Zc[i]; u[cc][b][1] = Zc[i + half];
+                        }
                     __syncthreads();
 #pragma unroll
-                    for (int b = 0; b < 2 * kWgQ; ++b) {
-                        const int i = tid + 256 * b;
-                        if (i < half) {
-                            const int k = i & (p - 1);
-                            const int j = ((i - k) << 1) + k;
-                            const double2 w1 = tw[k * tstep];
-                            const double2 u1 = make_double2(u[b][1].x * w1.x - u[b][1].y * w1.y, u[b][1].x * w1.y + u[b][1].y * w1.x);
-                            Z[j] = make_double2(u[b][0].x + u1.x, u[b][0].y + u1.y);
-                            Z[j + p] = make_double2(u[b][0].x - u1.x, u[b][0].y - u1.y);
+                    for (int cc = 0; cc < kCP; ++cc)
+#pragma unroll
+                        for (int b = 0; b < 2 * kWgQ; ++b) {
+                            const int i = tid + 256 * b;
+                            if (i < half && cc < nc) {
+                                double2* Zc = Z + cc * M;
+                                const int k = i & (p - 1);
+                                const int j = ((i - k) << 1) + k;
+                                const double2 w1 = tw(k * tstep);
+                                const double2 u1 = make_double2(u[cc][b][1].x * w1.x - u[cc][b][1].y * w1.y, u[cc][b][1].x * w1.y + u[cc][b][1].y * w1.x);
+                                Zc[j] = make_double2(u[cc][b][0].x + u1.x, u[cc][b][0].y + u1.y);
+                                Zc[j + p] = make_double2(u[cc][b][0].x - u1.x, u[cc][b][0].y - u1.y);
+                            }
                         }
-                    }
                     p *= 2;
                 }
                 __syncthreads();
@@ -571,16 +609,21 @@ __global__ __launch_bounds__(256) void unit_rows_f64_wg_kernel(UnitRowsArgs x) {
                 if (q <= nq) {                                   // (q == nq: bin M, thread 0)
                     const int k = min(kk, M);
                     const double2 wk = s.twiddle64[k];
-                    const double2 a = Z[k & (M - 1)], b = Z[(M - k) & (M - 1)];
-                    const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
-                    const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
-                    const double orr = di, oi = -dr;
-                    const double xr = er + orr * wk.x - oi * wk.y, xi = ei + orr * wk.y + oi * wk.x;
-                    const double m = sqrt(xr * xr + xi * xi);
-                    acc[q] += (kk <= M) ? m : 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < kCP; ++cc) {
+                        if (cc >= nc) break;
+                        const double2* Zc = Z + cc * M;
+                        const double2 a = Zc[k & (M - 1)], b = Zc[(M - k) & (M - 1)];
+                        const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+                        const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+                        const double orr = di, oi = -dr;
+                        const double xr = er + orr * wk.x - oi * wk.y, xi = ei + orr * wk.y + oi * wk.x;
+                        const double m = sqrt(xr * xr + xi * xi);
+                        acc[q] += (kk <= M) ? m : 0.0;
+                    }
                 }
             }
-            __syncthreads();                                     // (the next channel overwrites Z)
+            __syncthreads();                                     // (the next channels overwrite Z)
         }
         double part = 0.0;
 #pragma unroll
@@ -1044,7 +1087,8 @@ hipError_t launch_unit_rows_f64(const ExactSource& src, const PeakRefine* refine
     while ((2 << logM) < src.W) ++logM;
     x.logM = logM;
     const int Mh = src.W / 2;
-    const int lds = 2 * Mh * (int)sizeof(double2);
+    // windows up to 2048: half a twiddle table + two transforms (channel pairs) = 40 KB, four workgroups per CU; else twiddles + one
+    const int lds = Mh <= 1024 ? (Mh / 2 + 2 * Mh) * (int)sizeof(double2) : 2 * Mh * (int)sizeof(double2);
     auto go_wg = [&](auto tag) -> hipError_t {
         constexpr int KQ = decltype(tag)::value;
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&unit_rows_f64_wg_kernel<KQ>), lds);
