@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define REPET_ABI_VERSION 3
+#define REPET_ABI_VERSION 4
 
 typedef enum repet_status {
     REPET_OK = 0,
@@ -67,17 +67,21 @@ typedef struct repet_params {
     double sim_threshold;        /* similarity_threshold                            repet.py:58  */
 } repet_params;
 
-/* repet_params.flags, bit 0 -- strict reference behaviour on samples that are not finite. repet.py never looks at its input
- * (:125, :1220): a NaN sample makes the frames that hold it NaN; `sim` / `simonline` confine the damage to those frames; the
- * period family turns the beat spectrum of the clip / segment / windows NaN (period = period_range[0] + 1 there) and, through
- * np.median's NaN rule, marks the same position of EVERY period. By default the drop-in REFUSES such input (REPET_ERR_BAD_ARG,
- * "contains NaN or infinite samples"). With this flag repet_run / repet_run_batch let the samples through and all five variants
- * return what the reference returns for NaN samples: NaN positions equal, every other sample within the usual bar, periods and
- * similar-frame lists equal (tested against the oracle, which equals the reference bit for bit on such input). An INFINITE
- * sample is treated as a NaN sample: for `sim` / `simonline` that is the reference's result; for the period family the
- * reference's own result depends on where pocketfft's butterflies meet inf - inf, and the engine's NaN samples
- * are a superset of the reference's. Context calls: repet_ctx_set_strict_reference. */
+/* repet_params.flags -- samples that are not finite. repet.py never looks at its input (:125, :1220): a NaN sample makes the
+ * frames that hold it NaN; `sim` / `simonline` confine the damage to those frames; the period family turns the beat spectrum
+ * of the clip / segment / windows NaN (period = period_range[0] + 1 there) and, through np.median's NaN rule, marks the same
+ * position of EVERY period. Since ABI 4 that is the DEFAULT here too (flags = 0, a fresh context): repet_run / repet_run_batch
+ * (both transports) and the context calls let the samples through and all five variants return what the reference returns for
+ * NaN samples: NaN positions equal, every other sample within the usual bar, periods and similar-frame lists equal (tested
+ * against the oracle, which equals the reference bit for bit on such input). An INFINITE sample is treated as a NaN sample:
+ * for `sim` / `simonline` that is the reference's result; for the period family the reference's own result depends on where
+ * pocketfft's butterflies meet inf - inf, and the engine's NaN samples are a superset of the reference's.
+ * REPET_FLAG_REFUSE_NONFINITE (bit 1) is the option: host arrays with such samples are refused (REPET_ERR_BAD_ARG, "contains
+ * NaN or infinite samples" -- the default before ABI 4). Bit 0 (REPET_FLAG_STRICT_REFERENCE, the ABI-3 opt-in) is still
+ * accepted and means the default. Any other bit is an argument error. Context calls: repet_ctx_set_strict_reference(ctx, 0)
+ * turns the refusal on for that context's uploads. */
 #define REPET_FLAG_STRICT_REFERENCE 1
+#define REPET_FLAG_REFUSE_NONFINITE 2
 
 /* The nine module-level parameters of the reference (repet.py:42-63), for hosts that do not keep them as Python
  * globals, and the derivation of repet_params from them exactly as the reference's public functions do it
@@ -162,7 +166,7 @@ int repet_ctx_download_device(repet_ctx* ctx, float* dev_out);
  * repet_ctx_input_view  : the resident fp32 samples and, when a float64 upload left any, their fp32 remainders (else NULL)
  * repet_ctx_download_from: n_values fp32 values from ANY device buffer of this context's device widened into a host float64
  *                         array through the context's pinned ring (the gather side of a scatter: results received from peers) */
-int repet_ctx_set_strict_reference(repet_ctx* ctx, int on);   /* (ABI 3) REPET_FLAG_STRICT_REFERENCE for this context's uploads and runs */
+int repet_ctx_set_strict_reference(repet_ctx* ctx, int on);   /* (ABI 3; on by default since ABI 4) on = 0: REPET_FLAG_REFUSE_NONFINITE for this context's uploads */
 int repet_ctx_stream(repet_ctx* ctx, void** hip_stream);
 int repet_ctx_result_view(repet_ctx* ctx, float** dev_out, int64_t* n_values /* nullable */);
 int repet_ctx_input_view(repet_ctx* ctx, float** dev_audio, float** dev_audio_lo /* nullable */, int64_t* n_values /* nullable */);

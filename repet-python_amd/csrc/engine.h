@@ -107,8 +107,12 @@ struct repet_ctx {
     std::function<int()> pre_synthesis;      // run_original calls it (once) right before its inverse STFT
     bool clip_loop = false;       // true while run_algo works through the clips one by one
     int32_t n_channels = 0;
-    bool strict = false;          // REPET_FLAG_STRICT_REFERENCE: samples that are not finite are let through (sim / simonline)
+    bool strict = true;           // samples that are not finite are let through as repet.py lets them (all five variants); false: REPET_FLAG_REFUSE_NONFINITE
     bool input_not_finite = false;   // the resident clip came from a host array that held such samples
+    // the resident clip was never scanned (device planes -- the RCCL transport, torch tensors --, float WAVE payloads): under
+    // `strict` the passes that reproduce the reference on such samples then run unconditionally (they cost microseconds)
+    bool input_unscanned = false;
+    bool nonfinite_passes() const { return input_not_finite || (strict && input_unscanned); }
     // workspaces
     DevBuf X, V, Vn, P, S, band, beat, idx, cnt, periods, win_periods, frames, tmp_a, tmp_b, tmp_c;
     DevBuf peak_scratch;          // per-segment candidates of long similarity rows (launch_local_maxima)

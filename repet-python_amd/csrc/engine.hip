@@ -351,7 +351,7 @@ int run_stft(repet_ctx* c, const Geo& g, const Tables* tb, int64_t offset, int64
     a.n_batch = B; a.batch_sample_stride = batch_sample_stride; a.batch_spec_stride = (int64_t)g.C * g.chan_stride;
     a.batch_mean_stride = g.Tpad * g.FS;
     HIP_TRY(launch_stft(a, c->stream));
-    if (c->input_not_finite) HIP_TRY(launch_infinite_frames_fix(a, c->stream));      // (strict reference mode only: see the kernel)
+    if (c->nonfinite_passes()) HIP_TRY(launch_infinite_frames_fix(a, c->stream));    // (strict reference mode only: see the kernel)
     const double in_b = 4.0 * n * g.C, spec_b = (8.0 + 4.0) * g.F * g.T * g.C, mean_b = 4.0 * g.F * g.T;
     mark(c, "stft", B * (in_b + spec_b + mean_b), 0);
     return REPET_OK;
@@ -395,6 +395,8 @@ int check_params(const repet_params* p) {
         return fail(REPET_ERR_LIMIT, "window length must be a power of two in [64, 8192]");
     if (p->step_length * 2 != p->window_length) return fail(REPET_ERR_BAD_ARG, "step length must be half the window length");
     if (p->period_lo < 0 || p->cutoff_bins < 0 || p->sim_distance_frames < 0) return fail(REPET_ERR_BAD_ARG, "negative parameter");
+    if (p->flags & ~(REPET_FLAG_STRICT_REFERENCE | REPET_FLAG_REFUSE_NONFINITE))
+        return fail(REPET_ERR_BAD_ARG, "unknown bits in repet_params.flags (an ABI-2 caller must zero reserved0)");
     return REPET_OK;
 }
 
@@ -654,6 +656,7 @@ int repet_ctx_upload_batch(repet_ctx* c, const void* audio, int dtype, int64_t n
     HIP_TRY(staged_upload(c->ring, audio, dtype, c->audio.as<float>(), (size_t)count, c->stream, lo_dst, &c->has_lo, lo_dst ? c->copy_stream : nullptr,
                           &not_finite));
     c->input_not_finite = not_finite;
+    c->input_unscanned = false;
     if (not_finite && !c->strict) {
         // repet.py computes on, and NaN spreads from the frames that hold it through whatever is global in the variant (the
         // beat spectrum of original / extended / adaptive: whole segments or clips of NaN); host arrays with such samples are
@@ -690,7 +693,10 @@ int repet_ctx_upload_device_split(repet_ctx* c, const float* dev_audio, const fl
         c->has_lo = true;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->input_not_finite = false;               // (device buffers are not scanned: what they hold is computed on, as in repet.py)
+    // device buffers are not scanned: what they hold is computed on, as in repet.py -- and in strict reference mode the passes
+    // that make the result the reference's on NaN / infinite samples run whatever the planes hold (nonfinite_passes)
+    c->input_not_finite = false;
+    c->input_unscanned = true;
     c->ring.lo_in_flight = false;              // (the stream waited for it above and is idle now)
     c->n_samples = n; c->n_channels = ch; c->n_clips = n_clips; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
@@ -973,6 +979,9 @@ int repet_ctx_upload_wav(repet_ctx* c, const void* file_bytes, int64_t n_bytes, 
     HIP_TRY(staged_upload_bytes(c->ring, static_cast<const unsigned char*>(file_bytes) + w.data_offset, c->staging.p, raw_bytes, c->stream));
     HIP_TRY(launch_decode_pcm(c->staging.p, w.format, w.bytes_per_sample, c->audio.as<float>(), count, c->stream));
     c->has_lo = false;
+    // integer PCM is finite by construction; float payloads are decoded on the device and not scanned (see upload_device_split)
+    c->input_not_finite = false;
+    c->input_unscanned = w.format != 1;
     c->n_samples = w.n_samples; c->n_channels = w.n_channels; c->n_clips = 1; c->clip_base = 0;
     c->win_total = 0; c->win_offset = 0;
     c->last_fs = w.sampling_frequency;
@@ -1112,7 +1121,7 @@ int repet_run(int algo, const void* audio, int dtype, int64_t n, int32_t ch, con
     repet_ctx* c = nullptr;
     RP_TRY(thread_ctx(device, &c));
     RP_TRY(check_params(p));
-    c->strict = (p->flags & REPET_FLAG_STRICT_REFERENCE) != 0;
+    c->strict = !(p->flags & REPET_FLAG_REFUSE_NONFINITE);
     RP_TRY(repet_ctx_upload(c, audio, dtype, n, ch));
     // (without a timing request nothing waits between the last kernel and the first copy back: the download is ordered behind
     // the run on the context's stream, and an error of the run surfaces there)

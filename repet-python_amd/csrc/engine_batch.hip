@@ -100,7 +100,7 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
         run_threads([&](int dev) {
             repet_ctx* c = nullptr;
             int rc = repet_ctx_create(dev % physical, &c);
-            if (rc == REPET_OK) c->strict = p && (p->flags & REPET_FLAG_STRICT_REFERENCE) != 0;
+            if (rc == REPET_OK) c->strict = !(p && (p->flags & REPET_FLAG_REFUSE_NONFINITE));
             for (int i = dev; rc == REPET_OK && i < n_clips; i += n_devices) {
                 const int k = order[i];
                 rc = repet_ctx_upload(c, audio[k], dtype, n_samples[k], n_channels[k]);
@@ -191,7 +191,7 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
                 if (want_lo) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q.lo_root), bytes));
                 bool not_finite = false;
                 HIP_TRY(staged_upload(io->ring, audio[k], dtype, q.in_root, count, io->stream, q.lo_root, &q.has_lo, nullptr, &not_finite));
-                if (not_finite && !(p && (p->flags & REPET_FLAG_STRICT_REFERENCE) && (algo == REPET_SIM || algo == REPET_SIMONLINE)))
+                if (not_finite && p && (p->flags & REPET_FLAG_REFUSE_NONFINITE))
                     return fail(REPET_ERR_BAD_ARG, "audio_signal contains NaN or infinite samples");
             }
             if (q.has_lo) ++g_batch_info.clips_with_remainders;
@@ -242,7 +242,12 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
     };
     auto body = [&]() -> int {
         RP_TRY(repet_ctx_create(0, &io));
-        for (int d = 0; d < n_devices; ++d) RP_TRY(repet_ctx_create(d, &ctx[d]));
+        for (int d = 0; d < n_devices; ++d) {
+            RP_TRY(repet_ctx_create(d, &ctx[d]));
+            // (the planes arrive through repet_ctx_upload_device_split, unscanned: with `strict` the passes that reproduce
+            // repet.py on NaN / infinite samples run on every clip, so both transports give the same result)
+            ctx[d]->strict = !(p && (p->flags & REPET_FLAG_REFUSE_NONFINITE));
+        }
         if (n_rounds > 0) RP_TRY(stage_round(0));
         for (int r = 0; r < n_rounds; ++r) {
             // the devices work on round r in their own threads while this one stages round r + 1

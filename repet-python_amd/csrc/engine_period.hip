@@ -235,6 +235,7 @@ int exec_extended_plan(repet_ctx* c, const repet_params* p, int64_t first, int64
         x->out.borrow(c->out.p, c->out.cap);
         x->n_samples = c->n_samples; x->n_channels = c->n_channels; x->n_clips = 1; x->clip_base = c->clip_base;
         x->timing = nullptr;
+        x->strict = c->strict; x->input_not_finite = c->input_not_finite; x->input_unscanned = c->input_unscanned;
         MaskPlaneScope aux_plane(x, c->mask_plane);
         HIP_TRY(hipEventRecord(c->aux_start, c->stream));              // the clip is resident, `out` is cleared
         HIP_TRY(hipStreamWaitEvent(x->stream, c->aux_start, 0));

@@ -314,7 +314,7 @@ int exec_simonline(repet_ctx* c, const repet_params* p) {
                               N, N * g.C, 0, T, nb));
     mark(c, "local_maxima", nb * (4.0 * rows * B + 4.0 * K * rows), 0);
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(B, p->sim_distance_frames + 1));
-    if (c->input_not_finite && B > 1) {
+    if (c->nonfinite_passes() && B > 1) {
         // strict reference mode: repet.py never writes the warm-up frames (repet.py:834: its background stays 0 there); the engine
         // gives them the mask 0, and 0 x NaN would be NaN -- their spectra (which only the inverse STFT still reads) are cleared
         for (int b = 0; b < nb; ++b)

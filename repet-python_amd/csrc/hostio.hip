@@ -97,6 +97,7 @@ public:
     bool start(const std::function<void(int, int)>& fn, size_t work_items = ~(size_t)0) {
         if (n_threads_ <= 1 || work_items < 65536) return false;     // not worth waking anybody up
         job_mutex_.lock();
+        note_device();
         fn_ = &fn;
         pending_.store(n_threads_ - 1, std::memory_order_relaxed);
         {
@@ -123,6 +124,18 @@ private:
         std::this_thread::yield();
 #endif
     }
+    // The workers are pinned to the NUMA node of the device that was current when the pool was made. A process that drives
+    // devices on BOTH sockets (repet_run_batch, one host thread per device, all sharing this pool) would convert half its
+    // clips on the far node -- measured slower than leaving the placement to the scheduler (4.95 against 4.33 ms per call):
+    // the first job that arrives for a device on another node lifts the pinning for good.
+    void note_device() {
+        if (near_cpus_.empty() || unpin_.load(std::memory_order_relaxed)) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev == pinned_device_) return;
+        if (dev == last_other_device_) return;                      // (already compared: same node)
+        if (host_cpus_near_device(dev) != near_cpus_) unpin_.store(true, std::memory_order_release);
+        else last_other_device_ = dev;
+    }
     static std::vector<int> gpu_node_cpus() {
         const char* off = getenv("REPET_HOST_NUMA");
         if (off && off[0] == '0') return {};
@@ -148,6 +161,10 @@ private:
             n = hw >= 32 ? 8 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
         }
         n_threads_ = std::min(n, 32);
+        (void)hipGetDevice(&pinned_device_);
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+        have_all_cpus_ = sched_getaffinity(0, sizeof(all_cpus_), &all_cpus_) == 0;
+#endif
         near_cpus_ = gpu_node_cpus();
         if ((int)near_cpus_.size() < n_threads_) near_cpus_.clear();
         // more threads than CPUs (REPET_HOST_THREADS above a container's share): spinners would take the CPU from the thread
@@ -165,6 +182,7 @@ private:
         }
 #endif
         unsigned seen = 0;
+        [[maybe_unused]] bool pinned = !near_cpus_.empty();
         for (;;) {
             // the next job: spin for about 200 us of WALL time (the gaps between the chunks of one copy), then sleep
             bool have = generation_.load(std::memory_order_acquire) != seen;
@@ -183,6 +201,12 @@ private:
                 sleepers_.fetch_sub(1, std::memory_order_release);
             }
             seen = generation_.load(std::memory_order_acquire);
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+            if (pinned && unpin_.load(std::memory_order_acquire)) {       // devices on several nodes: back to the process's own mask
+                if (have_all_cpus_) (void)sched_setaffinity(0, sizeof(all_cpus_), &all_cpus_);
+                pinned = false;
+            }
+#endif
             const std::function<void(int, int)>* fn = fn_;
             (*fn)(part, n_threads_);
             pending_.fetch_sub(1, std::memory_order_release);
@@ -191,6 +215,12 @@ private:
     int n_threads_ = 1;
     bool spin_ok_ = true;
     std::vector<int> near_cpus_;
+    int pinned_device_ = 0, last_other_device_ = -1;
+    std::atomic<bool> unpin_{false};
+    [[maybe_unused]] bool have_all_cpus_ = false;
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+    cpu_set_t all_cpus_;
+#endif
     std::mutex job_mutex_, m_;
     std::condition_variable cv_;
     const std::function<void(int, int)>* fn_ = nullptr;

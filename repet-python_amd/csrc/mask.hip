@@ -486,7 +486,12 @@ namespace repet {
 #endif
 
 // One lane per frame, bin F-1 only: the index list, its length and every row offset are per-lane here.
-template <int NET>
+// PRELOAD (round 6; lists of at most 128 entries in rows of a multiple of four): a lane fetches its whole list first, as 16-byte
+// loads that do not depend on each other, and the NET row gathers follow side by side. Entry by entry ("list[k]", then the
+// row it names) the kernel was a chain of 2 x 100 memory round trips per lane with 64 lines per instruction: 84 us for 244
+// waves at cfg 2 -- hidden beside the selection kernel, but serial latency all the same. The selection network and its
+// inputs are unchanged: the same bits.
+template <int NET, bool PRELOAD = false>
 __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
                                                               const int* __restrict__ count, int64_t first_frame) {
     const int c = blockIdx.y;
@@ -506,10 +511,92 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_kernel(MaskArgs a, const 
     const int f = a.F - 1;
     const int row_bytes = a.FS * 4, pad_bytes = (int)a.pad_row * row_bytes;
     const __amdgpu_buffer_rsrc_t rsrc = channel_rsrc(Vc, a.chan_stride);
+    if constexpr (PRELOAD && NET >= 2) {
+        constexpr int NQ = (NET + 3) / 4;
+        int e[4 * NQ];
+        const int4* list4 = reinterpret_cast<const int4*>(list);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const int4 v = list4[q]; e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w; }
+        const float v_own = Vc[t * a.FS + f];
+        const float med = median_of<NET>(n, [&](int k) {
+            const int row_off = k < n ? e[k] * row_bytes : pad_offset<NET>(k, n, pad_bytes, row_bytes);
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_off + f * 4, 0, 0)); });
+        if (active) emit(a, c, t, f, soft_mask(v_own, med, f, a.cutoff));
+        return;
+    }
     const float med = median_of<NET>(n, [&](int k) {
         const int row_off = k < n ? list[k] * row_bytes : pad_offset<NET>(k, n, pad_bytes, row_bytes);
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_off + f * 4, 0, 0)); });
     if (active) emit(a, c, t, f, soft_mask(Vc[t * a.FS + f], med, f, a.cutoff));
+}
+
+// Round 6: one WAVE per (frame, channel) for that bin. The lane-per-frame kernel above walks its list entry by entry -- a
+// hundred dependent list -> row round trips per lane and the 776-comparator network for ONE cell per lane: 84 us beside the
+// selection at cfg 2 (244 waves), 7 % of all kernel time. Here lane l holds entries l and l + 64 of the list (rows of idx
+// hold at least 128), so the whole gather is two loads per lane in flight at once, and the two middle order statistics come
+// from counting: the rank of an entry = entries below it (+ equal ones in front of it), one v_readlane per entry. The
+// network's pad slots (-1 below, +inf above, pad_offset) take part as counts, so the wire read is the network's own --
+// same values in the same (signed-integer, as v_min_i32) order: the same bits.
+__global__ __launch_bounds__(64) void mask_sim_nyquist_wave_kernel(MaskArgs a, const int* __restrict__ idx, int idx_pitch,
+                                                                   const int* __restrict__ count, int64_t first_frame, int net) {
+    const int c = blockIdx.y;
+    a.V += blockIdx.z * a.batch_stride;
+    if (a.X) a.X += blockIdx.z * a.batch_stride;
+    if (a.mask) a.mask += blockIdx.z * a.batch_stride;
+    idx += blockIdx.z * a.idx_batch_stride;
+    count += blockIdx.z * a.cnt_batch_stride;
+    const int64_t r = blockIdx.x, t = first_frame + r;
+    const int lane = threadIdx.x;
+    const float* Vc = a.V + c * a.chan_stride;
+    const int f = a.F - 1;
+    const int n = __builtin_amdgcn_readfirstlane(count[r]);
+    const int* list = idx + r * (int64_t)idx_pitch;
+    const int e0 = list[lane], e1 = list[lane + 64];
+    const int64_t o = c * a.chan_stride + t * a.FS + f;
+    const float v_own = Vc[t * a.FS + f];
+    float2 x_own = make_float2(0.f, 0.f);
+    if (a.X && lane == 0) x_own = a.X[o];
+    const int v0 = lane < n ? __float_as_int(Vc[(int64_t)e0 * a.FS + f]) : 0;
+    const int v1 = lane + 64 < n ? __float_as_int(Vc[(int64_t)e1 * a.FS + f]) : 0;
+    int c0 = 0, c1 = 0;
+    const int n_lo = n < 64 ? n : 64;
+    for (int k = 0; k < n_lo; ++k) {
+        const int s = __builtin_amdgcn_readlane(v0, k);
+        c0 += (s < v0 || (s == v0 && k < lane)) ? 1 : 0;
+        c1 += (s <= v1) ? 1 : 0;                                        // (entry k < 64 stands in front of entry lane + 64)
+    }
+    for (int k = 64; k < n; ++k) {
+        const int s = __builtin_amdgcn_readlane(v1, k - 64);
+        c0 += (s < v0) ? 1 : 0;
+        c1 += (s < v1 || (s == v1 && k - 64 < lane)) ? 1 : 0;
+    }
+    // the pads as the network sees them: (net - n) / 2 slots of -1.0f, the rest +inf
+    const int low_pads = (net - n) >> 1, high_pads = net - n - low_pads;
+    const int kLow = (int)0xbf800000u, kHigh = 0x7f800000;
+    const int m0 = c0 + (kLow < v0 ? low_pads : 0) + (kHigh < v0 ? high_pads : 0);
+    const int m1 = c1 + (kLow < v1 ? low_pads : 0) + (kHigh < v1 ? high_pads : 0);
+    auto wire = [&](int w) -> float {                                   // what the sorted network holds at wire w
+        const unsigned long long h0 = __ballot(lane < n && m0 == w), h1 = __ballot(lane + 64 < n && m1 == w);
+        if (h0) return __int_as_float(__builtin_amdgcn_readlane(v0, (int)__ffsll((long long)h0) - 1));
+        if (h1) return __int_as_float(__builtin_amdgcn_readlane(v1, (int)__ffsll((long long)h1) - 1));
+        return w < low_pads ? -1.0f : INFINITY;
+    };
+    float med = __uint_as_float(0x7fc00000u);                           // np.median of an empty slice
+    if (n > 0) {
+        const float lo = wire(net / 2 - 1);
+        med = (n & 1) ? lo : 0.5f * (lo + wire(net / 2));
+    }
+    if (lane == 0) {
+        const float m = soft_mask(v_own, med, f, a.cutoff);
+        if (a.mask) a.mask[o] = m;
+        if (a.X) a.X[o] = make_float2(x_own.x * m, x_own.y * m);
+    }
+}
+// REPET_NYQUIST=wave: the wave-per-frame kernel; =lane: the lane-per-frame kernel walking its list entry by entry (round 5);
+// default: the lane-per-frame kernel with its list fetched up front (agreement test / A-B)
+static int nyquist_path() {
+    static const int path = [] { const char* e = getenv("REPET_NYQUIST"); return (e && e[0] == 'w') ? 1 : (e && e[0] == 'l') ? 2 : 0; }();
+    return path;
 }
 
 hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pitch, const int32_t* count,
@@ -529,8 +616,15 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
         if (split) {
             if (rows > 0 && (parts & 2)) {
                 if (forked) { (void)hipEventRecord(fork, s); (void)hipStreamWaitEvent(side, fork, 0); }
-                hipLaunchKernelGGL(mask_sim_nyquist_kernel<NET>, dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels, nb),
-                                   dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
+                if (NET >= 2 && idx_pitch >= 128 && nyquist_path() == 1)
+                    hipLaunchKernelGGL(mask_sim_nyquist_wave_kernel, dim3((unsigned)rows, (unsigned)m.n_channels, nb),
+                                       dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame, (int)NET);
+                else if (NET >= 2 && idx_pitch >= 128 && (idx_pitch & 3) == 0 && nyquist_path() == 0)
+                    hipLaunchKernelGGL((mask_sim_nyquist_kernel<NET, true>), dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels, nb),
+                                       dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
+                else
+                    hipLaunchKernelGGL(mask_sim_nyquist_kernel<NET>, dim3((unsigned)ceil_div(rows, 64), (unsigned)m.n_channels, nb),
+                                       dim3(64), 0, forked ? side : s, m, idx, idx_pitch, count, first_frame);
                 if (forked) (void)hipEventRecord(join, side);
             }
             if (parts & 1) {

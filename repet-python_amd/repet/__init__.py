@@ -34,11 +34,12 @@ similarity_number = 100
 buffer_length = 10
 
 # Not a parameter of the reference: what to do with samples that are NOT FINITE. repet.py computes on (a NaN sample makes the
-# frames that hold it NaN; repet.py:125 has no input check). False (default): such input raises ValueError. True: the samples
-# are let through and every variant returns what the reference returns for NaN samples (``sim`` / ``simonline``: NaN on the
-# samples of the affected frames only; the period family: also at the same position of every period, and the period
-# ``period_range[0] + 1``); an infinite sample is treated as NaN. Read at call time like the others.
-strict_reference = False
+# frames that hold it NaN; repet.py:125 has no input check). True (default since round 6: the reference's behaviour): the
+# samples are let through and every variant returns what the reference returns for NaN samples (``sim`` / ``simonline``: NaN
+# on the samples of the affected frames only; the period family: also at the same position of every period, and the period
+# ``period_range[0] + 1``); an infinite sample is treated as NaN. False: such input raises ValueError
+# (REPET_FLAG_REFUSE_NONFINITE). Read at call time like the others.
+strict_reference = True
 
 _device = 0  # HIP device used by the one-shot calls
 
@@ -103,7 +104,7 @@ def derive_params(sampling_frequency):
     p.seg_len_samples = int(round(segment_length * fs))                       # repet.py:266
     p.seg_step_samples = int(round(segment_step * fs))                        # repet.py:267
     p.sim_threshold = float(similarity_threshold)
-    p.flags = _native.FLAG_STRICT_REFERENCE if strict_reference else 0
+    p.flags = 0 if strict_reference else _native.FLAG_REFUSE_NONFINITE
     return p
 
 

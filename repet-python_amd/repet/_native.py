@@ -9,14 +9,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPET_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "librepet_hip.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ORIGINAL, EXTENDED, ADAPTIVE, SIM, SIMONLINE = range(5)
 ALGO_IDS = {"original": ORIGINAL, "extended": EXTENDED, "adaptive": ADAPTIVE, "sim": SIM, "simonline": SIMONLINE}
 F32, F64, I16 = 0, 1, 2
 MAX_STAGES = 16
 
 ERR_BAD_ARG, ERR_TOO_SHORT, ERR_HIP, ERR_OOM, ERR_LIMIT = -1, -2, -3, -4, -5
-FLAG_STRICT_REFERENCE = 1
+FLAG_STRICT_REFERENCE = 1      # (ABI 3 opt-in; the default since ABI 4)
+FLAG_REFUSE_NONFINITE = 2
 
 
 class Params(C.Structure):
@@ -292,7 +293,8 @@ class Context:
         check(lib().repet_ctx_download_device(self._h, C.c_void_p(int(data_ptr))))
 
     def set_strict_reference(self, on=True):
-        """REPET_FLAG_STRICT_REFERENCE for this context: NaN / infinite samples are let through (``sim`` / ``simonline``)."""
+        """NaN / infinite samples are let through as repet.py lets them (the default since ABI 4); ``on=False``: host uploads
+        with such samples are refused (REPET_FLAG_REFUSE_NONFINITE)."""
         check(lib().repet_ctx_set_strict_reference(self._h, 1 if on else 0))
 
     def stream(self):

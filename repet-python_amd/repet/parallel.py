@@ -448,6 +448,11 @@ class ExtendedShard:
         self.ctx = None
         self.view = None
         self.inbox = {}
+        # ranks as the point-to-point calls want them: dst / src of send / recv / P2POp are GLOBAL ranks, the plan's are
+        # group-local
+        self.peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+        # what travels: fp32 from the engine, float64 from a range_fn (the dtype a root with an empty window must expect)
+        self.wire_dtype = torch.float32 if range_fn is None else torch.float64
         if self.hi <= self.lo:
             return
         if window is None or np.shape(window) != (self.hi - self.lo, self.channels):
@@ -492,19 +497,19 @@ class ExtendedShard:
                 ops = []
                 for src, dst, lo, hi in mine:
                     if src == self.rank:
-                        ops.append(dist.P2POp(dist.isend, self._piece(lo, hi), dst, self.group))
+                        ops.append(dist.P2POp(dist.isend, self._piece(lo, hi), self.peer(dst), self.group))
                     else:
-                        ops.append(dist.P2POp(dist.irecv, self.inbox[(src, lo, hi)], src, self.group))
+                        ops.append(dist.P2POp(dist.irecv, self.inbox[(src, lo, hi)], self.peer(src), self.group))
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()                                  # (orders the stream behind the transfer; no host wait)
             else:
                 # gloo: CPU wire. Sends first (non-blocking), then the receives in the plan's order.
                 self.synchronize()
-                pending = [dist.isend(self._piece(lo, hi).cpu().contiguous(), dst, self.group) for src, dst, lo, hi in mine if src == self.rank]
+                pending = [dist.isend(self._piece(lo, hi).cpu().contiguous(), self.peer(dst), self.group) for src, dst, lo, hi in mine if src == self.rank]
                 for src, dst, lo, hi in mine:
                     if dst == self.rank:
                         box = torch.empty((hi - lo, self.channels), dtype=self.view.dtype)
-                        dist.recv(box, src, self.group)
+                        dist.recv(box, self.peer(src), self.group)
                         self.inbox[(src, lo, hi)].copy_(box)
                 for req in pending:
                     req.wait()
@@ -532,7 +537,7 @@ class ExtendedShard:
         wire = (lambda t: t) if self.on_gpu else (lambda t: t.cpu())
         if self.rank != root:
             if mine is not None and mine.shape[0] > 0:
-                dist.send(wire(mine).contiguous(), root, self.group)
+                dist.send(wire(mine).contiguous(), self.peer(root), self.group)
             return None
         out = np.zeros((self.n, self.channels), dtype=np.float64)
         for r in range(self.world):
@@ -542,9 +547,9 @@ class ExtendedShard:
             if r == root:
                 part = mine
             else:
-                part = torch.empty((hi - lo, self.channels), dtype=self.view.dtype if self.view is not None else torch.float32,
-                                   device=self.view.device if (self.on_gpu and self.view is not None) else "cpu")
-                dist.recv(part, r, self.group)
+                part = torch.empty((hi - lo, self.channels), dtype=self.wire_dtype,
+                                   device=torch.device("cuda", self.device) if self.on_gpu else "cpu")
+                dist.recv(part, self.peer(r), self.group)
             out[lo:hi] = part.cpu().numpy()
         return out
 

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in repet_hip.h but not exported"
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
-    assert lib.repet_abi_version() == _native.ABI_VERSION == 3
+    assert lib.repet_abi_version() == _native.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -121,10 +121,13 @@ def test_edge_cases_behave_like_the_reference():
     assert np.array_equal(repet.extended(x149, fs), repet.original(x149, fs))
 
 
-def test_nan_and_infinite_samples_are_refused():
+def test_nan_and_infinite_samples_are_refused(monkeypatch):
     """repet.py computes on with such samples; what comes out depends on what is global in the variant (`sim`: the frames that
-    hold them; original / extended / adaptive: NaN through the beat spectrum, i.e. whole segments or clips). The drop-in refuses
-    host arrays that contain them, whatever the dtype, and is usable afterwards."""
+    hold them; original / extended / adaptive: NaN through the beat spectrum, i.e. whole segments or clips). With
+    ``repet.strict_reference = False`` (REPET_FLAG_REFUSE_NONFINITE; the default until round 5) the drop-in refuses host arrays
+    that contain them, whatever the dtype, and is usable afterwards."""
+    monkeypatch.setattr(repet, "strict_reference", False)
+    assert repet.derive_params(8000).flags == 2
     fs = 8000
     x = synth(12, fs, 2, 7)
     for value, dtype in ((np.nan, np.float64), (np.inf, np.float64), (-np.inf, np.float32), (np.nan, np.float32)):
@@ -152,7 +155,7 @@ def test_strict_reference_reproduces_repet_py_on_samples_that_are_not_finite(alg
     this kind of input: NaN positions equal, max-abs 0.0 elsewhere -- checked against /root/reference when the strict mode was
     built), and the similar-frame lists of every other frame equal to the oracle's. 44.1 kHz / 40 s takes the rank-domain
     median: the NaN / inf magnitudes go through the column sort. (The period family: the next test.)"""
-    monkeypatch.setattr(repet, "strict_reference", True)
+    assert repet.strict_reference is True                 # the default: the reference's behaviour
     x = synth(seconds, fs, channels, 11).astype(dtype)
     n = len(x)
     x[n // 3, 0] = np.nan                                   # one sample
@@ -163,9 +166,8 @@ def test_strict_reference_reproduces_repet_py_on_samples_that_are_not_finite(alg
     with np.errstate(all="ignore"):
         want = orc.ALGORITHMS[algo](x.astype(np.float64), fs, None, tr)
     p = repet.derive_params(fs)
-    assert p.flags == 1
-    ctx = repet.Context(0)
-    ctx.set_strict_reference(True)
+    assert p.flags == 0
+    ctx = repet.Context(0)                                  # (a fresh context lets such samples through as well)
     ctx.upload(x)
     ctx.execute(algo, p)
     got = ctx.download()
@@ -595,6 +597,52 @@ def test_rccl_transport_sends_to_itself_and_carries_the_remainders(monkeypatch):
     assert repet.last_batch_info()["clips_sent"] == 0 and repet.last_batch_info()["transport"] == "host"
 
 
+@pytest.mark.parametrize("algo", ["simonline", "sim", "original", "extended"])
+def test_samples_that_are_not_finite_give_the_same_result_on_every_transport(algo, monkeypatch):
+    """The reference's behaviour on NaN / infinite samples (the default) must not depend on HOW a clip reached the engine: the
+    one-shot call scans the host array on its way into the pinned ring, the RCCL transport and device-tensor uploads hand over
+    device planes that nobody scanned (round 5's advisor: the passes that reproduce repet.py -- NaN frames for infinite samples,
+    `simonline`'s cleared warm-up spectra, 0 x NaN -- were keyed on the host scan and skipped there). NaN inside `simonline`'s
+    first buffer_length seconds, an infinite sample later; `extended` has its longer last segment on the auxiliary context."""
+    fs = 16000
+    x = synth(36 if algo == "extended" else 24, fs, 2, 17)
+    n = len(x)
+    x[3 * fs + 123, 0] = np.nan                             # inside simonline's warm-up (10-s buffer)
+    x[(3 * n) // 4, 1] = np.inf
+    x[n - 2000, 0] = np.nan                                 # the last segment of `extended`
+    with np.errstate(all="ignore"):
+        want = orc.ALGORITHMS[algo](x, fs)
+    one_shot = getattr(repet, algo)(x, fs)
+    if algo in ("sim", "simonline"):
+        assert np.array_equal(np.isnan(one_shot), np.isnan(want))
+    else:
+        assert not (np.isnan(want) & ~np.isnan(one_shot)).any()         # (infinite samples: a superset, INTEGRATION.md)
+    monkeypatch.setenv("REPET_RCCL_SELF", "1")
+    sent = repet.run_batch(algo, [x], fs, n_devices=1, transport="rccl")[0]
+    assert repet.last_batch_info()["clips_sent"] == 1
+    monkeypatch.delenv("REPET_RCCL_SELF")
+    assert np.array_equal(sent, one_shot, equal_nan=True)
+    host = repet.run_batch(algo, [x], fs, n_devices=1, transport="host")[0]
+    assert np.array_equal(host, one_shot, equal_nan=True)
+    # device planes handed to a context (what a torch.distributed worker does with a received tensor)
+    import torch
+    hi = x.astype(np.float32)
+    lo = (x - hi.astype(np.float64)).astype(np.float32)
+    lo[~np.isfinite(lo)] = 0.0
+    t_hi, t_lo = torch.from_numpy(hi).cuda(), torch.from_numpy(lo).cuda()
+    torch.cuda.synchronize()
+    ctx = repet.Context(0)
+    ctx.upload_device(t_hi.data_ptr(), n, 2, 1, t_lo.data_ptr())
+    ctx.execute(algo, repet.derive_params(fs))
+    got = ctx.download()
+    ctx.close()
+    assert np.array_equal(got, one_shot, equal_nan=True)
+    # and the refusal as the option, on the RCCL transport too
+    monkeypatch.setattr(repet, "strict_reference", False)
+    with pytest.raises(ValueError, match="NaN or infinite"):
+        repet.run_batch(algo, [x], fs, n_devices=1, transport="rccl")
+
+
 @pytest.mark.slow
 def test_sim_headline_config_properties():
     """cfg 2 (180 s, 44.1 kHz stereo): strided golden samples + size-independent properties."""
@@ -752,7 +800,7 @@ def test_mask_plane_gives_the_same_bits():
         subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_MASK_PLANE=plane))
         outs.append(np.load(out))
         os.remove(out)
-    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    assert np.array_equal(outs[0], outs[2], equal_nan=True) and np.array_equal(outs[1], outs[2], equal_nan=True)
     assert np.array_equal(outs[0], outs[2], equal_nan=True)
 
 
@@ -838,6 +886,32 @@ def test_median_paths_agree_bit_for_bit(seconds, fs, channels, number, distance)
     assert any("rank_columns" in n for n in outs[0]["stages"].tolist()) and not any("rank_columns" in n for n in outs[2]["stages"].tolist())
     assert np.array_equal(outs[1]["y"], outs[2]["y"])
     assert np.array_equal(outs[0]["y"], outs[2]["y"])
+
+
+@pytest.mark.parametrize("variant,seconds,fs,channels,number,distance", [
+    ("sim", 50, 44100, 2, 100, 1.0), ("sim", 30, 44100, 2, 31, 0.1), ("sim", 40, 44100, 1, 128, 0.05), ("sim", 100, 8000, 3, 101, 0.1),
+    ("sim", 12, 16000, 2, 7, 1.0), ("simonline", 30, 44100, 2, 100, 1.0), ("simonline", 20, 16000, 2, 5, 0.3)])
+def test_nyquist_bin_kernels_agree_bit_for_bit(variant, seconds, fs, channels, number, distance):
+    """Bin F - 1 of `sim` / `simonline` (the one bin outside the 64-bin blocks of the selection kernels): the wave-per-frame
+    kernel of round 6 (rank by counting, the network's pad slots as counts) against the lane-per-frame kernel that runs the
+    selection network itself (REPET_NYQUIST=lane) -- odd and even lists, lists shorter than their network (pads on both
+    sides), more than 64 entries (both registers of a lane), one to three channels. A selection: the same bits."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "repet.similarity_number = {number}; repet.similarity_distance = {distance}; "
+            "x = synth({seconds}, {fs}, {channels}, 41); y = repet.{variant}(x, {fs}); np.save(sys.argv[1], y)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (code % (os.path.join(root, "repet-python_amd"), root)).format(number=number, distance=distance, seconds=seconds, fs=fs,
+                                                                          channels=channels, variant=variant)
+    outs = []
+    for path in ("lists", "wave", "lane"):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_nyquist_{path}_{os.getpid()}.npy")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, REPET_NYQUIST=path))
+        outs.append(np.load(out))
+        os.remove(out)
+    assert np.array_equal(outs[0], outs[2], equal_nan=True) and np.array_equal(outs[1], outs[2], equal_nan=True)
 
 
 def test_long_similarity_number_uses_bisection_path():

@@ -13,6 +13,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import kernel_name  # noqa: E402  (full names: `stft_reg_kernel<2>`, not "void repet::")
+
 root, out = sys.argv[1], sys.argv[2]
 # kernel name fragment -> (stage, fetch correction k, note)
 KERNELS = [
@@ -28,7 +31,7 @@ KERNELS = [
     ("mask_sim_bits_kernel", "mask_sim_select", 1, "4 B/lane gathers of plane rows"),
     ("mask_from_codes_kernel", "mask_sim", 1, "8-16 B/lane streams beside 4-byte table reads: uncalibrated"),
     ("code_planes_from_columns_kernel", "rank_columns", 2, "16 B/lane"),
-    ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist_kernel", "mask_sim", 1, "4 B/lane gathers"),
+    ("mask_sim_rank_kernel", "mask_sim", 1, "4-16 B/lane gathers"), ("mask_sim_nyquist", "mask_sim", 1, "4 B/lane gathers"),
     ("mask_sim_kernel", "mask_sim", 1, "4 B/lane gathers"),
     ("istft_ola_reg_kernel", "istft_ola", 2, "16 B/lane spectrum loads"), ("istft_ola", "istft_ola", 1, "4-8 B/lane"),
     # the second level of the peak picking (inside the peak-picking stage)
@@ -59,7 +62,7 @@ for kernel, counters in acc.items():
     st["fetch_bytes"] += fetch * k
     st["write_bytes"] += write
     st["hbm_bytes_per_launch"] += fetch * k + write
-    st["kernels"].append({"kernel": kernel.split("(")[0][-60:], "fetch_counted": fetch, "k": k, "write": write})
+    st["kernels"].append({"kernel": kernel_name(kernel), "fetch_counted": fetch, "k": k, "write": write})
     st["fetch_correction"] = (st["fetch_correction"] + "; " if st["fetch_correction"] else "") + f"x{k} ({width})"
 doc = {"_about": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_profile.sh) for bench.py's default workload "
                  "(repet.sim, 180 s, 44.1 kHz stereo), mean per launch. Bytes = WRITE_SIZE*1024 + FETCH_SIZE*1024*k, k = 2 for kernels whose "
