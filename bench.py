@@ -112,9 +112,8 @@ def scatter_gather_leg(dist, rank, world, local_rank, algo, fs, channels, second
     timings = {}
 
     def one_round():
-        if dist is None:                     # one process, one GPU: the root's own share is everything
-            repet.set_device(local_rank)
-            return [getattr(repet, algo)(c, fs) for c in clips]
+        if dist is None:                     # one process, one GPU: the root's own share is everything -- two clips in flight (repet_run_stream)
+            return repet.run_batch(algo, clips, fs, device=local_rank, depth=int(os.environ.get("REPET_BENCH_DEPTH", "2")))
         timings.clear()
         return parallel.separate_clips(algo, clips, fs, device=local_rank, stage_device=local_rank if shared_gpu else None, timings=timings)
 

@@ -274,6 +274,14 @@ int repet_last_batch_info(int64_t out[4]);
 /* The resident clip as the engine holds it: the fp32 samples and, for a float64 upload, their fp32 remainders
  * (x - (double)(float)x; zeros and *has_remainders = 0 when none was needed). [n_clips][n_samples][n_channels] floats each. */
 int repet_ctx_download_input(repet_ctx* ctx, float* samples_out, float* remainders_out, int32_t* has_remainders);
+/* (ABI 4) Clips one after another through ONE device with `depth` (1 .. 8) of them in flight: every clip in flight has a
+ * context of its own (stream, pinned ring, workspaces), so clip k + 1 is narrowed and uploaded and clip k - 1 copied back and
+ * widened while clip k is separated. Results are what repet_run gives for each clip, bit for bit. The contexts stay cached
+ * for the next call; repet_release_thread_ctx frees them. (What a root rank does with its own share of a scattered batch,
+ * and the one-GPU form of repet.run_batch.) */
+int repet_run_stream(int algo, int32_t n_clips, const void* const* audio, int dtype,
+                     const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
+                     double* const* out, int device, int32_t depth);
 int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype,
                          const int64_t* n_samples, const int32_t* n_channels, const repet_params* p,
                          double* const* out, int32_t n_devices);

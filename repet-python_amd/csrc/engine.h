@@ -190,7 +190,9 @@ extern thread_local BatchInfo g_batch_info;
 
 int logical_device_count(int physical);
 int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
-                   const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices, int transport);
+                   const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices, int transport,
+                   int one_device = -1);
+void release_stream_contexts();
 float peak_refine_delta(int FS, bool f16_gram);
 double peak_exact_delta2();
 int ensure_stamps(repet_ctx* c, DevBuf& buf, size_t count);

@@ -1107,6 +1107,7 @@ int repet_median_network_info(int32_t list_bound, int32_t* network_size, int32_t
 int repet_release_thread_ctx(void) {
     for (auto& kv : g_thread_ctx.by_device) repet_ctx_destroy(kv.second);
     g_thread_ctx.by_device.clear();
+    release_stream_contexts();                     // (the idle contexts of repet_run_stream: process-wide)
     return REPET_OK;
 }
 

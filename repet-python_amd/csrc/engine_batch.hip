@@ -6,6 +6,8 @@ using namespace repet_eng;
 
 #include <dlfcn.h>
 
+#include <atomic>
+
 namespace repet_eng {
 
 // Logical devices (test switch): REPET_LOGICAL_DEVICES=n lets repet_run_batch deal its clips over n "devices" although
@@ -63,18 +65,51 @@ struct Rccl {
         if (r_ != 0) return fail(REPET_ERR_HIP, std::string(#expr) + ": " + (rc.GetErrorString ? rc.GetErrorString(r_) : "RCCL error")); \
     } while (0)
 
+// Contexts of repet_run_stream, kept between calls: per device a list of idle ones. A call takes `depth` of them (creating what
+// is missing) and gives them back; concurrent calls get disjoint sets.
+struct StreamPool {
+    std::mutex mu;
+    std::map<int, std::vector<repet_ctx*>> idle;
+    static StreamPool& get() { static StreamPool* p = new StreamPool(); return *p; }
+    int take(int device, int n, std::vector<repet_ctx*>* out) {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<repet_ctx*>& v = idle[device];
+        while ((int)out->size() < n && !v.empty()) { out->push_back(v.back()); v.pop_back(); }
+        while ((int)out->size() < n) {
+            repet_ctx* c = nullptr;
+            RP_TRY(repet_ctx_create(device, &c));
+            out->push_back(c);
+        }
+        return REPET_OK;
+    }
+    void give_back(int device, const std::vector<repet_ctx*>& cs) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (repet_ctx* c : cs) idle[device].push_back(c);
+    }
+    void release() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& kv : idle) for (repet_ctx* c : kv.second) repet_ctx_destroy(c);
+        idle.clear();
+    }
+};
+void release_stream_contexts() { StreamPool::get().release(); }
+
 // transport 0: every device's worker thread uploads its own clips from the caller's host arrays and downloads its own
 // results (with the data in host RAM this uses every device's own PCIe link: SURVEY 8e's "honest comparison").
 // transport 1: the clips enter through device 0, travel to their devices as ONE group of ncclSend / ncclRecv over xGMI
 // (fp32, interleaved), are separated there from the received device buffers, and the results come back the same way.
+// transport 2 (repet_run_stream): ONE device (`one_device`), n_devices = clips in flight -- the workers of transport 0, all on
+// that device, each with its own context and stream.
 int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
-                   const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices, int transport) {
+                   const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices, int transport,
+                   int one_device) {
     if (n_clips < 0 || (n_clips > 0 && (!audio || !n_samples || !n_channels || !out)))
         return fail(REPET_ERR_BAD_ARG, "null argument");
     const int physical = repet_device_count();
     if (physical < 1) return fail(REPET_ERR_HIP, "no HIP device");
-    const int avail = transport == 1 ? physical : logical_device_count(physical);     // (RCCL needs distinct physical devices)
-    if (n_devices < 1 || n_devices > avail) return fail(REPET_ERR_BAD_ARG, "n_devices out of range");
+    const int avail = transport == 1 ? physical : transport == 2 ? 8 : logical_device_count(physical);     // (RCCL needs distinct physical devices)
+    if (n_devices < 1 || n_devices > avail) return fail(REPET_ERR_BAD_ARG, transport == 2 ? "depth must be 1 .. 8" : "n_devices out of range");
+    if (transport == 2 && (one_device < 0 || one_device >= physical)) return fail(REPET_ERR_BAD_ARG, "no such device");
     // longest first, dealt round-robin: clip order[i] -> device i % n_devices
     std::vector<int> order(n_clips);
     std::iota(order.begin(), order.end(), 0);
@@ -95,6 +130,33 @@ int run_batch_impl(int algo, int32_t n_clips, const void* const* audio, int dtyp
         return REPET_OK;
     };
 
+    if (transport == 2) {
+        // `depth` clips in flight on one device: worker j takes clips j, j + depth, ... through a context of its own (stream,
+        // pinned ring, workspaces), so that while one clip is being separated the next is narrowed and uploaded and the one
+        // before is copied back and widened -- PCIe both ways and the kernels side by side, the host conversions taking turns
+        // chunk by chunk (hostio.hip). The contexts are kept for the next call (a context's workspaces are half a gigabyte
+        // for a 3-minute clip; repet_release_thread_ctx frees them).
+        g_batch_info = BatchInfo{};
+        std::vector<repet_ctx*> taken;
+        const int rc_take = StreamPool::get().take(one_device, n_devices, &taken);
+        if (rc_take != REPET_OK) { StreamPool::get().give_back(one_device, taken); return rc_take; }
+        std::atomic<int> next{0};
+        run_threads([&](int j) {
+            repet_ctx* c = taken[j];
+            c->strict = !(p && (p->flags & REPET_FLAG_REFUSE_NONFINITE));
+            int rc = REPET_OK;
+            // (clips in the caller's order, whichever worker is free takes the next: the results of equal clips come back in order)
+            for (int i = next.fetch_add(1); rc == REPET_OK && i < n_clips; i = next.fetch_add(1)) {
+                rc = repet_ctx_upload(c, audio[i], dtype, n_samples[i], n_channels[i]);
+                if (rc == REPET_OK) rc = repet_ctx_execute_async(c, algo, p);
+                if (rc == REPET_OK) rc = repet_ctx_download(c, out[i]);
+            }
+            if (rc != REPET_OK) msgs[j] = g_last_error;
+            rcs[j] = rc;
+        });
+        StreamPool::get().give_back(one_device, taken);
+        return first_error();
+    }
     if (transport != 1) {
         g_batch_info = BatchInfo{};
         run_threads([&](int dev) {
@@ -294,6 +356,11 @@ int repet_last_batch_info(int64_t out[4]) {
 int repet_run_batch(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
                     const int32_t* n_channels, const repet_params* p, double* const* out, int32_t n_devices) {
     return run_batch_impl(algo, n_clips, audio, dtype, n_samples, n_channels, p, out, n_devices, 0);
+}
+
+int repet_run_stream(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,
+                     const int32_t* n_channels, const repet_params* p, double* const* out, int device, int32_t depth) {
+    return run_batch_impl(algo, n_clips, audio, dtype, n_samples, n_channels, p, out, depth, 2, device);
 }
 
 int repet_run_batch_rccl(int algo, int32_t n_clips, const void* const* audio, int dtype, const int64_t* n_samples,

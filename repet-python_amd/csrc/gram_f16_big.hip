@@ -67,11 +67,20 @@ constexpr int kBigLds = kPatchLds > kLoopLds ? kPatchLds : kLoopLds;
 // patches the stores read: lane l takes row l of the 64 x 64 patch, i.e. two segments of 32 columns.
 __global__ __launch_bounds__(512) void gram_f16_big_pipe_kernel(const _Float16* __restrict__ planes, int64_t T, int FS,
                                                            float* __restrict__ out, int64_t pitch,
-                                                           const int2* __restrict__ tiles, float* __restrict__ seg, int seg_pitch) {
+                                                           const int2* __restrict__ tiles, float* __restrict__ seg, int seg_pitch,
+                                                           int stagger_ticks, int stagger_groups) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds_big[];
     const int2 tile = tiles[blockIdx.x];
     const int bi = tile.x, bj = tile.y;
     if (bi < 0) return;
+    // Experiment of round 6 (REPET_GRAM_STAGGER_US = d, REPET_GRAM_STAGGER_GROUPS = g; default off): the workgroups of the FIRST
+    // round start in g groups, group q held back by q d microseconds, so that the store bursts at the end of a round (all 256
+    // workgroups leave their K loops together: 128 MB) arrive in g pieces under the other groups' MFMAs.
+    if (stagger_ticks > 0 && blockIdx.x < 256u) {
+        const int q = (int)((blockIdx.x >> 3) % (unsigned)stagger_groups);      // (the eight XCDs alike)
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(q * stagger_ticks);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -348,8 +357,10 @@ hipError_t launch_gram_full_f16_big(const void* planes, int64_t T, int32_t FS, f
     if (T <= 0 || n_tiles <= 0) return hipSuccess;
     hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_f16_big_pipe_kernel), kBigLds);
     if (attr != hipSuccess) return attr;
+    static const int stagger_ticks = [] { const char* e = getenv("REPET_GRAM_STAGGER_US"); return e ? (int)(100.0 * atof(e)) : 0; }();
+    static const int stagger_groups = [] { const char* e = getenv("REPET_GRAM_STAGGER_GROUPS"); const int g = e ? atoi(e) : 2; return g < 2 ? 2 : g; }();
     hipLaunchKernelGGL(gram_f16_big_pipe_kernel, dim3((unsigned)n_tiles), dim3(512), kBigLds, s,
-                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, seg, seg_pitch);
+                       reinterpret_cast<const _Float16*>(planes), T, FS, S, TS, tiles, seg, seg_pitch, stagger_ticks, stagger_groups);
     return hipGetLastError();
 }
 

@@ -13,6 +13,10 @@
 // module wraps them as NumPy arrays, so a result array is already faulted-in and pinned when the next call fills it.
 #include "common.h"
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -257,8 +261,148 @@ REPET_HOST_CLONES bool narrow_f32(const float* src, float* dst, size_t lo, size_
 REPET_HOST_CLONES void narrow_i16(const int16_t* src, float* dst, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) dst[i] = (float)src[i];
 }
-REPET_HOST_CLONES void widen_f32(const float* src, double* dst, size_t lo, size_t hi) {
+REPET_HOST_CLONES void widen_f32_plain(const float* src, double* dst, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) dst[i] = (double)src[i];
+}
+// Round 6: the big conversions write with NON-TEMPORAL stores. A plain store of a line the core does not own reads the line
+// first: widening a 3-minute stereo result (127 MB of float64) read those 127 MB for nothing and pushed the caller's other
+// data out of the caches; the staging ring is read by the DMA engine only. Streams of whole 64-byte lines (the head of a part
+// goes the plain way up to the first line boundary); a store fence closes every part -- the hand-over to the thread that
+// issues the DMA (or returns the result) is an ordinary atomic, which non-temporal stores are not ordered with.
+// REPET_HOST_NT=0: plain stores everywhere (A/B).
+static bool host_nt() {
+    static const bool on = [] { const char* e = getenv("REPET_HOST_NT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static inline void store_fence() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_sfence();
+#endif
+}
+// (explicit intrinsics: hipcc's host pass drops __builtin_nontemporal_store's hint AND leaves such a loop scalar)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define REPET_HOST_X86 1
+__attribute__((target("avx512f"))) static void widen_lines_512(const float* s, double* d, size_t n) {      // d on a 64-byte boundary
+    size_t k = 0;
+    for (; k + 16 <= n; k += 16) {
+        _mm512_stream_pd(d + k, _mm512_cvtps_pd(_mm256_loadu_ps(s + k)));
+        _mm512_stream_pd(d + k + 8, _mm512_cvtps_pd(_mm256_loadu_ps(s + k + 8)));
+    }
+    for (; k < n; ++k) d[k] = (double)s[k];
+}
+__attribute__((target("avx2"))) static void widen_lines_256(const float* s, double* d, size_t n) {
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) {
+        _mm256_stream_pd(d + k, _mm256_cvtps_pd(_mm_loadu_ps(s + k)));
+        _mm256_stream_pd(d + k + 4, _mm256_cvtps_pd(_mm_loadu_ps(s + k + 4)));
+    }
+    for (; k < n; ++k) d[k] = (double)s[k];
+}
+// float64 -> fp32 sample + fp32 remainder, both planes as whole lines (ph, pl on 64-byte boundaries); true: a sample was not finite
+__attribute__((target("avx512f"))) static bool split_lines_512(const double* s, float* ph, float* pl, size_t n) {
+    const __m512d big = _mm512_set1_pd(std::numeric_limits<double>::max());
+    __mmask8 fine = 0xff;
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) {
+        const __m512d x = _mm512_loadu_pd(s + k);
+        const __m256 h = _mm512_cvtpd_ps(x);
+        _mm256_stream_ps(ph + k, h);
+        _mm256_stream_ps(pl + k, _mm512_cvtpd_ps(_mm512_sub_pd(x, _mm512_cvtps_pd(h))));
+        fine &= _mm512_cmp_pd_mask(_mm512_abs_pd(x), big, _CMP_LE_OQ);
+    }
+    bool bad = fine != 0xff;
+    for (; k < n; ++k) {
+        const double x = s[k];
+        const float h = (float)x;
+        ph[k] = h;
+        pl[k] = (float)(x - (double)h);
+        bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+    }
+    return bad;
+}
+__attribute__((target("avx2"))) static bool split_lines_256(const double* s, float* ph, float* pl, size_t n) {
+    const __m256d big = _mm256_set1_pd(std::numeric_limits<double>::max());
+    const __m256d sign = _mm256_set1_pd(-0.0);
+    int fine = 0xf;
+    size_t k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const __m256d x = _mm256_loadu_pd(s + k);
+        const __m128 h = _mm256_cvtpd_ps(x);
+        _mm_stream_ps(ph + k, h);
+        _mm_stream_ps(pl + k, _mm256_cvtpd_ps(_mm256_sub_pd(x, _mm256_cvtps_pd(h))));
+        fine &= _mm256_movemask_pd(_mm256_cmp_pd(_mm256_andnot_pd(sign, x), big, _CMP_LE_OQ));
+    }
+    bool bad = fine != 0xf;
+    for (; k < n; ++k) {
+        const double x = s[k];
+        const float h = (float)x;
+        ph[k] = h;
+        pl[k] = (float)(x - (double)h);
+        bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+    }
+    return bad;
+}
+// float64 -> fp32 samples only (ph on a 64-byte boundary), the remainders TESTED: bit 0 of the result = a remainder is not
+// zero, bit 1 = a sample is not finite
+__attribute__((target("avx512f"))) static int narrow_test_lines_512(const double* s, float* ph, size_t n) {
+    const __m512d big = _mm512_set1_pd(std::numeric_limits<double>::max());
+    __mmask8 fine = 0xff, exact = 0xff;
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) {
+        const __m512d x = _mm512_loadu_pd(s + k);
+        const __m256 h = _mm512_cvtpd_ps(x);
+        _mm256_stream_ps(ph + k, h);
+        exact &= _mm512_cmp_pd_mask(x, _mm512_cvtps_pd(h), _CMP_EQ_OQ);        // (NaN: not equal -- its remainder must travel)
+        fine &= _mm512_cmp_pd_mask(_mm512_abs_pd(x), big, _CMP_LE_OQ);
+    }
+    int out = (exact != 0xff ? 1 : 0) | (fine != 0xff ? 2 : 0);
+    for (; k < n; ++k) {
+        const double x = s[k];
+        const float h = (float)x;
+        ph[k] = h;
+        out |= (x != (double)h) ? 1 : 0;
+        out |= !(std::fabs(x) <= std::numeric_limits<double>::max()) ? 2 : 0;
+    }
+    return out;
+}
+__attribute__((target("avx2"))) static int narrow_test_lines_256(const double* s, float* ph, size_t n) {
+    const __m256d big = _mm256_set1_pd(std::numeric_limits<double>::max());
+    const __m256d sign = _mm256_set1_pd(-0.0);
+    int fine = 0xf, exact = 0xf;
+    size_t k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const __m256d x = _mm256_loadu_pd(s + k);
+        const __m128 h = _mm256_cvtpd_ps(x);
+        _mm_stream_ps(ph + k, h);
+        exact &= _mm256_movemask_pd(_mm256_cmp_pd(x, _mm256_cvtps_pd(h), _CMP_EQ_OQ));
+        fine &= _mm256_movemask_pd(_mm256_cmp_pd(_mm256_andnot_pd(sign, x), big, _CMP_LE_OQ));
+    }
+    int out = (exact != 0xf ? 1 : 0) | (fine != 0xf ? 2 : 0);
+    for (; k < n; ++k) {
+        const double x = s[k];
+        const float h = (float)x;
+        ph[k] = h;
+        out |= (x != (double)h) ? 1 : 0;
+        out |= !(std::fabs(x) <= std::numeric_limits<double>::max()) ? 2 : 0;
+    }
+    return out;
+}
+static int host_simd() {            // 2: AVX-512F, 1: AVX2, 0: neither
+    static const int level = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
+    return level;
+}
+#endif
+void widen_f32(const float* src, double* dst, size_t lo, size_t hi) {
+#ifdef REPET_HOST_X86
+    if (host_nt() && hi - lo >= 4096 && host_simd() > 0) {
+        size_t i = lo;
+        for (; i < hi && (reinterpret_cast<uintptr_t>(dst + i) & 63); ++i) dst[i] = (double)src[i];
+        if (host_simd() == 2) widen_lines_512(src + i, dst + i, hi - i); else widen_lines_256(src + i, dst + i, hi - i);
+        store_fence();
+        return;
+    }
+#endif
+    widen_f32_plain(src, dst, lo, hi);
 }
 
 // float64 -> the fp32 sample and the fp32 remainder (hi + lo carries 48 bits of the double); true when a remainder is not zero
@@ -269,6 +413,31 @@ REPET_HOST_CLONES bool split_part(const double* src, float* dst_hi, float* dst_l
     constexpr size_t kBlock = 1024;
     size_t i = lo;
     bool bad = false;
+#ifdef REPET_HOST_X86
+    const bool lines = host_nt() && host_simd() > 0 && hi - lo >= 4096;
+    if (lines) {                                  // the head of the part up to the first line boundary, the plain way
+        bool any = false;
+        size_t k = lo;
+        for (; k < hi && (reinterpret_cast<uintptr_t>(dst_hi + k) & 63); ++k) {
+            const double x = src[k];
+            const float h = (float)x;
+            dst_hi[k] = h;
+            any |= (x != (double)h);
+            bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+        }
+        if (any) i = lo;                          // (a remainder already: the second loop redoes the part from its start)
+        else {
+            for (i = k; i < hi; i += kBlock) {
+                const size_t end = std::min(hi, i + kBlock);
+                const int r = host_simd() == 2 ? narrow_test_lines_512(src + i, dst_hi + i, end - i) : narrow_test_lines_256(src + i, dst_hi + i, end - i);
+                bad |= (r & 2) != 0;
+                if (r & 1) break;
+            }
+            store_fence();
+        }
+    }
+    if (!lines)
+#endif
     for (; i < hi; i += kBlock) {
         const size_t end = std::min(hi, i + kBlock);
         bool any = false;
@@ -283,7 +452,23 @@ REPET_HOST_CLONES bool split_part(const double* src, float* dst_hi, float* dst_l
     }
     if (i < hi) {
         std::memset(dst_lo + lo, 0, (i - lo) * sizeof(float));
-        for (size_t k = i; k < hi; ++k) {
+        size_t k = i;
+#ifdef REPET_HOST_X86
+        if (host_nt() && host_simd() > 0 && ((reinterpret_cast<uintptr_t>(dst_hi) ^ reinterpret_cast<uintptr_t>(dst_lo)) & 63) == 0) {
+            // both planes as streams of whole lines (they share their alignment: same offset into two 64-byte-aligned buffers)
+            for (; k < hi && (reinterpret_cast<uintptr_t>(dst_hi + k) & 63); ++k) {
+                const double x = src[k];
+                const float h = (float)x;
+                dst_hi[k] = h;
+                dst_lo[k] = (float)(x - (double)h);
+                bad |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+            }
+            bad |= host_simd() == 2 ? split_lines_512(src + k, dst_hi + k, dst_lo + k, hi - k) : split_lines_256(src + k, dst_hi + k, dst_lo + k, hi - k);
+            store_fence();
+            k = hi;
+        }
+#endif
+        for (; k < hi; ++k) {
             const double x = src[k];
             const float h = (float)x;
             dst_hi[k] = h;

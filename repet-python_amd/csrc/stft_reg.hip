@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
     if (tid < 64) tw_lds[16 * 64 + tid] = a.twiddle[32 * (tid >> 4) * (tid & 15)];    // exp(-2 pi i m2 j1 / 64)
     for (int i = tid; i < N; i += 64 * kFwdWaves) {
         win_lds[i] = *reinterpret_cast<const float2*>(a.window + 2 * i);
-        split_lds[i] = a.twiddle[i];
+        const float2 w = a.twiddle[i];
+        split_lds[i] = make_float2(0.5f * w.x, 0.5f * w.y);       // W^k / 2 (exact)
     }
     const RegTwiddles tw{tw_lds, tw_lds + 16 * 64};
     __syncthreads();
@@ -308,31 +309,42 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             float* Vrow = Vb + c * a.chan_stride + row;
             // Hermitian split: X[k] = E + W_2048^k O with E = (Z[k] + conj Z[N-k]) / 2, O = (Z[k] - conj Z[N-k]) / 2i.
             // Z[N-k] for k = lane + 64 s is slot 15 - s of lane 64 - lane (lane 0: its own slot (16 - s) & 15).
+            // Round 6: bins k and N - k come out of the SAME two values -- E[N-k] = conj E[k], O[N-k] = conj O[k], W^(N-k) = -conj W^k,
+            // so X[N-k] = conj(E - W^k O) -- and a lane now takes its slots s < 8 only, in pairs: X[k] for its own bin and X[N-k]
+            // for the bin that lane 64 - lane holds in slot 15 - s (which in turn serves this lane's slots 8 .. 15). Twelve
+            // instructions per PAIR where every bin took twenty, half the cross-lane fetches; the table holds W^k / 2. The pair
+            // (0, N) is lane 0's slot 0 (Z[N] = Z[0]), so the Nyquist bin needs no code of its own; bin N/2 pairs with itself:
+            // X[512] = conj Z[512], lane 0's slot 8. Accumulators: acc[s] bin lane + 64 s, acc[8 + s] bin N - lane - 64 s, acc[16] bin 512.
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int k = lane + 64 * s;
+            for (int s = 0; s < 8; ++s) {
+                const int k = lane + 64 * s, km = N - k;
                 const float2 zk = v[s];
                 const float2 other = make_float2(lane_fetch(v[15 - s].x, partner), lane_fetch(v[15 - s].y, partner));
                 const float2 mine = v[(16 - s) & 15];
                 const float2 zn = (lane == 0) ? mine : other;
-                const float2 zc = cconj(zn);
-                const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
-                const float2 d = csub(zk, zc);
-                const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
-                const float2 x = cadd(e, cmul(split_lds[k], o));
-                const float mag = magnitude(x);
+                const float sx = zk.x + zn.x, sy = zk.y - zn.y;           // Z[k] + conj Z[N-k]
+                const float dx = zk.x - zn.x, dy = zk.y + zn.y;           // Z[k] - conj Z[N-k]
+                const float2 wh = split_lds[k];                            // W^k / 2
+                const float tx = fmaf(wh.x, dy, wh.y * dx);               // W^k O, O = (dy, -dx) / 2
+                const float ty = fmaf(wh.y, dy, -(wh.x * dx));
+                const float2 x = make_float2(fmaf(0.5f, sx, tx), fmaf(0.5f, sy, ty));
+                const float2 xm = make_float2(fmaf(0.5f, sx, -tx), fmaf(-0.5f, sy, ty));
+                const float mag = magnitude(x), magm = magnitude(xm);
                 // non-temporal: the spectrum is read again only after the similarity / period stages -- stored the ordinary way it
                 // pushes the magnitudes and unit rows those stages read next out of the caches (1-2 % of every variant's step)
-                { typedef float f2 __attribute__((ext_vector_type(2))); f2 y; y.x = x.x; y.y = x.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + k)); }
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                { f2 y; y.x = x.x; y.y = x.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + k)); }
+                { f2 y; y.x = xm.x; y.y = xm.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + km)); }
                 Vrow[k] = mag;
+                Vrow[km] = magm;
                 acc[s] += mag;
-                if ((s & (REPET_FWD_SPLIT_BATCH - 1)) == REPET_FWD_SPLIT_BATCH - 1) __builtin_amdgcn_sched_barrier(0);    // a few bins in flight, not sixteen
+                acc[8 + s] += magm;
+                if (s & 1) __builtin_amdgcn_sched_barrier(0);             // a few bins in flight, not sixteen
             }
-            {   // k = N (Nyquist): Z[N & (N-1)] = Z[0] on both sides, W_2048^N = -1
-                const float z0x = __shfl(v[0].x, 0), z0y = __shfl(v[0].y, 0);
-                const float2 x = make_float2(z0x - z0y, 0.f);
-                const float mag = magnitude(x);           // (not fabsf: the inverse recomputes every bin's magnitude the same way)
-                if (lane == 0) { Xrow[N] = x; Vrow[N] = mag; }
+            {   // k = N / 2: its own partner, W_2048^(N/2) = -i: X = conj Z (lane 0's slot 8)
+                const float2 x = make_float2(v[8].x, -v[8].y);
+                const float mag = magnitude(x);
+                if (lane == 0) { Xrow[N / 2] = x; Vrow[N / 2] = mag; }
                 acc[16] += mag;
             }
             if (lane < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
@@ -379,21 +391,25 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         // masks per store (300 integer instructions per frame)
         const int64_t plane_lane = 2 * row + ((lane >> 5) << 6) + (lane & 31);
         _Float16* vh_lane = Vh ? static_cast<_Float16*>(Vh) + plane_lane : nullptr;
+        // the mirrored bins N - lane - 64 s = 960 - 64 s + j, j = 64 - lane (1 .. 64): block 30 - 2 s + (j >> 5), component j & 31
+        const int jm = 64 - lane;
+        const int64_t plane_mirror = 2 * row + (((int64_t)(30 + (jm >> 5))) << 6) + (jm & 31);
+        _Float16* vh_mirror = Vh ? static_cast<_Float16*>(Vh) + plane_mirror : nullptr;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = lane + 64 * s;
-            if (Vm) Vm[k] = acc[s];
-            const float unit = (acc[s] * pre) * inv_norm;
-            if (Vn) Vn[k] = unit;
-            if (Vh) store_split_f16_at(vh_lane + 128 * s, unit);
-            if (P) P[k] = acc[s] * acc[s];
-            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 8; ++s) {
+            const int k = lane + 64 * s, km = N - k;
+            if (Vm) { Vm[k] = acc[s]; Vm[km] = acc[8 + s]; }
+            const float unit = (acc[s] * pre) * inv_norm, unit_m = (acc[8 + s] * pre) * inv_norm;
+            if (Vn) { Vn[k] = unit; Vn[km] = unit_m; }
+            if (Vh) { store_split_f16_at(vh_lane + 128 * s, unit); store_split_f16_at(vh_mirror - 128 * s, unit_m); }
+            if (P) { P[k] = acc[s] * acc[s]; P[km] = acc[8 + s] * acc[8 + s]; }
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        if (lane == 0) {
-            if (Vm) Vm[N] = acc[16];
-            if (Vn) Vn[N] = (acc[16] * pre) * inv_norm;
-            if (Vh) store_split_f16(Vh, row + N, (acc[16] * pre) * inv_norm);
-            if (P) P[N] = acc[16] * acc[16];
+        if (lane == 0) {                                   // bin N / 2
+            if (Vm) Vm[N / 2] = acc[16];
+            if (Vn) Vn[N / 2] = (acc[16] * pre) * inv_norm;
+            if (Vh) store_split_f16(Vh, row + N / 2, (acc[16] * pre) * inv_norm);
+            if (P) P[N / 2] = acc[16] * acc[16];
         }
         if (lane < a.FS - (N + 1)) {
             if (Vm) Vm[N + 1 + lane] = 0.f;
@@ -412,12 +428,14 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             void* Ph = static_cast<void*>(static_cast<_Float16*>(a.Ph) + 2 * b * a.batch_mean_stride);
             if (lane == 0) a.Ph_inv[b * a.batch_inv_stride + t] = 1.0f / sc;
             _Float16* ph_lane = static_cast<_Float16*>(Ph) + plane_lane;
+            _Float16* ph_mirror = static_cast<_Float16*>(Ph) + plane_mirror;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < 8; ++s) {
                 store_split_f16_scaled_at(ph_lane + 128 * s, acc[s] * acc[s], sc);
-                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                store_split_f16_scaled_at(ph_mirror - 128 * s, acc[8 + s] * acc[8 + s], sc);
+                if (s & 1) __builtin_amdgcn_sched_barrier(0);
             }
-            if (lane == 0) store_split_f16_scaled(Ph, row + N, acc[16] * acc[16], sc);
+            if (lane == 0) store_split_f16_scaled(Ph, row + N / 2, acc[16] * acc[16], sc);
             if (lane < a.FS - (N + 1)) store_split_f16_scaled(Ph, row + N + 1 + lane, 0.f, sc);
         }
         RSTAMP(4)                                      // mean rows

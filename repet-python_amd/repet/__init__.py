@@ -160,10 +160,12 @@ def online(sampling_frequency, number_channels):
     return _OnlineSeparator(derive_params(sampling_frequency), number_channels, _device)
 
 
-def run_batch(algo, audio_signals, sampling_frequency, n_devices=1, transport="host"):
+def run_batch(algo, audio_signals, sampling_frequency, n_devices=1, transport="host", device=None, depth=None):
     """Separate a list of independent clips, dealt longest-first over ``n_devices`` GPUs of this process. ``transport``:
     "host" -- every device moves its own clips over its own PCIe link; "rccl" -- the clips enter through device 0 and
-    travel to their devices (and the results back) as grouped ncclSend / ncclRecv over xGMI."""
+    travel to their devices (and the results back) as grouped ncclSend / ncclRecv over xGMI. ``device`` / ``depth``: the clips
+    one after another through that ONE device with ``depth`` (default 2) of them in flight -- upload, kernels and download of
+    neighbouring clips side by side (``repet_run_stream``); every result is what the one-shot call returns, bit for bit."""
     import ctypes as C
     params = derive_params(sampling_frequency)
     ins, outs, ns, cs, code = [], [], [], [], None
@@ -184,6 +186,12 @@ def run_batch(algo, audio_signals, sampling_frequency, n_devices=1, transport="h
     count = len(ins)
     in_ptrs = (C.c_void_p * count)(*[x.ctypes.data for x in ins])
     out_ptrs = (C.c_void_p * count)(*[x.ctypes.data for x in outs])
+    if device is not None or depth is not None:
+        _native.check(_native.lib().repet_run_stream(
+            _native.ALGO_IDS[algo], count, in_ptrs, code if code is not None else _native.F64,
+            (C.c_int64 * count)(*ns), (C.c_int32 * count)(*cs), params, out_ptrs, int(_device if device is None else device),
+            int(2 if depth is None else depth)))
+        return outs
     entry = _native.lib().repet_run_batch_rccl if transport == "rccl" else _native.lib().repet_run_batch
     _native.check(entry(
         _native.ALGO_IDS[algo], count, in_ptrs, code if code is not None else _native.F64,

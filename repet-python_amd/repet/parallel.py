@@ -217,65 +217,77 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     io = _context(("io", dev.index)) if (on_gpu and separate_fn is None and np.dtype(wire_dtype) == np.float32) else None
 
     shares_of = lambda shapes_: deal_clips([s[0] for s in shapes_], world)
-    planes = {}
     meta = [None]
     if rank == root:
-        shapes = [(int(c.shape[0]), int(c.shape[1])) for c in clips]
-        with_lo = [False] * len(shapes)
-        if np.dtype(wire_dtype) == np.float32:                 # (a float64 wire carries everything in one plane)
-            for r, ids in enumerate(shares_of(shapes)):
-                if r != root:
-                    for i in ids:
-                        planes[i] = _split_on_device(io, clips[i], dev) if io is not None else split_float64(clips[i])
-                        with_lo[i] = planes[i][1] is not None
-        meta = [(shapes, with_lo)]
+        meta = [[(int(c.shape[0]), int(c.shape[1])) for c in clips]]
     dist.broadcast_object_list(meta, src=root)
-    shapes, with_lo = meta[0]
+    shapes = meta[0]
     shares = shares_of(shapes)
+    split_wire = np.dtype(wire_dtype) == np.float32             # (a float64 wire carries everything in one plane)
 
     if rank == root:
-        pending = []
-        for r, ids in enumerate(shares):                       # the workers' clips leave first, then the root computes
-            if r != root:
-                for i in ids:
-                    if i in planes:
-                        hi, lo = planes.pop(i)
-                        pending.append(dist.isend(hi if isinstance(hi, torch.Tensor) else _wire(hi, wire_dtype, dev), dst=r))
-                        if lo is not None:
-                            pending.append(dist.isend(lo if isinstance(lo, torch.Tensor) else _wire(lo, wire_dtype, dev), dst=r))
-                    else:
-                        pending.append(dist.isend(_wire(clips[i], wire_dtype, dev), dst=r))
+        # The root is a PIPELINE (round 6; before, it split every travelling clip, then sent them all, then separated its own,
+        # then fetched the results one by one: 8.8 ms per clip of a batch against 5.6 ms for the same clip through the drop-in).
+        # A worker's clip leaves as soon as IT has been narrowed -- the worker separates while the root narrows the next one;
+        # a one-word header in front of the planes says whether a remainder plane follows, so nobody waits for a table of the
+        # whole batch. The receives of all results are posted before the root turns to its own share, which goes through
+        # repet_run_stream (upload, kernels and download of neighbouring clips side by side); the results are widened in the
+        # order the workers finish their first clips.
+        pending, keep = [], []
+        order = [(r, i) for k in range(max((len(ids) for ids in shares), default=0)) for r, ids in enumerate(shares) if r != root and k < len(ids) for i in [ids[k]]]
+        for r, i in order:                                      # every worker's first clip, then every worker's second, ...
+            if split_wire:
+                hi, lo = _split_on_device(io, clips[i], dev) if io is not None else split_float64(clips[i])
+            else:
+                hi, lo = clips[i], None
+            hi = hi if isinstance(hi, torch.Tensor) else _wire(hi, wire_dtype, dev)
+            lo = None if lo is None else (lo if isinstance(lo, torch.Tensor) else _wire(lo, wire_dtype, dev))
+            header = torch.tensor([1 if lo is not None else 0], dtype=torch.int32, device=dev)
+            keep += [header, hi, lo]
+            pending.append(dist.isend(header, dst=r))
+            pending.append(dist.isend(hi, dst=r))
+            if lo is not None:
+                pending.append(dist.isend(lo, dst=r))
         out = [None] * len(shapes)
+        boxes = {i: torch.empty(shapes[i], dtype=tdtype, device=dev) for r, i in order}
+        arrivals = [(i, dist.irecv(boxes[i], src=r)) for r, i in order]
         t_c = time.perf_counter()
-        for i in shares[root]:
-            out[i] = np.ascontiguousarray(_host(fn(np.asarray(clips[i]), sampling_frequency)), dtype=np.float64)
+        own = list(shares[root])
+        if separate_fn is None and len(own) > 1 and engine_device is not None:
+            import repet
+            for i, y in zip(own, repet.run_batch(algo, [np.asarray(clips[i]) for i in own], sampling_frequency, device=engine_device, depth=2)):
+                out[i] = y
+        else:
+            for i in own:
+                out[i] = np.ascontiguousarray(_host(fn(np.asarray(clips[i]), sampling_frequency)), dtype=np.float64)
         compute_s = time.perf_counter() - t_c
+        for i, req in arrivals:
+            req.wait()
+            if io is not None:
+                torch.cuda.current_stream(dev).synchronize()       # the receive has landed
+                out[i] = io.download_from(boxes[i].data_ptr(), shapes[i])
+            else:
+                out[i] = _host(boxes[i]).astype(np.float64)
+            boxes[i] = None
         for req in pending:
             req.wait()
-        for r, ids in enumerate(shares):
-            if r != root:
-                for i in ids:
-                    t = torch.empty(shapes[i], dtype=tdtype, device=dev)
-                    dist.recv(t, src=r)
-                    if io is not None:
-                        torch.cuda.current_stream(dev).synchronize()       # the receive has landed
-                        out[i] = io.download_from(t.data_ptr(), shapes[i])
-                    else:
-                        out[i] = _host(t).astype(np.float64)
         if timings is not None:
             timings.update(compute_ms=compute_s * 1e3, total_ms=(time.perf_counter() - t_start) * 1e3, clips=len(shares[root]))
         return out
 
-    received = []
-    for i in shares[rank]:
+    def receive(i):
+        header = torch.empty(1, dtype=torch.int32, device=dev)
+        dist.recv(header, src=root)
         t = torch.empty(shapes[i], dtype=tdtype, device=dev)
         dist.recv(t, src=root)
         lo = None
-        if with_lo[i]:
+        if int(header.item()):
             lo = torch.empty(shapes[i], dtype=tdtype, device=dev)
             dist.recv(lo, src=root)
-        received.append((t, lo))
-    for t, lo in received:
+        return t, lo
+
+    for i in shares[rank]:                                      # (a clip is separated as soon as it is here: the next one arrives meanwhile)
+        t, lo = receive(i)
         if stage is not None:                                  # (gloo wire, engine on a GPU: the worker's device-resident path)
             t, lo = t.to(stage), (lo.to(stage) if lo is not None else None)
         as_arg = (lambda v: v) if (on_gpu or stage is not None) else (lambda v: v.numpy())

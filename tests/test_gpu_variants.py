@@ -597,6 +597,38 @@ def test_rccl_transport_sends_to_itself_and_carries_the_remainders(monkeypatch):
     assert repet.last_batch_info()["clips_sent"] == 0 and repet.last_batch_info()["transport"] == "host"
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3, 5])
+def test_clips_in_flight_on_one_device_equal_the_one_shot_calls(depth, monkeypatch):
+    """repet_run_stream (repet.run_batch(..., device=, depth=)): clips one after another through one device with `depth` of them
+    in flight, each in a context of its own -- upload, kernels and download of neighbouring clips overlap. Every result must be
+    the one-shot call's, bit for bit, whatever the depth, for clips of different lengths, channel counts and dtypes (float64
+    with remainders, PCM-exact, float32), for every variant; a second call reuses the pooled contexts; a refused clip reports
+    its error and leaves the pool usable."""
+    fs = 16000
+    clips = [synth(d, fs, c, s) for d, c, s in [(21, 2, 3), (14, 1, 4), (17, 2, 5), (13, 2, 6), (25, 1, 7), (12, 2, 8), (19, 2, 9)]]
+    clips[3] = np.round(clips[3] * 32768.0).clip(-32768, 32767) / 32768.0
+    for algo in ("sim", "original", "simonline"):            # (simonline: every clip longer than its 10-s buffer)
+        outs = repet.run_batch(algo, clips, fs, device=0, depth=depth)
+        for x, y in zip(clips, outs):
+            assert np.array_equal(y, getattr(repet, algo)(x, fs)), algo
+    f32 = [c.astype(np.float32) for c in clips[:3]]
+    for x, y in zip(f32, repet.run_batch("adaptive", f32, fs, device=0, depth=depth)):
+        assert y.dtype == np.float64 and np.array_equal(y, repet.adaptive(x, fs))
+    assert repet.run_batch("sim", [], fs, device=0, depth=depth) == []
+    bad = clips[1].copy()
+    bad[5000, 0] = np.nan
+    with np.errstate(all="ignore"):
+        got = repet.run_batch("sim", [clips[0], bad, clips[2]], fs, device=0, depth=depth)
+    assert np.array_equal(got[1], repet.sim(bad, fs), equal_nan=True) and np.isnan(got[1]).any() and np.array_equal(got[2], repet.sim(clips[2], fs))
+    monkeypatch.setattr(repet, "strict_reference", False)
+    with pytest.raises(ValueError, match="NaN or infinite"):
+        repet.run_batch("sim", [clips[0], bad, clips[2]], fs, device=0, depth=depth)
+    assert np.array_equal(repet.run_batch("sim", clips[:2], fs, device=0, depth=depth)[1], repet.sim(clips[1], fs))
+    with pytest.raises(ValueError):
+        repet.run_batch("sim", clips[:2], fs, device=0, depth=9)
+    repet.release_workspaces()
+
+
 @pytest.mark.parametrize("algo", ["simonline", "sim", "original", "extended"])
 def test_samples_that_are_not_finite_give_the_same_result_on_every_transport(algo, monkeypatch):
     """The reference's behaviour on NaN / infinite samples (the default) must not depend on HOW a clip reached the engine: the
