@@ -680,10 +680,38 @@ def main():
                                               "behind every kernel); in the timed runs the two chains overlap on two streams: ms above is both")
                         st["chains_alone_ms"] = {"peaks": round(sum(r["ms_alone"] for r in rows_k if r["name"].startswith("local_maxima")), 4),
                                                  "sort": round(sum(r["ms_alone"] for r in rows_k if not r["name"].startswith("local_maxima")), 4)}
+                        # What bounds the STAGE (round 6): the chip's LDS. Every kernel of both chains holds its workgroups' LDS for
+                        # their lifetime, and the two chains together ask for more LDS x time than 256 CUs x 160 KB offer in the
+                        # time of the longer chain: the stage's floor is the sum, over its kernels, of (time alone) x (share of the
+                        # chip's LDS its resident workgroups hold while it runs alone). The shares from the launch geometry
+                        # (rank.hip, peaks_wave.hip, peaks_exact.hip); the first peak pass is a tail of fewer and fewer rows, its
+                        # share is taken at the mean concurrency of its rows (profiles/r05_peak_gram_spans.txt: 1 749 of 3 840).
+                        cu_lds, n_cu = 160 * 1024, 256
+                        ts_ = -(-T // 64) * 64
+                        seg_pitch = -(-(-(-ts_ // 32)) // 4) * 4
+                        cap = -(-(T // (params.sim_distance_frames + 1) + 2) // 4) * 4
+                        pass1_lds = max(324, -(-(5 * seg_pitch * 4) // 16)) * 16 + cap * 8 + 96 * (8 + 8 + 4 + 4 + 4 + 6 + 2) + 16
+                        sort_lds = (n_sort + n_sort // 8) * 4 + (n_sort >> 4) * 4
+                        shares = {"local_maxima_pass1": min(cu_lds // pass1_lds, 16) * pass1_lds / cu_lds * (1749.0 / 3840.0),
+                                  "local_maxima_level2": 4 * 40960 / cu_lds,                  # float64 unit rows: four 40-KB workgroups per CU
+                                  "columns_from_rows": 8 * 64 * 65 * 4 / cu_lds,              # eight 16.6-KB workgroups per CU (wave slots)
+                                  "rank_columns_sort": (cu_lds // sort_lds) * sort_lds / cu_lds,
+                                  "code_planes": 1024 * 66 * 2 / cu_lds}                      # one 135-KB workgroup per CU
+                        view = [{"name": r["name"], "ms_alone": r["ms_alone"], "lds_share_when_alone": round(shares[r["name"]], 3),
+                                 "lds_ms": round(r["ms_alone"] * shares[r["name"]], 4)} for r in rows_k if r["name"] in shares]
+                        floor = sum(v["lds_ms"] for v in view)
+                        st.update({"bound": "lds_capacity", "achieved": round(floor, 4), "peak": st["ms"], "unit": "ms of the whole chip's LDS (256 CUs x 160 KB)",
+                                   "frac": round(floor / st["ms"], 4), "lds_time": view,
+                                   "note_bound": "floor = sum over the stage's kernels of (ms alone) x (share of the chip's LDS held while alone); "
+                                                 "frac = floor / stage time = how tightly the two chains pack the LDS (DESIGN.md 8.2)"})
             except Exception as exc:  # noqa: BLE001 -- a breakdown must never cost the headline
                 for st in stages:
                     if st["name"] == "peaks+rank_columns":
                         st["kernels_error"] = f"{type(exc).__name__}: {exc}"
+            # the longest stage's own bound beside the longest kernel's (roofline.dominant_stage)
+            for st in stages:
+                if st["name"] == roof["dominant_stage"]["name"] and "frac" in st and not roof["dominant_stage"]["is_a_single_kernel"]:
+                    roof["dominant_stage"].update({k: st[k] for k in ("bound", "achieved", "peak", "unit", "frac", "chains_alone_ms") if k in st})
         if world == 1 and args.config == 2 and not args.no_variants and example_clip is None and args.clips == 1:
             # A GPU that serves INDEPENDENT clips can keep several in flight: three contexts (three streams, three resident clips)
             # fill the latency-bound stages of one another. Beside the headline, never instead of it (the metric is quoted on one clip).

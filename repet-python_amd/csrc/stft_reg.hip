@@ -310,42 +310,52 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             // Hermitian split: X[k] = E + W_2048^k O with E = (Z[k] + conj Z[N-k]) / 2, O = (Z[k] - conj Z[N-k]) / 2i.
             // Z[N-k] for k = lane + 64 s is slot 15 - s of lane 64 - lane (lane 0: its own slot (16 - s) & 15).
             // Round 6: bins k and N - k come out of the SAME two values -- E[N-k] = conj E[k], O[N-k] = conj O[k], W^(N-k) = -conj W^k,
-            // so X[N-k] = conj(E - W^k O) -- and a lane now takes its slots s < 8 only, in pairs: X[k] for its own bin and X[N-k]
-            // for the bin that lane 64 - lane holds in slot 15 - s (which in turn serves this lane's slots 8 .. 15). Twelve
-            // instructions per PAIR where every bin took twenty, half the cross-lane fetches; the table holds W^k / 2. The pair
-            // (0, N) is lane 0's slot 0 (Z[N] = Z[0]), so the Nyquist bin needs no code of its own; bin N/2 pairs with itself:
-            // X[512] = conj Z[512], lane 0's slot 8. Accumulators: acc[s] bin lane + 64 s, acc[8 + s] bin N - lane - 64 s, acc[16] bin 512.
+            // so X[N-k] = conj(E - W^k O) -- and a lane computes its slots s < 8 only, in pairs: X[k] for its own bin and X[N-k]
+            // for the bin that lane 64 - lane holds in slot 15 - s, which it hands over (one cross-lane fetch per component,
+            // as many as the split took before; twelve instructions per PAIR where every bin took twenty). Every lane still
+            // stores its own sixteen bins, in ascending lane order: storing the mirrored bins where they are computed -- lanes on
+            // descending addresses -- made the kernel 20 % SLOWER at cfg 3 / 5 (0.383 -> 0.459, 0.778 -> 0.899 ms; equal at cfg 2).
+            // The table holds W^k / 2. Lane 0's pairs are its own slots s and 16 - s; its pair 0 is (0, N): the Nyquist bin;
+            // bin N/2 (its slot 8) pairs with itself: X[512] = conj Z[512].
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto put = [&](int s_, float2 x) {                       // bin lane + 64 s_ of this lane
+                const int k = lane + 64 * s_;
+                const float mag = magnitude(x);
+                // non-temporal: the spectrum is read again only after the similarity / period stages -- stored the ordinary way it
+                // pushes the magnitudes and unit rows those stages read next out of the caches (1-2 % of every variant's step)
+                { f2 y; y.x = x.x; y.y = x.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + k)); }
+                Vrow[k] = mag;
+                acc[s_] += mag;
+            };
+            float2 xs[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const int k = lane + 64 * s, km = N - k;
                 const float2 zk = v[s];
                 const float2 other = make_float2(lane_fetch(v[15 - s].x, partner), lane_fetch(v[15 - s].y, partner));
                 const float2 mine = v[(16 - s) & 15];
                 const float2 zn = (lane == 0) ? mine : other;
                 const float sx = zk.x + zn.x, sy = zk.y - zn.y;           // Z[k] + conj Z[N-k]
                 const float dx = zk.x - zn.x, dy = zk.y + zn.y;           // Z[k] - conj Z[N-k]
-                const float2 wh = split_lds[k];                            // W^k / 2
+                const float2 wh = split_lds[lane + 64 * s];                // W^k / 2
                 const float tx = fmaf(wh.x, dy, wh.y * dx);               // W^k O, O = (dy, -dx) / 2
                 const float ty = fmaf(wh.y, dy, -(wh.x * dx));
-                const float2 x = make_float2(fmaf(0.5f, sx, tx), fmaf(0.5f, sy, ty));
-                const float2 xm = make_float2(fmaf(0.5f, sx, -tx), fmaf(-0.5f, sy, ty));
-                const float mag = magnitude(x), magm = magnitude(xm);
-                // non-temporal: the spectrum is read again only after the similarity / period stages -- stored the ordinary way it
-                // pushes the magnitudes and unit rows those stages read next out of the caches (1-2 % of every variant's step)
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                { f2 y; y.x = x.x; y.y = x.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + k)); }
-                { f2 y; y.x = xm.x; y.y = xm.y; __builtin_nontemporal_store(y, reinterpret_cast<f2*>(Xrow + km)); }
-                Vrow[k] = mag;
-                Vrow[km] = magm;
-                acc[s] += mag;
-                acc[8 + s] += magm;
+                put(s, make_float2(fmaf(0.5f, sx, tx), fmaf(0.5f, sy, ty)));
+                xs[s] = make_float2(fmaf(0.5f, sx, -tx), fmaf(-0.5f, sy, ty));
                 if (s & 1) __builtin_amdgcn_sched_barrier(0);             // a few bins in flight, not sixteen
             }
-            {   // k = N / 2: its own partner, W_2048^(N/2) = -i: X = conj Z (lane 0's slot 8)
-                const float2 x = make_float2(v[8].x, -v[8].y);
-                const float mag = magnitude(x);
-                if (lane == 0) { Xrow[N / 2] = x; Vrow[N / 2] = mag; }
+            {   // k = N (Nyquist): lane 0's pair 0
+                const float2 x = make_float2(xs[0].x, 0.f);
+                const float mag = magnitude(x);           // (not fabsf: the inverse recomputes every bin's magnitude the same way)
+                if (lane == 0) { Xrow[N] = x; Vrow[N] = mag; }
                 acc[16] += mag;
+            }
+            const float2 x512 = make_float2(v[8].x, -v[8].y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                                 // slots 15 .. 8: what the mirror lane computed for them
+                const float2 got = make_float2(lane_fetch(xs[j].x, partner), lane_fetch(xs[j].y, partner));
+                const float2 own0 = j < 7 ? xs[j + 1] : x512;
+                put(15 - j, (lane == 0) ? own0 : got);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
             if (lane < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
                 Xrow[N + 1 + lane] = make_float2(0.f, 0.f);
@@ -391,25 +401,21 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
         // masks per store (300 integer instructions per frame)
         const int64_t plane_lane = 2 * row + ((lane >> 5) << 6) + (lane & 31);
         _Float16* vh_lane = Vh ? static_cast<_Float16*>(Vh) + plane_lane : nullptr;
-        // the mirrored bins N - lane - 64 s = 960 - 64 s + j, j = 64 - lane (1 .. 64): block 30 - 2 s + (j >> 5), component j & 31
-        const int jm = 64 - lane;
-        const int64_t plane_mirror = 2 * row + (((int64_t)(30 + (jm >> 5))) << 6) + (jm & 31);
-        _Float16* vh_mirror = Vh ? static_cast<_Float16*>(Vh) + plane_mirror : nullptr;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = lane + 64 * s, km = N - k;
-            if (Vm) { Vm[k] = acc[s]; Vm[km] = acc[8 + s]; }
-            const float unit = (acc[s] * pre) * inv_norm, unit_m = (acc[8 + s] * pre) * inv_norm;
-            if (Vn) { Vn[k] = unit; Vn[km] = unit_m; }
-            if (Vh) { store_split_f16_at(vh_lane + 128 * s, unit); store_split_f16_at(vh_mirror - 128 * s, unit_m); }
-            if (P) { P[k] = acc[s] * acc[s]; P[km] = acc[8 + s] * acc[8 + s]; }
-            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 16; ++s) {
+            const int k = lane + 64 * s;
+            if (Vm) Vm[k] = acc[s];
+            const float unit = (acc[s] * pre) * inv_norm;
+            if (Vn) Vn[k] = unit;
+            if (Vh) store_split_f16_at(vh_lane + 128 * s, unit);
+            if (P) P[k] = acc[s] * acc[s];
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        if (lane == 0) {                                   // bin N / 2
-            if (Vm) Vm[N / 2] = acc[16];
-            if (Vn) Vn[N / 2] = (acc[16] * pre) * inv_norm;
-            if (Vh) store_split_f16(Vh, row + N / 2, (acc[16] * pre) * inv_norm);
-            if (P) P[N / 2] = acc[16] * acc[16];
+        if (lane == 0) {
+            if (Vm) Vm[N] = acc[16];
+            if (Vn) Vn[N] = (acc[16] * pre) * inv_norm;
+            if (Vh) store_split_f16(Vh, row + N, (acc[16] * pre) * inv_norm);
+            if (P) P[N] = acc[16] * acc[16];
         }
         if (lane < a.FS - (N + 1)) {
             if (Vm) Vm[N + 1 + lane] = 0.f;
@@ -428,14 +434,12 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
             void* Ph = static_cast<void*>(static_cast<_Float16*>(a.Ph) + 2 * b * a.batch_mean_stride);
             if (lane == 0) a.Ph_inv[b * a.batch_inv_stride + t] = 1.0f / sc;
             _Float16* ph_lane = static_cast<_Float16*>(Ph) + plane_lane;
-            _Float16* ph_mirror = static_cast<_Float16*>(Ph) + plane_mirror;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < 16; ++s) {
                 store_split_f16_scaled_at(ph_lane + 128 * s, acc[s] * acc[s], sc);
-                store_split_f16_scaled_at(ph_mirror - 128 * s, acc[8 + s] * acc[8 + s], sc);
-                if (s & 1) __builtin_amdgcn_sched_barrier(0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            if (lane == 0) store_split_f16_scaled(Ph, row + N / 2, acc[16] * acc[16], sc);
+            if (lane == 0) store_split_f16_scaled(Ph, row + N, acc[16] * acc[16], sc);
             if (lane < a.FS - (N + 1)) store_split_f16_scaled(Ph, row + N + 1 + lane, 0.f, sc);
         }
         RSTAMP(4)                                      // mean rows
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
         tw_lds[i] = cconj(a.twiddle[2 * l * k1]);                 // exp(+2 pi i l k1 / 1024)
     }
     if (tid < 64) tw_lds[16 * 64 + tid] = cconj(a.twiddle[32 * (tid >> 4) * (tid & 15)]);
-    for (int i = tid; i < N; i += 64 * kInvWaves) split_lds[i] = cconj(a.twiddle[i]);
+    for (int i = tid; i < N; i += 64 * kInvWaves) { const float2 w = a.twiddle[i]; split_lds[i] = make_float2(0.5f * w.x, -0.5f * w.y); }   // conj(W^k) / 2 (exact)
     for (int i = tid; i < C * 8 * 64; i += 64 * kInvWaves) carry[i] = make_float2(0.f, 0.f);
     const RegTwiddles tw{tw_lds, tw_lds + 16 * 64};
     __syncthreads();
@@ -524,74 +528,68 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                 const float* Mr = MASKED == 1 ? a.M + c * a.chan_stride + t * a.FS : nullptr;
                 // MASKED == 2: the model row of this frame's position inside its period (wave-uniform)
                 const float* Wr = MASKED == 2 ? a.model + c * a.model_chan_stride + (t % period) * a.FS : nullptr;
-                // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D. All loads of a
-                // half (of the whole transform without a mask plane) are issued before the first is consumed: in batches
-                // of four the transform waited for memory four times over
-                constexpr int kHalf = MASKED != 0 ? 8 : 16;
-                // MASKED == 2: the masks of the frame's 1 025 bins go through the wave's exchange region (idle until the
-                // transform's first transpose). Every lane fetches the spectrum and the model of ITS bins k = lane + 64 s
-                // (and the Nyquist bin), the mirrored bins of the first half behind them, computes |X| with the forward
-                // kernel's own roundings (magnitude(): V is not read at all), the masks, and parks them as floats in `ex`;
-                // the merge picks mask[k] and mask[N - k] from there and keeps the lane's own bins in registers. Two memory
-                // round trips per transform as with a mask plane (with model and magnitude of every PAIR in flight beside
-                // the spectrum the kernel either spilled, 58 registers, or took four round trips: 0.47 -> 0.58 ms at cfg 3).
-                float* mask_lds = reinterpret_cast<float*>(ex);
-                float2 own[MASKED == 2 ? 16 : 1], xc0[MASKED == 2 ? kHalf : 1];
+                // merge the half spectrum back into the packed transform: Z[k] = E + i conj(W_2048^k) D, E = (A + B) / 2,
+                // D = (A - B) / 2, A = X[k], B = conj X[N-k] (both masked first). Round 6: in PAIRS, as the forward kernel splits --
+                // Z[N-k] = conj(E) + i conj(conj(W^k) D) comes out of the same E and D, so a lane takes its slots s < 8 only:
+                // it fetches X[k] and X[N-k] once (every bin was fetched twice before, by its own lane and by its mirror's), keeps
+                // Z[k] and hands Z[N-k] to lane 64 - lane, whose slot 15 - s it is (one cross-lane fetch per component). The masks
+                // of exactly these sixteen bins are what the lane needs: MASKED == 2 computes them where they are used -- the
+                // trip of all masks through the wave's exchange region (and the two waits around it) is gone. The table holds
+                // conj(W^k) / 2. Lane 0: its pairs are its own slots s and 16 - s; (0, N) gives Z[0] alone; bin N/2 pairs with
+                // itself, Z[N/2] = conj(A). All loads of a transform are issued before the first is consumed.
+                const int partner = (64 - lane) & 63;
+                float2 xk[8], xc[8], x512;
+                float mk[MASKED ? 8 : 1], mc[MASKED ? 8 : 1], m512 = 1.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xk[j] = Y[64 * j + lane]; xc[j] = Y[N - (64 * j + lane)]; }
+                x512 = Y[N / 2];                                              // (every lane the same address: one request)
+                if constexpr (MASKED == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { mk[j] = Mr[64 * j + lane]; mc[j] = Mr[N - (64 * j + lane)]; }
+                    m512 = Mr[N / 2];
+                }
                 if constexpr (MASKED == 2) {
-                    float mw[17];
+                    float wk[8], wc[8];
 #pragma unroll
-                    for (int s_ = 0; s_ < 16; ++s_) { own[s_] = Y[lane + 64 * s_]; mw[s_] = Wr[lane + 64 * s_]; }
-                    const float2 xn = Y[N];                                 // (every lane the same address: one request)
-                    mw[16] = Wr[N];
+                    for (int j = 0; j < 8; ++j) { wk[j] = Wr[64 * j + lane]; wc[j] = Wr[N - (64 * j + lane)]; }
+                    const float w512 = Wr[N / 2];
+                    // |X| with the forward kernel's own roundings (magnitude(): V is not read at all)
 #pragma unroll
-                    for (int j = 0; j < kHalf; ++j) xc0[j] = Y[N - (64 * j + lane)];
-#pragma unroll
-                    for (int s_ = 0; s_ < 16; ++s_) {
-                        mask_lds[lane + 64 * s_] = soft_mask(magnitude(own[s_]), mw[s_], lane + 64 * s_, a.cutoff);
-                        if (s_ & 1) __builtin_amdgcn_sched_barrier(0);             // two divisions' temporaries at a time, not sixteen
+                    for (int j = 0; j < 8; ++j) {
+                        mk[j] = soft_mask(magnitude(xk[j]), wk[j], 64 * j + lane, a.cutoff);
+                        mc[j] = soft_mask(magnitude(xc[j]), wc[j], N - (64 * j + lane), a.cutoff);
+                        __builtin_amdgcn_sched_barrier(0);                     // two divisions' temporaries at a time, not sixteen
                     }
-                    if (lane == 0) mask_lds[N] = soft_mask(magnitude(xn), mw[16], N, a.cutoff);  // (the forward kernels' Nyquist magnitude: the same call)
-                    __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the region is wave-private
-                    __builtin_amdgcn_wave_barrier();
+                    m512 = soft_mask(magnitude(x512), w512, N / 2, a.cutoff);
                 }
+                float2 send[8];
 #pragma unroll
-                for (int h0_ = 0; h0_ < 16; h0_ += kHalf) {
-                    float2 xk[kHalf], xc[kHalf];
-                    float mk[MASKED ? kHalf : 1], mc[MASKED ? kHalf : 1];
-#pragma unroll
-                    for (int j = 0; j < kHalf; ++j) {
-                        const int k = 64 * (h0_ + j) + lane;
-                        if constexpr (MASKED == 2) {
-                            xk[j] = own[h0_ + j];
-                            if (h0_ == 0) xc[j] = xc0[j]; else xc[j] = Y[N - k];
-                            mk[j] = mask_lds[k]; mc[j] = mask_lds[N - k];
-                        } else {
-                            xk[j] = Y[k]; xc[j] = Y[N - k];
-                            if constexpr (MASKED == 1) { mk[j] = Mr[k]; mc[j] = Mr[N - k]; }
-                        }
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 64 * j + lane;
+                    float2 a_ = xk[j], b_ = xc[j];
+                    if constexpr (MASKED != 0) {
+                        a_ = make_float2(mul_rounded(a_.x, mk[j]), mul_rounded(a_.y, mk[j]));
+                        b_ = make_float2(mul_rounded(b_.x, mc[j]), mul_rounded(b_.y, mc[j]));
                     }
+                    const float ex_ = a_.x + b_.x, ey_ = a_.y - b_.y;         // A + B   (B = conj X[N-k])
+                    const float dx_ = a_.x - b_.x, dy_ = a_.y + b_.y;         // A - B
+                    const float2 w = split_lds[k];                             // conj(W^k) / 2
+                    const float ox = fmaf(dx_, w.x, -(dy_ * w.y));            // o = conj(W^k) D
+                    const float oy = fmaf(dx_, w.y, dy_ * w.x);
+                    v[j] = make_float2(fmaf(0.5f, ex_, -oy), fmaf(0.5f, ey_, ox));         // E + i o
+                    send[j] = make_float2(fmaf(0.5f, ex_, oy), fmaf(-0.5f, ey_, ox));      // conj(E) + i conj(o)
+                }
+                float2 z512 = x512;
+                if constexpr (MASKED != 0) z512 = make_float2(mul_rounded(x512.x, m512), mul_rounded(x512.y, m512));
+                z512.y = -z512.y;                                              // Z[N/2] = conj(A)
+                // slots 15 .. 8: from the mirror lane's pairs 0 .. 7 (lane 0: its own pairs 1 .. 7 are its slots 15 .. 9, slot 8 is bin N/2)
 #pragma unroll
-                    for (int j = 0; j < kHalf; ++j) {
-                        const int k = 64 * (h0_ + j) + lane;
-                        float2 a_ = xk[j], b_ = xc[j];
-                        if constexpr (MASKED != 0) {
-                            a_ = make_float2(mul_rounded(a_.x, mk[j]), mul_rounded(a_.y, mk[j]));
-                            b_ = make_float2(mul_rounded(b_.x, mc[j]), mul_rounded(b_.y, mc[j]));
-                        }
-                        b_ = cconj(b_);
-                        const float2 e = make_float2(0.5f * (a_.x + b_.x), 0.5f * (a_.y + b_.y));
-                        const float2 d = make_float2(0.5f * (a_.x - b_.x), 0.5f * (a_.y - b_.y));
-                        const float2 w = split_lds[k];
-                        const float ox = fmaf(d.x, w.x, -mul_rounded(d.y, w.y));
-                        const float oy = fmaf(d.x, w.y, mul_rounded(d.y, w.x));
-                        v[h0_ + j] = make_float2(e.x - oy, e.y + ox);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8; ++j) {
+                    const float2 got = make_float2(lane_fetch(send[j].x, partner), lane_fetch(send[j].y, partner));
+                    const float2 own0 = j < 7 ? send[j + 1] : z512;
+                    v[15 - j] = (lane == 0) ? own0 : got;
                 }
-                if constexpr (MASKED == 2) {                                // every lane is done with the parked masks
-                    __builtin_amdgcn_s_waitcnt(0xC07F);
-                    __builtin_amdgcn_wave_barrier();
-                }
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_sched_barrier(0);
                 wave_fft1024<true>(v, ex, tw, lane);
                 __builtin_amdgcn_sched_barrier(0);
