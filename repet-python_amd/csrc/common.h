@@ -283,7 +283,12 @@ struct PeakRefine {
     // queue of frames whose float64 unit rows are needed (frame = clip * frame_clip_stride + frame row)
     unsigned char* records; int32_t record_bytes; int32_t* lite_list; unsigned int* lite_flag;
     int32_t* frame_list; unsigned int* frame_flag; int64_t frame_clip_stride;
+    // (nullable) float64 norms of the fp32 unit rows, one per row of unit_rows (launch_unit_row_norms): with them the first
+    // pass's float64 similarities are one dot product per item instead of two and a square root
+    const double* unit_norms;
 };
+// float64 L2 norm of every fp32 row: norms[r] = sqrt(sum_k rows[r * pitch + k]^2), n_rows rows of `pitch` floats (pitch % 4 == 0)
+hipError_t launch_unit_row_norms(const float* rows, int64_t n_rows, int32_t pitch, double* norms, hipStream_t s);
 // batch (nullable): blockIdx.y = clip of a batch of equal-shape matrices; element strides between the clips
 struct PeakBatch { int32_t n_batch; int64_t m_stride, idx_stride, cnt_stride, unit_stride; };
 hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int32_t n_cols, int64_t pitch,

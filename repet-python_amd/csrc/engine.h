@@ -83,6 +83,7 @@ struct repet_ctx {
     hipStream_t copy_stream = nullptr;   // the remainder plane of a float64 upload follows the samples here (created on first use)
     std::vector<hipStream_t> ballast_streams;   // candidates that shared the main stream's hardware queue (pick_side_stream)
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    hipEvent_t norms_fork = nullptr, norms_done = nullptr;      // exec_sim: the unit rows' float64 norms on the side stream beside the Gram kernel
     // resident clip
     DevBuf staging, audio, out, out64;
     StagingRing ring;             // pinned chunks the waveforms travel through (hostio.hip)
@@ -126,6 +127,7 @@ struct repet_ctx {
     // handed over, the table of float64 unit rows with its generation stamps, the row workspaces of the fixed grid
     DevBuf audio_lo; bool has_lo = false;
     DevBuf redo_list, redo_flag, u64, u64_gen, exact_scratch;
+    DevBuf unit_norms;            // float64 norms of the fp32 unit rows (PeakRefine::unit_norms)
     DevBuf lite_list, lite_flag, lite_records, frame_list, frame_flag;   // the wavefront kernel's fast path (peaks_wave.hip)
     unsigned int exact_gen = 0;
     bool refine_stats_cleared = false;   // ensure_spectra's housekeeping launch has zeroed them for the run being enqueued

@@ -528,6 +528,8 @@ int ctx_create(int device, repet_ctx** out, bool probe_side_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->norms_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->norms_done, hipEventDisableTiming);
     // The two streams must sit on DIFFERENT hardware queues, or the kernels meant to run side by side (column sort | peak
     // picking, Nyquist bins | mask) run one after the other. The runtime deals its GPU_MAX_HW_QUEUES = 4 queues by use
     // count: in a process that has already opened several streams (PyTorch with an RCCL communicator: seven) two streams
@@ -572,6 +574,8 @@ int repet_ctx_destroy(repet_ctx* c) {
     for (hipStream_t b : c->ballast_streams) (void)hipStreamDestroy(b);
     if (c->fork_event) (void)hipEventDestroy(c->fork_event);
     if (c->join_event) (void)hipEventDestroy(c->join_event);
+    if (c->norms_fork) (void)hipEventDestroy(c->norms_fork);
+    if (c->norms_done) (void)hipEventDestroy(c->norms_done);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return REPET_OK;

@@ -182,7 +182,25 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     if (with_seg) HIP_TRY(c->seg.ensure((size_t)T * 3 * seg_pitch * sizeof(float)));
     float* seg = with_seg ? c->seg.as<float>() : nullptr;
     bool seg_written = false;
+    // The float64 norms of the unit rows (the first pass's float64 similarities divide by them: peaks.h) need the unit rows only:
+    // they are computed on the side stream BESIDE the Gram kernel -- enqueued behind its launch, so the Gram's workgroups take the
+    // CUs first and the 1 939 small workgroups of this kernel run where its second round leaves CUs idle (496 tiles on 256 CUs).
+    // Measured (profiles/r06_peak_norms_ab.txt): the first pass is NOT faster with the table (98.6 -> 100.5 us: its span is the late
+    // start of its slow rows plus their sweep, not the arithmetic of their similarities), and the two events that tie the side
+    // stream's kernel in cost the Gram stage 13 us and the peak stage 12: 0.854 -> 0.881 ms per step. Off by default;
+    // REPET_PEAK_NORMS=1 turns it on (A/B).
+    static const bool use_norms = [] { const char* e = getenv("REPET_PEAK_NORMS"); return e && e[0] == '1'; }();
+    const bool norms_beside = use_norms && c->side_stream && peak_refine_delta(g.FS, gram_f16_enabled()) > 0.0f && (g.FS & 3) == 0 && g.FS <= 1280;
+    if (norms_beside) {
+        HIP_TRY(c->unit_norms.ensure((size_t)g.Tpad * sizeof(double)));
+        HIP_TRY(hipEventRecord(c->norms_fork, c->stream));               // the unit rows are there
+    }
     RP_TRY(run_gram_full(c, c->Vn.as<float>(), T, g.FS, c->S.as<float>(), TS, true, split_in_stft(1), seg, seg_pitch, &seg_written));
+    if (norms_beside) {
+        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->norms_fork, 0));
+        HIP_TRY(launch_unit_row_norms(c->Vn.as<float>(), T, g.FS, c->unit_norms.as<double>(), c->side_stream));
+        HIP_TRY(hipEventRecord(c->norms_done, c->side_stream));
+    }
     {
         // flops as EXECUTED: upper-triangle 128 x 128 tiles over the padded K = FS, three f16 products per term on the
         // split kernel (hi hi' + hi lo' + lo hi'); bench.py prices them against the f16 (or fp32) matrix peak and
@@ -204,6 +222,10 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const int max_peaks = (int)std::min<int64_t>(K, ceil_div(T, p->sim_distance_frames + 1));
     PeakRefine rf{};
     RP_TRY(make_refine(c, c->Vn.as<float>(), g.FS, p->sim_threshold, &rf, T, 1, (int)T, p->sim_distance_frames, T));
+    if (norms_beside) {
+        rf.unit_norms = c->unit_norms.as<double>();
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->norms_done, 0));
+    }
     {
         MaskArgs m = mask_args(c, g, p->cutoff_bins);
         const bool use_rank = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&

@@ -11,6 +11,7 @@ struct PeakArgs {
     int* idx; int idx_pitch; int* count; int dl; int groups; int peak_cap; int64_t shift;
     // near-tie refinement (see below): unit rows the similarities were computed from, or null
     const float* unit; int unit_pitch; float delta; double min_value64; unsigned int* stats;
+    const double* unit_norm;       // (nullable) float64 norm of every unit row (same row index as `unit`, batch stride unit_stride / unit_pitch)
     int64_t m_stride, idx_stride, cnt_stride, unit_stride;      // batch: blockIdx.y = clip
     // long rows: STAGE 1 workgroups handle one segment [seg * seg_len, (seg+1) * seg_len) of the row each (blockIdx.z)
     // and leave their candidates in cand_*[(row * n_seg + seg) * cand_cap ...]; STAGE 2 ranks a row's candidates
@@ -208,6 +209,58 @@ __device__ __forceinline__ void exact_similarity_list(const float* __restrict__ 
         xy = wave_sum_f64(xy);
         yy = wave_sum_f64(yy);
         store(it, xy / sqrt(xx * yy));
+#pragma unroll
+        for (int u = 0; u < 5; ++u) q[u] = r[u];
+    }
+}
+
+// The same list with the float64 norms of the rows on a table (PeakArgs::unit_norm; round 6): cos = x.y / (|x| |y|) is ONE dot
+// product per item -- twenty float64 multiply-adds and one wave reduction where the form above takes forty, two reductions and
+// a square root (all at the float64 rate, by one wave: 66 k of the 145 k cycles of the slowest rows of the first pass were
+// these similarities). The values differ from the form above in the last bits (the norm is summed in another order): they
+// are level-1 values, compared with a tolerance of delta2 = 2.5e-7 before anything is decided from them.
+template <class RowOf, class NormOf, class Store>
+__device__ __forceinline__ void exact_similarity_list_normed(const float* __restrict__ x, double norm_x, int len4, int lane, int n_items,
+                                                             RowOf row_of, NormOf norm_of, Store store) {
+    auto fetch_row = [&](const float* row, float4 (&dst)[5]) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) dst[u] = r4[min(64 * u + lane, len4 - 1)];
+    };
+    {   // (the rows into this XCD's L2 behind one round trip: see exact_similarity_list)
+        float sink = 0.f;
+        const int at = min(32 * lane, 4 * len4 - 1);
+        for (int it0 = 0; it0 < n_items; it0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) t[b] = row_of(min(it0 + b, n_items - 1))[at];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sink += t[b];
+        }
+        asm volatile("" ::"v"(sink));
+    }
+    float4 p[5], q[5];
+    fetch_row(x, p);
+    if (n_items > 0) fetch_row(row_of(0), q);
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+        if (64 * u + lane >= len4) p[u] = make_float4(0.f, 0.f, 0.f, 0.f);      // (x * 0: the clamped tail of y adds nothing)
+    double ny = n_items > 0 ? norm_of(0) : 1.0;
+    for (int it = 0; it < n_items; ++it) {
+        float4 r[5];
+        const int nx = it + 1 < n_items ? it + 1 : it;
+        fetch_row(row_of(nx), r);                                      // in flight during the sums below
+        const double ny_next = norm_of(nx);
+        double xy = 0.0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const double p0 = p[u].x, p1 = p[u].y, p2 = p[u].z, p3 = p[u].w;
+            const double q0 = q[u].x, q1 = q[u].y, q2 = q[u].z, q3 = q[u].w;
+            xy += p0 * q0 + p1 * q1 + p2 * q2 + p3 * q3;
+        }
+        xy = wave_sum_f64(xy);
+        store(it, xy / (norm_x * ny));
+        ny = ny_next;
 #pragma unroll
         for (int u = 0; u < 5; ++u) q[u] = r[u];
     }

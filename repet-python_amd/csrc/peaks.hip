@@ -533,6 +533,7 @@ hipError_t launch_local_maxima(const float* M, int64_t n_rows, int64_t row0, int
     if (refine && refine->unit_rows && refine->delta > 0.0f && (refine->pitch & 3) == 0) {
         a.unit = refine->unit_rows; a.unit_pitch = refine->pitch; a.delta = refine->delta;
         a.min_value64 = refine->min_value; a.stats = refine->stats;
+        a.unit_norm = refine->unit_norms;
         if (refine->redo_list && refine->stats) {
             a.delta2 = refine->delta2; a.redo_list = refine->redo_list; a.redo_flag = refine->redo_flag; a.gen = refine->gen;
             a.flag_stride = refine->flag_stride;

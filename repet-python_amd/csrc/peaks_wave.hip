@@ -273,11 +273,18 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
             auto item_row = [&](int it) -> const float* {
                 return elem_row(it < n_near ? L.amb_idx[it] : L.riv_idx[L.unl_list[it - n_near]]);
             };
-            exact_similarity_list(self_row, len4, lane, n_items, item_row, [&](int it, double e) {
+            auto keep = [&](int it, double e) {
                 if (lane == 0) {
                     if (it < n_near) L.amb_exact[it] = e; else L.riv_exact[L.unl_list[it - n_near]] = e;
                 }
-            });
+            };
+            if (a.unit_norm && len4 <= 320) {
+                auto item_norm = [&](int it) -> double {
+                    return a.unit_norm[elem_frame(it < n_near ? L.amb_idx[it] : L.riv_idx[L.unl_list[it - n_near]])];
+                };
+                exact_similarity_list_normed(self_row, a.unit_norm[self_frame], len4, lane, n_items, item_row, item_norm, keep);
+            } else
+                exact_similarity_list(self_row, len4, lane, n_items, item_row, keep);
             wave_sync();
         }
         // best[s]: the largest rival value of near-tied element s (similarities of magnitude spectra are >= 0: their bit
@@ -536,6 +543,7 @@ __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64
     a.idx += blockIdx.y * a.idx_stride;
     a.count += blockIdx.y * a.cnt_stride;
     if (a.unit) a.unit += blockIdx.y * a.unit_stride;
+    if (a.unit_norm) a.unit_norm += blockIdx.y * (a.unit_stride / a.unit_pitch);
     const int64_t j = a.row0 + r;                            // absolute row (mode 1: current frame)
     float dlt = a.delta;                                     // 0: no refinement
 
@@ -1232,6 +1240,35 @@ __global__ __launch_bounds__(256) void segment_maxima_kernel(const float* __rest
             reinterpret_cast<int*>(rec)[2 * seg_pitch + s] = t.at;
         }
     }
+}
+
+// norms[r] = float64 L2 norm of fp32 row r (PeakRefine::unit_norms): one wavefront per row, 16-byte loads
+__global__ __launch_bounds__(256) void unit_row_norms_kernel(const float* __restrict__ rows, int64_t n_rows, int pitch, double* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float4* r4 = reinterpret_cast<const float4*>(rows + r * pitch);
+    const int len4 = pitch >> 2;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < len4; k0 += 320) {
+        float4 p[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) p[u] = r4[min(k0 + 64 * u + lane, len4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const double live = (k0 + 64 * u + lane < len4) ? 1.0 : 0.0;
+            const double p0 = p[u].x, p1 = p[u].y, p2 = p[u].z, p3 = p[u].w;
+            acc += live * (p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3);
+        }
+    }
+    acc = wave_sum_f64(acc);
+    if (lane == 0) norms[r] = sqrt(acc);
+}
+hipError_t launch_unit_row_norms(const float* rows, int64_t n_rows, int32_t pitch, double* norms, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    if (!rows || !norms || (pitch & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(unit_row_norms_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, s, rows, n_rows, pitch, norms);
+    return hipGetLastError();
 }
 
 hipError_t launch_segment_maxima(const float* M, int64_t n_rows, int n_cols, int64_t pitch, float* seg, int seg_pitch, hipStream_t s) {
