@@ -45,7 +45,7 @@ VALU_FULL_RATE_GINSTR = 1024 * 2.4 / 2.0
 # rows gathered from a table that an XCD's L2 holds: 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, 'Indexed rows'); the
 # vector memory path of the CUs caps the same traffic at 256 CUs x 64 B/clk x 2.4 GHz = 39 TB/s, which it never reaches
 L2_GATHER_PEAK_GBS = 17800.0
-PMC_FILE = "r05_pmc_traffic.json"
+PMC_FILE = "r06_pmc_traffic.json"
 # arithmetic type of the path: fp32 end to end, except that the similarity GEMM of sim / simonline runs on the f16 matrix
 # cores as a three-product split of the fp32 operands (22 significant bits per product, fp32 accumulate; gram_f16.hip)
 DTYPE_NOTE = {"sim": "f32 (similarity GEMM: f16x3 split of the fp32 unit rows, fp32 accumulate; median: exact selection on bit-sliced rank codes)",

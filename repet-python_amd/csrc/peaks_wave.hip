@@ -532,7 +532,12 @@ __device__ __forceinline__ void wave_finish_row(const PeakArgs& a, const WaveLds
 template <int RD, bool SEG>
 // One wavefront per WORKGROUP: rows take 30 .. 140 us (the refinement of near-ties varies), and a workgroup's LDS and
 // registers are only handed back when its last wave is done (s_memrealtime spans of every row: tools/peak_stamps.py).
+#ifdef REPET_PEAK_WAVES      // experiment (round 6): at most that many waves of this kernel per SIMD -- the rest of the SIMD's registers and the
+                             // CU's LDS are left to the column sort that runs beside it
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REPET_PEAK_WAVES, REPET_PEAK_WAVES))) void local_maxima_wave_kernel(PeakArgs a, int64_t n_rows, int lds_per_wave) {
+#else
 __global__ __launch_bounds__(64) void local_maxima_wave_kernel(PeakArgs a, int64_t n_rows, int lds_per_wave) {
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char wave_smem[];
     const int lane = threadIdx.x & 63, wave = 0;
     const int64_t r = (int64_t)blockIdx.x;                   // row within this launch

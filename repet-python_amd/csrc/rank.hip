@@ -120,34 +120,45 @@ struct Phases {
 
 // Tiled transposes either side of the column sort: the spectrogram is frame-major (a column is one float every FS),
 // the sort wants whole columns. in[c][t][FS] -> out[c * n_cols + f][pitch] (fp32, 64 x 64 tiles through LDS).
+// TF = frames per tile. 64 (the round-4 form): 16.6 KB of LDS per workgroup, eight workgroups per CU hold 133 KB. 32 (round 6):
+// half of that for the same 256 threads -- the stage this kernel opens is bound by the chip's LDS, and its
+// workgroups have to find room beside the first pass of the peak picking. A column's 32 frames still leave as one 128-byte line.
+template <int TF>
 __global__ __launch_bounds__(256) void columns_from_rows_kernel(RankArgs a) {
-    __shared__ float tile[64][65];
+    static_assert(TF == 64 || TF == 32, "tile height");
+    constexpr int kRounds = TF / 16;                              // frame rows per thread on the way in
+    constexpr int kOutLanes = TF / 4;                             // lanes that cover a column's frames on the way out
+    constexpr int kOutRounds = 64 * kOutLanes / 256;              // columns per thread on the way out
+    __shared__ float tile[TF][65];
     const int c = blockIdx.z, f0 = blockIdx.y * 64;
-    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int64_t t0 = (int64_t)blockIdx.x * TF;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 bytes per lane both ways: 4 bins in, 4 frames out
     const float* in = a.V + c * a.chan_stride;
-    // all four loads first (clamped row: a load behind "t < T ?" sits in a branch and is waited for at its join), the choice
+    // all loads first (clamped row: a load behind "t < T ?" sits in a branch and is waited for at its join), the choice
     // afterwards
-    float4 r[4];
+    float4 r[kRounds];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kRounds; ++k) {
         const int64_t t = t0 + ty + 16 * k;
         r[k] = *reinterpret_cast<const float4*>(in + (t < a.T ? t : a.T - 1) * a.FS + f0 + 4 * tx);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kRounds; ++k) {
         const bool live = t0 + ty + 16 * k < a.T;
         float* row = tile[ty + 16 * k] + 4 * tx;                   // (pitch 65: the four words go one by one, conflict-free both ways)
         row[0] = live ? r[k].x : 0.f; row[1] = live ? r[k].y : 0.f; row[2] = live ? r[k].z : 0.f; row[3] = live ? r[k].w : 0.f;
     }
     __syncthreads();
     float* out = a.Vs + ((int64_t)c * a.n_cols + f0) * a.vs_pitch;
-    if (t0 + 4 * tx < a.vs_pitch) {
+    // thread -> (4 frames ox, column): a wave's reads of the tile must fall on 64 different banks (row pitch 65: bank = 4 ox + column)
+    const int ox = threadIdx.x % kOutLanes, oy = threadIdx.x / kOutLanes;
+    const int col0 = TF == 64 ? oy : (oy & 3) + 32 * ((oy >> 2) & 1) + 4 * (threadIdx.x >> 6);
+    if (t0 + 4 * ox < a.vs_pitch) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = ty + 16 * k;
-            *reinterpret_cast<float4*>(out + (int64_t)f * a.vs_pitch + t0 + 4 * tx) =
-                make_float4(tile[4 * tx][f], tile[4 * tx + 1][f], tile[4 * tx + 2][f], tile[4 * tx + 3][f]);
+        for (int k = 0; k < kOutRounds; ++k) {
+            const int f = col0 + 16 * k;
+            *reinterpret_cast<float4*>(out + (int64_t)f * a.vs_pitch + t0 + 4 * ox) =
+                make_float4(tile[4 * ox][f], tile[4 * ox + 1][f], tile[4 * ox + 2][f], tile[4 * ox + 3][f]);
         }
     }
 }
@@ -201,18 +212,22 @@ __device__ __forceinline__ void plane_transpose_stage(unsigned (&x)[16]) {
 // values of l -- 1 024 columns, 128 bytes of each, through LDS (column pitch 66 codes: lanes on adjacent l read adjacent
 // banks) -- and a thread builds the plane words of two (frame, l) with the transpose above, lanes adjacent in l so that a
 // wave writes two 128-byte halves of plane rows.
-constexpr int kPlaneFrames = 64, kPlaneColPitch = 66;
+// PF = frames per workgroup: 64 (round 4: 135 KB of LDS, one workgroup per CU -- it cannot start on a CU before the column sort
+// has left it altogether) or 32 (round 6: 70 KB, two per CU, a workgroup fits as soon as two of a CU's four sort workgroups
+// are gone; a plane row's words are still written 128 bytes at a time).
+template <int PF>
 __global__ __launch_bounds__(1024) void code_planes_from_columns_kernel(RankArgs a) {
-    extern __shared__ unsigned short plane_lds[];                 // [1024 columns][66]
+    constexpr int kPlaneFrames = PF, kPlaneColPitch = PF + 2, kPieces = PF / 8;
+    extern __shared__ unsigned short plane_lds[];                 // [1024 columns][PF + 2]
     const int64_t t0 = (int64_t)blockIdx.x * kPlaneFrames;
     const int l0 = blockIdx.y * 32;
     const int bpc = a.n_cols >> 6, n_bits = a.n_channels * bpc;
     // column q of the tile: bit b = q / 32, l = l0 + q % 32 -> cell 64 b + l = channel b / bpc, bin 64 (b % bpc) + l.
     // 16-byte pieces (8 frames of one column), eight per thread, all loads first
-    uint4 v[8];
+    uint4 v[kPieces];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = threadIdx.x + 1024 * k, q = i >> 3, piece = i & 7;
+    for (int k = 0; k < kPieces; ++k) {
+        const int i = threadIdx.x + 1024 * k, q = i / kPieces, piece = i % kPieces;
         const int b = q >> 5, l = l0 + (q & 31);
         const int64_t t = t0 + piece * 8;
         const bool in = b < n_bits && t < a.vs_pitch;
@@ -221,15 +236,15 @@ __global__ __launch_bounds__(1024) void code_planes_from_columns_kernel(RankArgs
         if (!in) v[k] = make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = threadIdx.x + 1024 * k, q = i >> 3, piece = i & 7;
-        unsigned* dst = reinterpret_cast<unsigned*>(plane_lds + q * kPlaneColPitch + piece * 8);      // 4-byte aligned (pitch 132 bytes)
+    for (int k = 0; k < kPieces; ++k) {
+        const int i = threadIdx.x + 1024 * k, q = i / kPieces, piece = i % kPieces;
+        unsigned* dst = reinterpret_cast<unsigned*>(plane_lds + q * kPlaneColPitch + piece * 8);      // 4-byte aligned (even pitch)
         dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
     }
     __syncthreads();
     const int l = threadIdx.x & 31;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PF / 32; ++k) {
         const int tl = (threadIdx.x >> 5) + 32 * k;
         const int64_t t = t0 + tl;
         if (t >= a.T) continue;
@@ -391,16 +406,30 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook h
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
     const int64_t cols = (int64_t)a.n_channels * a.n_cols;
-    hipLaunchKernelGGL(columns_from_rows_kernel, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
-                       dim3(256), 0, s, a);
+    // REPET_RANK_TILE=64: the 64-frame tiles of round 4 (A/B)
+    static const bool tall = [] { const char* e = getenv("REPET_RANK_TILE"); return e && e[0] == '6'; }();
+    if (tall)
+        hipLaunchKernelGGL(columns_from_rows_kernel<64>, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
+                           dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(columns_from_rows_kernel<32>, dim3((unsigned)ceil_div(a.vs_pitch, 32), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
+                           dim3(256), 0, s, a);
     if (hook) hook(user, 0);
     hipLaunchKernelGGL(rank_columns_kernel<LOG2N>, dim3((unsigned)cols), dim3(N / 32), lds, s, a);
     if (hook) hook(user, 1);
     if (a.P) {                           // the bit-sliced selection reads the planes only: no frame-major codes
-        constexpr int plane_lds_bytes = 1024 * kPlaneColPitch * 2;
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(&code_planes_from_columns_kernel), plane_lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(code_planes_from_columns_kernel, dim3((unsigned)ceil_div(a.T, kPlaneFrames), 2), dim3(1024), plane_lds_bytes, s, a);
+        // REPET_RANK_TILE=64: the 64-frame workgroups of round 4 (A/B)
+        if (tall) {
+            constexpr int plane_lds_bytes = 1024 * 66 * 2;
+            e = ensure_dynamic_lds(reinterpret_cast<const void*>(&code_planes_from_columns_kernel<64>), plane_lds_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(code_planes_from_columns_kernel<64>, dim3((unsigned)ceil_div(a.T, 64), 2), dim3(1024), plane_lds_bytes, s, a);
+        } else {
+            constexpr int plane_lds_bytes = 1024 * 34 * 2;
+            e = ensure_dynamic_lds(reinterpret_cast<const void*>(&code_planes_from_columns_kernel<32>), plane_lds_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(code_planes_from_columns_kernel<32>, dim3((unsigned)ceil_div(a.T, 32), 2), dim3(1024), plane_lds_bytes, s, a);
+        }
         if (hook) hook(user, 2);
         return hipGetLastError();
     }
