@@ -693,10 +693,12 @@ def main():
                         pass1_lds = max(324, -(-(5 * seg_pitch * 4) // 16)) * 16 + cap * 8 + 96 * (8 + 8 + 4 + 4 + 4 + 6 + 2) + 16
                         sort_lds = (n_sort + n_sort // 8) * 4 + (n_sort >> 4) * 4
                         shares = {"local_maxima_pass1": min(cu_lds // pass1_lds, 16) * pass1_lds / cu_lds * (1749.0 / 3840.0),
-                                  "local_maxima_level2": 4 * 40960 / cu_lds,                  # float64 unit rows: four 40-KB workgroups per CU
-                                  "columns_from_rows": 8 * 64 * 65 * 4 / cu_lds,              # eight 16.6-KB workgroups per CU (wave slots)
+                                  # float64 unit rows: one 40-KB workgroup per queued frame, all resident at once, for two thirds of the
+                                  # second level's time; its lite and general kernels (the other third) hold a quarter of the LDS
+                                  "local_maxima_level2": (2.0 * min(ex["unit_rows_f64"] * 40960.0 / (n_cu * cu_lds), 1.0) + 0.25) / 3.0,
+                                  "columns_from_rows": 8 * 32 * 65 * 4 / cu_lds,              # eight 8.3-KB workgroups per CU (wave slots)
                                   "rank_columns_sort": (cu_lds // sort_lds) * sort_lds / cu_lds,
-                                  "code_planes": 1024 * 66 * 2 / cu_lds}                      # one 135-KB workgroup per CU
+                                  "code_planes": 2 * 1024 * 34 * 2 / cu_lds}                  # two 70-KB workgroups per CU
                         view = [{"name": r["name"], "ms_alone": r["ms_alone"], "lds_share_when_alone": round(shares[r["name"]], 3),
                                  "lds_ms": round(r["ms_alone"] * shares[r["name"]], 4)} for r in rows_k if r["name"] in shares]
                         floor = sum(v["lds_ms"] for v in view)

@@ -81,6 +81,69 @@ struct HighTrips {
     }
 };
 
+// Round 6: trips of up to FIVE stages. The trip above takes its 32 keys as 8 x 4 (three stage bits and the two lowest index
+// bits, so that every access is 16 bytes): three stages per trip through LDS, 23 trips for 2^13 keys. A thread may as well hold
+// 16 x 2 (four stage bits, 8-byte accesses) or 32 x 1 (five stage bits, 4-byte accesses): the LDS moves the same bytes per
+// trip whatever the access width, and the merge phases 9 .. 13 then need one trip less each (19 trips). Built, validated
+// (the index algebra of both forms in NumPy for 2^11 .. 2^15 keys, the rank tests on the GPU) and measured: no faster (see
+// launch_rank_n) -- kept behind REPET_RANK_TRIPS=5.
+// NB = stage bits of the trip (3, 4, 5), VW = 32 >> NB consecutive keys per access.
+template <int LOG2N, int P, int QHI, int QLO, int NB, bool FLIP>
+__device__ __forceinline__ void trip_high_n(unsigned* s, int tid) {
+    constexpr int VW = 32 >> NB, LV = NB == 3 ? 2 : (NB == 4 ? 1 : 0), NU = 1 << NB;
+    constexpr int HB = QLO < LOG2N - NB ? QLO : LOG2N - NB;      // the thread's NB high bits are [HB, HB + NB)
+    static_assert(NB >= 3 && NB <= 5 && HB >= 5 && QHI < HB + NB && QLO >= HB, "stage bits must lie inside the thread's bit group");
+    const int low = tid & ((1 << (HB - LV)) - 1), high = tid >> (HB - LV);
+    const int base = (low << LV) | (high << (HB + NB));
+    unsigned r[NU][VW];
+    __syncthreads();                                           // the previous trip's stores
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i0 = base | (u << HB);
+        const bool mirrored = FLIP && ((u >> (P - 1 - HB)) & 1);   // upper half of a 2^P block: read mirrored below bit P - 1
+        const int src = mirrored ? ((i0 ^ ((1 << (P - 1)) - 1)) & ~(VW - 1)) : i0;
+        if constexpr (VW == 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(s + phys(src));
+            if (mirrored) { r[u][0] = v.w; r[u][1] = v.z; r[u][2] = v.y; r[u][3] = v.x; }
+            else { r[u][0] = v.x; r[u][1] = v.y; r[u][2] = v.z; r[u][3] = v.w; }
+        } else if constexpr (VW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2*>(s + phys(src));
+            if (mirrored) { r[u][0] = v.y; r[u][1] = v.x; } else { r[u][0] = v.x; r[u][1] = v.y; }
+        } else r[u][0] = s[phys(src)];
+    }
+    if (FLIP) __syncthreads();                                 // mirrored reads touch other threads' keys: all read first
+#pragma unroll
+    for (int q = QHI; q >= QLO; --q) {
+        const int bit = 1 << (q - HB);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (!(u & bit)) {
+#pragma unroll
+                for (int w = 0; w < VW; ++w) cex(r[u][w], r[u | bit][w]);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        unsigned* dst = s + phys(base | (u << HB));
+        if constexpr (VW == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(r[u][0], r[u][1], r[u][2], r[u][3]);
+        else if constexpr (VW == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(r[u][0], r[u][1]);
+        else dst[0] = r[u][0];
+    }
+}
+// how many of the n high stages (n >= 1) the next trip takes: all of them up to five, else about half (6: 3 + 3, 7: 4 + 3, 8: 4 + 4, 9: 5 + 4, 10: 5 + 5)
+constexpr int wide_trip_stages(int n) { return n <= 5 ? n : ((n + 1) / 2 > 5 ? 5 : (n + 1) / 2); }
+template <int LOG2N, int P, int QHI>
+struct WideTrips {
+    static __device__ __forceinline__ void run(unsigned* s, int tid) {
+        constexpr int n = QHI - 4;                             // stages QHI .. 5
+        constexpr int take = wide_trip_stages(n);
+        constexpr int QLO = QHI - take + 1;
+        constexpr int NB = take <= 3 ? 3 : take;
+        trip_high_n<LOG2N, P, QHI, QLO, NB, QHI == P - 1>(s, tid);
+        if constexpr (QLO > 5) WideTrips<LOG2N, P, QLO - 1>::run(s, tid);
+    }
+};
+
 // stages 4..0 on 32 contiguous keys in registers
 __device__ __forceinline__ void stages_low(unsigned (&k)[32]) {
 #pragma unroll
@@ -104,15 +167,16 @@ __device__ __forceinline__ void store_run(unsigned* s, int tid, const unsigned (
         *reinterpret_cast<uint4*>(s + phys(tid * 32 + v * 4)) = make_uint4(k[4 * v], k[4 * v + 1], k[4 * v + 2], k[4 * v + 3]);
 }
 
-template <int LOG2N, int P>
+template <int LOG2N, int P, bool WIDE>
 struct Phases {
     static __device__ __forceinline__ void run(unsigned* s, int tid, unsigned (&k)[32]) {
-        HighTrips<LOG2N, P, P - 1>::run(s, tid);
+        if constexpr (WIDE) WideTrips<LOG2N, P, P - 1>::run(s, tid);
+        else HighTrips<LOG2N, P, P - 1>::run(s, tid);
         __syncthreads();
         load_run(s, tid, k);
         stages_low(k);
         store_run(s, tid, k);
-        if constexpr (P < LOG2N) Phases<LOG2N, P + 1>::run(s, tid, k);
+        if constexpr (P < LOG2N) Phases<LOG2N, P + 1, WIDE>::run(s, tid, k);
     }
 };
 
@@ -270,7 +334,7 @@ __global__ __launch_bounds__(1024) void code_planes_from_columns_kernel(RankArgs
 // per thread and keeps the one-node-per-thread form
 constexpr int rank_leaf_bits(int log2n) { return log2n >= 15 ? 5 : REPET_RANK_LEAF_BITS; }
 
-template <int LOG2N>
+template <int LOG2N, bool WIDE>
 __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArgs a) {
     constexpr int N = 1 << LOG2N, THREADS = N / 32;
     extern __shared__ uint4 rank_lds[];
@@ -306,7 +370,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void rank_columns_kernel(RankArg
         }
     }
     store_run(s, tid, k);
-    Phases<LOG2N, 6>::run(s, tid, k);
+    Phases<LOG2N, 6, WIDE>::run(s, tid, k);
     // code of every original key: 0x0400 + lower_bound(sorted, key), 32 independent binary searches per thread. The
     // keys are fetched again (cache-resident: this workgroup read them a few microseconds ago) rather than held in 32
     // registers through the whole sort.
@@ -402,7 +466,12 @@ template <int LOG2N>
 static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook hook, void* user) {
     constexpr int N = 1 << LOG2N;
     constexpr int lds = (N + N / 8) * 4 + (N >> rank_leaf_bits(LOG2N)) * 4;        // the padded keys + the breadth-first copy of the leaf ends
-    const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N>);
+    // REPET_RANK_TRIPS=5: the trips of up to five stages (WideTrips). Measured (profiles/r06_rank_trips_ab.txt): 19 trips instead of
+    // 23 and NOT faster -- rank_columns_kernel<13> 132.6 us beside the peak picking against 125-130, the stage 0.2411-0.2415 ms
+    // against 0.2392-0.2424: a trip's cost is its LDS INSTRUCTIONS (64 or 32 four- / eight-byte accesses per thread against 16
+    // sixteen-byte ones), not its bytes. Default: the three-stage trips.
+    static const bool wide = [] { const char* t = getenv("REPET_RANK_TRIPS"); return t && t[0] == '5'; }();
+    const void* fn = wide ? reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N, true>) : reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N, false>);
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
     const int64_t cols = (int64_t)a.n_channels * a.n_cols;
@@ -415,7 +484,8 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook h
         hipLaunchKernelGGL(columns_from_rows_kernel<32>, dim3((unsigned)ceil_div(a.vs_pitch, 32), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
                            dim3(256), 0, s, a);
     if (hook) hook(user, 0);
-    hipLaunchKernelGGL(rank_columns_kernel<LOG2N>, dim3((unsigned)cols), dim3(N / 32), lds, s, a);
+    if (wide) hipLaunchKernelGGL((rank_columns_kernel<LOG2N, true>), dim3((unsigned)cols), dim3(N / 32), lds, s, a);
+    else hipLaunchKernelGGL((rank_columns_kernel<LOG2N, false>), dim3((unsigned)cols), dim3(N / 32), lds, s, a);
     if (hook) hook(user, 1);
     if (a.P) {                           // the bit-sliced selection reads the planes only: no frame-major codes
         // REPET_RANK_TILE=64: the 64-frame workgroups of round 4 (A/B)

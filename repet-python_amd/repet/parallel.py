@@ -214,7 +214,8 @@ def separate_clips(algo, clips, sampling_frequency, separate_fn=None, device=Non
     t_start = time.perf_counter()
     compute_s = 0.0
     # the root's end of an fp32 RCCL wire: a staging context of the engine (pinned ring + host worker threads)
-    io = _context(("io", dev.index)) if (on_gpu and separate_fn is None and np.dtype(wire_dtype) == np.float32) else None
+    # (only the root stages anything: a context is a stream, a pinned ring and workspaces)
+    io = _context(("io", dev.index)) if (rank == root and on_gpu and separate_fn is None and np.dtype(wire_dtype) == np.float32) else None
 
     shares_of = lambda shapes_: deal_clips([s[0] for s in shapes_], world)
     meta = [None]
