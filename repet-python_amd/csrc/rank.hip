@@ -470,8 +470,12 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook h
     // 23 and NOT faster -- rank_columns_kernel<13> 132.6 us beside the peak picking against 125-130, the stage 0.2411-0.2415 ms
     // against 0.2392-0.2424: a trip's cost is its LDS INSTRUCTIONS (64 or 32 four- / eight-byte accesses per thread against 16
     // sixteen-byte ones), not its bytes. Default: the three-stage trips.
-    static const bool wide = [] { const char* t = getenv("REPET_RANK_TRIPS"); return t && t[0] == '5'; }();
-    const void* fn = wide ? reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N, true>) : reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N, false>);
+    // (2^15 keys: 1 024 threads at 128 registers each -- the wide trips spill there, that size keeps the three-stage form)
+    static const bool wide_env = [] { const char* t = getenv("REPET_RANK_TRIPS"); return t && t[0] == '5'; }();
+    constexpr bool kWideOk = LOG2N <= 14;
+    const bool wide = kWideOk && wide_env;
+    const void* fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N, false>);
+    if constexpr (kWideOk) { if (wide) fn = reinterpret_cast<const void*>(&rank_columns_kernel<LOG2N, true>); }
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
     const int64_t cols = (int64_t)a.n_channels * a.n_cols;
@@ -484,8 +488,11 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook h
         hipLaunchKernelGGL(columns_from_rows_kernel<32>, dim3((unsigned)ceil_div(a.vs_pitch, 32), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
                            dim3(256), 0, s, a);
     if (hook) hook(user, 0);
-    if (wide) hipLaunchKernelGGL((rank_columns_kernel<LOG2N, true>), dim3((unsigned)cols), dim3(N / 32), lds, s, a);
-    else hipLaunchKernelGGL((rank_columns_kernel<LOG2N, false>), dim3((unsigned)cols), dim3(N / 32), lds, s, a);
+    bool launched = false;
+    if constexpr (kWideOk) {
+        if (wide) { hipLaunchKernelGGL((rank_columns_kernel<LOG2N, true>), dim3((unsigned)cols), dim3(N / 32), lds, s, a); launched = true; }
+    }
+    if (!launched) hipLaunchKernelGGL((rank_columns_kernel<LOG2N, false>), dim3((unsigned)cols), dim3(N / 32), lds, s, a);
     if (hook) hook(user, 1);
     if (a.P) {                           // the bit-sliced selection reads the planes only: no frame-major codes
         // REPET_RANK_TILE=64: the 64-frame workgroups of round 4 (A/B)

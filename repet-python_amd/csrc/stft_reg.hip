@@ -327,9 +327,15 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
                 Vrow[k] = mag;
                 acc[s_] += mag;
             };
+            // (pairs 4 .. 7 first, then 0 .. 3, each group's mirrored bins handed over before the next: four of them live instead
+            // of eight -- with all eight the stereo kernel spilled two registers. Lane 0's slot 15 - j takes ITS pair j + 1: the
+            // first group needs x512 for slot 8, the second keeps pair 4's mirrored bin for slot 12.)
             float2 xs[8];
+            const float2 x512 = make_float2(v[8].x, -v[8].y);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int g = 1; g >= 0; --g) {
+#pragma unroll
+            for (int s = 4 * g; s < 4 * g + 4; ++s) {
                 const float2 zk = v[s];
                 const float2 other = make_float2(lane_fetch(v[15 - s].x, partner), lane_fetch(v[15 - s].y, partner));
                 const float2 mine = v[(16 - s) & 15];
@@ -343,19 +349,19 @@ __global__ __launch_bounds__(64 * kFwdWaves) void stft_reg_kernel(StftArgs a, in
                 xs[s] = make_float2(fmaf(0.5f, sx, -tx), fmaf(-0.5f, sy, ty));
                 if (s & 1) __builtin_amdgcn_sched_barrier(0);             // a few bins in flight, not sixteen
             }
+#pragma unroll
+            for (int j = 4 * g; j < 4 * g + 4; ++j) {                     // slots 15 - j: what the mirror lane computed for them
+                const float2 got = make_float2(lane_fetch(xs[j].x, partner), lane_fetch(xs[j].y, partner));
+                const float2 own0 = j < 7 ? xs[j + 1] : x512;
+                put(15 - j, (lane == 0) ? own0 : got);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            }
             {   // k = N (Nyquist): lane 0's pair 0
                 const float2 x = make_float2(xs[0].x, 0.f);
                 const float mag = magnitude(x);           // (not fabsf: the inverse recomputes every bin's magnitude the same way)
                 if (lane == 0) { Xrow[N] = x; Vrow[N] = mag; }
                 acc[16] += mag;
-            }
-            const float2 x512 = make_float2(v[8].x, -v[8].y);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                                 // slots 15 .. 8: what the mirror lane computed for them
-                const float2 got = make_float2(lane_fetch(xs[j].x, partner), lane_fetch(xs[j].y, partner));
-                const float2 own0 = j < 7 ? xs[j + 1] : x512;
-                put(15 - j, (lane == 0) ? own0 : got);
-                if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
             if (lane < a.FS - (N + 1)) {      // zero the pad bins [F, FS)
                 Xrow[N + 1 + lane] = make_float2(0.f, 0.f);
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                 // itself, Z[N/2] = conj(A). All loads of a transform are issued before the first is consumed.
                 const int partner = (64 - lane) & 63;
                 float2 xk[8], xc[8], x512;
-                float mk[MASKED ? 8 : 1], mc[MASKED ? 8 : 1], m512 = 1.f;
+                float mk[MASKED == 1 ? 8 : 1], mc[MASKED == 1 ? 8 : 1], m512 = 1.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { xk[j] = Y[64 * j + lane]; xc[j] = Y[N - (64 * j + lane)]; }
                 x512 = Y[N / 2];                                              // (every lane the same address: one request)
@@ -548,26 +554,25 @@ __global__ __launch_bounds__(64 * kInvWaves) void istft_ola_reg_kernel(IstftOlaA
                     for (int j = 0; j < 8; ++j) { mk[j] = Mr[64 * j + lane]; mc[j] = Mr[N - (64 * j + lane)]; }
                     m512 = Mr[N / 2];
                 }
+                float wk[MASKED == 2 ? 8 : 1], wc[MASKED == 2 ? 8 : 1];          // MASKED == 2: the model at the lane's sixteen bins
                 if constexpr (MASKED == 2) {
-                    float wk[8], wc[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { wk[j] = Wr[64 * j + lane]; wc[j] = Wr[N - (64 * j + lane)]; }
-                    const float w512 = Wr[N / 2];
-                    // |X| with the forward kernel's own roundings (magnitude(): V is not read at all)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        mk[j] = soft_mask(magnitude(xk[j]), wk[j], 64 * j + lane, a.cutoff);
-                        mc[j] = soft_mask(magnitude(xc[j]), wc[j], N - (64 * j + lane), a.cutoff);
-                        __builtin_amdgcn_sched_barrier(0);                     // two divisions' temporaries at a time, not sixteen
-                    }
-                    m512 = soft_mask(magnitude(x512), w512, N / 2, a.cutoff);
+                    m512 = soft_mask(magnitude(x512), Wr[N / 2], N / 2, a.cutoff);
                 }
                 float2 send[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = 64 * j + lane;
                     float2 a_ = xk[j], b_ = xc[j];
-                    if constexpr (MASKED != 0) {
+                    if constexpr (MASKED == 2) {
+                        // the pair's masks where they are used: |X| with the forward kernel's own roundings (magnitude(): V is not
+                        // read at all); the model values die here (all sixteen masks first cost a register spill)
+                        const float mk2 = soft_mask(magnitude(a_), wk[j], k, a.cutoff), mc2 = soft_mask(magnitude(b_), wc[j], N - k, a.cutoff);
+                        a_ = make_float2(mul_rounded(a_.x, mk2), mul_rounded(a_.y, mk2));
+                        b_ = make_float2(mul_rounded(b_.x, mc2), mul_rounded(b_.y, mc2));
+                        __builtin_amdgcn_sched_barrier(0);                     // two divisions' temporaries at a time, not sixteen
+                    } else if constexpr (MASKED == 1) {
                         a_ = make_float2(mul_rounded(a_.x, mk[j]), mul_rounded(a_.y, mk[j]));
                         b_ = make_float2(mul_rounded(b_.x, mc[j]), mul_rounded(b_.y, mc[j]));
                     }
