@@ -405,6 +405,12 @@ int repet_online_push(repet_online* h, const void* audio, int dtype, int64_t n_s
 int repet_online_finish(repet_online* h, double* out, int64_t capacity, int64_t* n_written);
 int repet_online_close(repet_online* h);
 
+/* (ABI 4) Self-test of the host conversions a staged upload / download runs (float64 -> fp32 samples + fp32 remainders,
+ * fp32 -> float64; non-temporal AVX-512 / AVX2 lines where the CPU has them) against scalar loops on n values with NaN,
+ * infinities, denormals, PCM-exact runs and every misalignment. No GPU needed. Returns the number of values that differ
+ * (0 = pass). */
+int64_t repet_host_conversion_selftest(int64_t n, uint32_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,8 +283,12 @@ Geo make_geo(int W, int H, int64_t T, int C) {
 // (one clip): the split pass disappears (-0.011 ms) and the STFT grows by as much (+0.012 ms: two 2-byte stores per
 // component from a thread that owns every 256th bin) -- no gain. Measured at cfg 5 (64 clips of 30 s): the split pass is
 // 0.136 ms there, the STFT grows by 0.065: step 2.54 -> 2.47 ms. So: batches yes, single clips no.
+// Round 6, measured again with the register STFT kernel (a lane writes the two halves of ITS sixteen components: profiles/
+// r06_split_in_stft_ab.txt): single clip, cfg 2: STFT 0.0734 -> 0.0770 ms, Gram stage (which held the split pass) 0.2038 ->
+// 0.1927: step 0.851 -> 0.843. So: always. REPET_SPLIT_IN_STFT=0: the separate pass for single clips (A/B).
 bool split_in_stft(int B) {
-    return B > 1 && gram_f16_enabled();
+    static const bool single_too = [] { const char* e = getenv("REPET_SPLIT_IN_STFT"); return !(e && e[0] == '0'); }();
+    return (B > 1 || single_too) && gram_f16_enabled();
 }
 
 // The mask kernels read V, read X and write X: 20 bytes per cell, and the inverse STFT reads X again. With the mask as a
@@ -293,8 +297,8 @@ bool split_in_stft(int B) {
 // about what the byte count says, so it depends on the mask kernel whether the sum gains (mask + inverse, ms, same box):
 //   extended cfg 3 (period mask, HBM-bound)      0.415 + 0.461 -> 0.249 + 0.498   default: plane
 //   simonline cfg 5 (ten similar frames: HBM)    0.763 + 0.544 -> 0.603 + 0.608   default: plane
-//   adaptive cfg 4                                0.077 + 0.055 -> 0.060 + 0.068   default: in place
-//   sim cfg 2 (selection-bound mask)              0.50 + 0.072 -> 0.50 + 0.091     default: in place
+//   adaptive cfg 4                                0.077 + 0.055 -> 0.060 + 0.068   default: in place (round 6: plane, 0.0775 + 0.0494 -> 0.0529 + 0.0573)
+//   sim cfg 2 (selection-bound mask)              0.50 + 0.072 -> 0.50 + 0.091     default: in place (round 6: plane, 0.1045 + 0.0533 -> 0.0855 + 0.0661)
 // REPET_MASK_PLANE=0 / 1 / p: never / in every variant (with the repeating-segment model where a variant has one) / the same
 // as a plain plane, without the model.
 int mask_plane_forced() {
@@ -302,7 +306,9 @@ int mask_plane_forced() {
     return forced;
 }
 bool mask_plane_wanted(MaskKind kind) {
-    return mask_plane_forced() >= 0 ? mask_plane_forced() != 0 : (kind == MaskKind::period || kind == MaskKind::sim_float);
+    // (round 6: `adaptive` too -- mask 0.0775 -> 0.0529, inverse 0.0494 -> 0.0573, step 0.262 -> 0.246 ms at cfg 4; and `sim` on rank
+    // codes where the register inverse kernel applies: exec_sim. profiles/r06_mask_plane_ab.txt)
+    return mask_plane_forced() >= 0 ? mask_plane_forced() != 0 : (kind == MaskKind::period || kind == MaskKind::sim_float || kind == MaskKind::adaptive);
 }
 
 

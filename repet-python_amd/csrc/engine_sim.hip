@@ -171,7 +171,12 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     const bool ranks_ahead = rank_median_enabled() && g.F > 128 && ((g.F - 1) & 127) == 0 && rank_columns_supported(T) &&
                              std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1)) >= kRankMinList &&
                              std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1)) <= 128;
-    MaskPlaneScope plane(c, mask_plane_wanted(ranks_ahead ? MaskKind::sim_ranks : MaskKind::sim_float));
+    // Round 6: with the median on rank codes too the mask leaves the lookup kernel as a PLANE when the register inverse STFT will
+    // apply it (W = 2048, mono / stereo). Rounds 3-5 masked X in place there (0.50 + 0.072 -> 0.50 + 0.091 ms with the kernels of
+    // round 3); with the lookups a kernel of their own and the inverse merging in pairs the plane wins: lookups 0.1045 -> 0.0855,
+    // inverse 0.0533 -> 0.0661, step 0.840 -> 0.829 ms (profiles/r06_mask_plane_ab.txt). REPET_MASK_PLANE=0 / p force either.
+    const bool plane_for_ranks = ranks_ahead && mask_plane_forced() < 0 && reg_fft_supported(g.W, g.C, true);
+    MaskPlaneScope plane(c, plane_for_ranks || mask_plane_wanted(ranks_ahead ? MaskKind::sim_ranks : MaskKind::sim_float));
     RP_TRY(ensure_spectra(c, g, true, false));
     RP_TRY(run_stft(c, g, tb, 0, N, 1, true, false));
     const int64_t TS = round_up(T, 64);

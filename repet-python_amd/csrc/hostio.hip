@@ -757,3 +757,73 @@ void host_free(void* ptr) {
 }
 
 }  // namespace repet
+
+// (ABI 4) Self-test of the host conversions, no GPU needed: the routines a staged upload / download runs (float64 -> fp32
+// samples + fp32 remainders, fp32 -> float64; non-temporal AVX-512 / AVX2 lines where the CPU has them) against scalar
+// loops, on n values with NaN, infinities, denormals, PCM-exact runs and every misalignment of the part's first element.
+// Returns the number of values that differ (0 = pass), -1 for n < 1.
+extern "C" int64_t repet_host_conversion_selftest(int64_t n, uint32_t seed) {
+    using namespace repet;
+    if (n < 1) return -1;
+    const size_t count = (size_t)n;
+    std::vector<double> src(count + 64);
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ seed;
+    auto rnd = [&st]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (size_t i = 0; i < src.size(); ++i) {
+        const uint64_t r = rnd();
+        double x = (double)(int64_t)(r >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;          // 53 random bits in [-1, 1)
+        const unsigned kind = (unsigned)(r & 1023u);
+        if (kind == 0) x = std::numeric_limits<double>::quiet_NaN();
+        else if (kind == 1) x = std::numeric_limits<double>::infinity();
+        else if (kind == 2) x = -std::numeric_limits<double>::infinity();
+        else if (kind == 3) x = 4.9e-324;
+        else if (kind == 4) x = 1.0e-42;                                                       // an fp32 denormal
+        else if (kind < 40) x = std::round(x * 32768.0) / 32768.0;                              // PCM-exact: no remainder
+        src[i] = x;
+    }
+    // a PCM-exact stretch at the start of some parts (the "remainders only tested" blocks of split_part)
+    for (size_t i = 0; i < std::min<size_t>(count, 5000); ++i) src[i] = std::round(src[i] == src[i] && std::fabs(src[i]) <= 1.0 ? src[i] * 32768.0 : 0.0) / 32768.0;
+    int64_t bad = 0;
+    auto same = [](float a, float b) { return std::memcmp(&a, &b, 4) == 0 || (a != a && b != b); };
+    auto same_d = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0 || (a != a && b != b); };
+    const size_t pad = 16;                                      // floats in front of the outputs: every misalignment of a line
+    std::vector<float> hi(count + 2 * pad + 64), lo(count + 2 * pad + 64), back(count + 64);
+    std::vector<double> wide(count + 2 * pad + 64);
+    for (size_t shift = 0; shift < 16; shift += 3) {
+        const size_t a = shift, b = count;                      // the part [a, b)
+        if (a >= b) break;
+        // float64 -> hi + lo
+        std::fill(hi.begin(), hi.end(), -7.f);
+        std::fill(lo.begin(), lo.end(), -7.f);
+        bool nf = false;
+        const bool any = split_part(src.data(), hi.data() + pad, lo.data() + pad, a, b, &nf);
+        bool want_any = false, want_nf = false;
+        for (size_t k = a; k < b; ++k) {
+            const double x = src[k];
+            const float h = (float)x;
+            want_any |= (x != (double)h);
+            want_nf |= !(std::fabs(x) <= std::numeric_limits<double>::max());
+        }
+        if (any != want_any || nf != want_nf) ++bad;
+        size_t first_lo = b;                                    // remainders are written from the first block that holds one
+        for (size_t k = a; k < b; ++k) if (src[k] != (double)(float)src[k]) { first_lo = k; break; }
+        for (size_t k = a; k < b; ++k) {
+            const double x = src[k];
+            const float h = (float)x;
+            if (!same(hi[pad + k], h)) ++bad;
+            if (any) {
+                const float l = (float)(x - (double)h);
+                const float got = lo[pad + k];
+                if (k >= first_lo ? !same(got, l) : !(same(got, 0.f) || same(got, l))) ++bad;
+            }
+        }
+        // fp32 -> float64
+        for (size_t k = 0; k < count; ++k) back[k] = hi[pad + std::max(k, a)];
+        std::fill(wide.begin(), wide.end(), -7.0);
+        widen_f32(back.data(), wide.data() + (shift & 7), a, b);
+        for (size_t k = a; k < b; ++k) if (!same_d(wide[(shift & 7) + k], (double)back[k])) ++bad;
+        if (a > 0 && wide[(shift & 7) + a - 1] != -7.0) ++bad;   // nothing written outside the part
+        if (wide[(shift & 7) + b] != -7.0) ++bad;
+    }
+    return bad;
+}

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void mask_sim_nyquist_wave_kernel(MaskArgs a, c
 // REPET_NYQUIST=wave: the wave-per-frame kernel; =lane: the lane-per-frame kernel walking its list entry by entry (round 5);
 // default: the lane-per-frame kernel with its list fetched up front (agreement test / A-B)
 static int nyquist_path() {
-    static const int path = [] { const char* e = getenv("REPET_NYQUIST"); return (e && e[0] == 'w') ? 1 : (e && e[0] == 'l') ? 2 : 0; }();
+    static const int path = [] { const char* e = getenv("REPET_NYQUIST"); return (e && e[0] == 'w') ? 1 : (e && e[0] == 'l' && e[1] == 'a') ? 2 : 0; }();   // wave | lane | (lists)
     return path;
 }
 
@@ -604,8 +604,12 @@ hipError_t launch_mask_sim(const MaskArgs& m, const int32_t* idx, int32_t idx_pi
                            hipEvent_t fork, hipEvent_t join, int parts, bool lookups_by_caller) {
     const int64_t t_end = m.frame_end > 0 ? m.frame_end : m.T;
     if (t_end - m.frame0 <= 0) return hipSuccess;
-    // the Nyquist-bin kernel (a few hundred latency-bound waves) runs on `side` next to the main kernel
-    const bool forked = side != nullptr && fork != nullptr && join != nullptr && parts == 3;
+    // Round 6: the Nyquist-bin kernel runs on the MAIN stream, in front of the selection. With its list fetched up front it is short,
+    // and beside the selection (rounds 2-5: a fork and a join) it cost that kernel what it took itself: selection stage 0.181 ->
+    // 0.176 ms at cfg 2 with the kernel in line, cfg 5 2.27 -> 2.21 ms (profiles/r06_nyquist_stream_ab.txt).
+    // REPET_NYQUIST_STREAM=side: the forked form.
+    static const bool nyq_side = [] { const char* e = getenv("REPET_NYQUIST_STREAM"); return e && e[0] == 's'; }();
+    const bool forked = nyq_side && side != nullptr && fork != nullptr && join != nullptr && parts == 3;
     const bool split = m.F > 64 && ((m.F - 1) & 63) == 0;
     const int64_t rows = m.T - first_frame;
     const unsigned n_launch = (unsigned)(t_end - m.frame0);   // frames [frame0, t_end) are processed

@@ -106,6 +106,7 @@ _SIGNATURES = {
                                   C.POINTER(C.c_int32), C.POINTER(Params), C.POINTER(_P), C.c_int32]),
     "repet_run_stream": (C.c_int, [C.c_int, C.c_int32, C.POINTER(_P), C.c_int, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int32), C.POINTER(Params), C.POINTER(_P), C.c_int, C.c_int32]),
+    "repet_host_conversion_selftest": (C.c_int64, [C.c_int64, C.c_uint32]),
     "repet_frame_count": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "repet_stft": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64]),
     "repet_istft": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, C.c_int64]),

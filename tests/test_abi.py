@@ -215,3 +215,13 @@ def test_no_compiled_binary_is_tracked():
                 if fh.read(4) == b"\x7fELF":
                     elf.append(name)
     assert not elf, elf
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (63, 2), (4095, 3), (4096, 4), (70001, 5), (1 << 20, 6)])
+def test_host_conversions_against_scalar_loops(n, seed):
+    """The conversions of a staged upload / download (hostio.hip: float64 -> fp32 samples + fp32 remainders with the
+    PCM-exact fast blocks, fp32 -> float64; non-temporal AVX-512 / AVX2 lines where the CPU has them, REPET_HOST_NT) against
+    scalar loops: NaN, infinities, denormals, PCM-exact runs, every misalignment of a part's first element, nothing written
+    outside the part. Runs without a GPU."""
+    assert _native.lib().repet_host_conversion_selftest(n, seed) == 0
+    assert _native.lib().repet_host_conversion_selftest(0, seed) == -1

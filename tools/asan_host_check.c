@@ -244,6 +244,10 @@ int main(void) {
     check_sizes();
     check_wav_parser();
     check_context_calls();
+    /* the host conversions (non-temporal lines, PCM-exact blocks) against scalar loops, every misalignment: under ASan / UBSan */
+    CHECK(repet_host_conversion_selftest(70001, 9u) == 0);
+    CHECK(repet_host_conversion_selftest(4095, 10u) == 0);
+    CHECK(repet_host_conversion_selftest(0, 1u) == -1);
     if (failures) {
         fprintf(stderr, "%d check(s) failed\n", failures);
         return 1;
