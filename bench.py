@@ -465,7 +465,7 @@ def main():
                 ach = meta["bytes"] / sec / 1e9
                 entry.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                               "algorithmic": meta["bytes"],
-                              "note": "streams V, the selected codes and X; the scattered 4-byte table reads (two per cell that needs them, a 128-byte "
+                              "note": "streams V and the selected codes, writes the mask plane (or masks X in place); the scattered 4-byte table reads (two per cell that needs them, a 128-byte "
                                       "L2 line each) are what it waits for"})
                 both = sec + stage_ms["mask_sim_select"] / steps * 1e-3
                 b8d = 4.0 * F * rows * C * (1.0 + k_mean + 1.0)
