@@ -946,6 +946,41 @@ def test_nyquist_bin_kernels_agree_bit_for_bit(variant, seconds, fs, channels, n
     assert np.array_equal(outs[0], outs[2], equal_nan=True) and np.array_equal(outs[1], outs[2], equal_nan=True)
 
 
+def test_round_six_switches_give_the_same_result():
+    """The A/B switches of round 6 select other kernels / schedules for the same arithmetic: the 64-frame transposes of the rank
+    chain, the five-stage trips of the column sort, the separate f16-split pass, the forked Nyquist-bin kernel, the Gram
+    kernel's staggered start, plain host stores, the mask multiplied in place -- `sim` on a clip long enough for the big-tile
+    Gram kernel and the rank-domain median must come out BIT FOR BIT as with the defaults. The float64 norms of the unit rows on
+    a table change level-1 values in their last bits (never a decision that is not re-taken at level 2): the lists' lengths
+    stay, the signal within 1e-6."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import repet; from repet_synth import synth; "
+            "x = synth(52, 44100, 2, 77); p = repet.derive_params(44100); c = repet.Context(0); c.upload(x); c.execute('sim', p); "
+            "y = c.download(); _, cnt = c.last_sim_indices(c.last_frame_count(), p.sim_number); np.savez(sys.argv[1], y=y, cnt=cnt)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (os.path.join(root, "repet-python_amd"), root)
+
+    def run(env):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"repet_r6_switch_{os.getpid()}.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, **env))
+        with np.load(out) as z:
+            got = {k: z[k] for k in z.files}
+        os.remove(out)
+        return got
+
+    base = run({})
+    assert np.all(np.isfinite(base["y"])) and base["cnt"].min() >= 1
+    for env in ({"REPET_RANK_TILE": "64"}, {"REPET_RANK_TRIPS": "5"}, {"REPET_SPLIT_IN_STFT": "0"}, {"REPET_NYQUIST_STREAM": "side"},
+                {"REPET_GRAM_STAGGER_US": "5", "REPET_GRAM_STAGGER_GROUPS": "4"}, {"REPET_HOST_NT": "0"}, {"REPET_MASK_PLANE": "0"}):
+        got = run(env)
+        assert np.array_equal(got["y"], base["y"]), env
+        assert np.array_equal(got["cnt"], base["cnt"]), env
+    got = run({"REPET_PEAK_NORMS": "1"})
+    assert np.array_equal(got["cnt"], base["cnt"]) and rms_err(got["y"], base["y"]) <= 1e-6
+
+
 def test_long_similarity_number_uses_bisection_path():
     """similarity_number > 128 takes the bisection median (no sorting network of that size)."""
     x, fs = golden_input("small_stereo")
