@@ -408,6 +408,9 @@ struct RankArgs {
     float* Vs; int64_t vs_pitch;          // Vs[c * n_cols + f][vs_pitch], vs_pitch = round_up(T, 32)
     unsigned short* codes;                // scratch: the codes column-major, [c * n_cols + f][vs_pitch]
     unsigned* P; int32_t n_planes;        // the codes bit-sliced INSTEAD of R (exactly one of R and P is set): MaskArgs::P
+    // phases of the chain a launch_rank_columns call runs: bit 0 the transpose V -> columns, bit 1 the sort and what follows
+    // (0 = both). The transpose needs V only and may run early (exec_sim, REPET_RANK_TRANSPOSE=early).
+    int32_t phases;
 };
 bool rank_columns_supported(int64_t T);
 // CPUs of the NUMA node device `dev` hangs off that this process may run on (hostio.hip; empty: unknown or nothing to choose)

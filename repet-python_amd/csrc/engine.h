@@ -205,7 +205,7 @@ int run_exact_rows(repet_ctx* c, const Tables* tb, const Geo& g, const float* M,
                    const PeakRefine& rf, const PeakBatch* batch, const float* hi, const float* lo, int64_t n_samples,
                    int64_t clip_stride, int64_t frame_sample0, int64_t n_frames, int clips);
 bool rank_median_enabled();
-int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count);
+int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count, int phases = 0);
 int exec_sim(repet_ctx* c, const repet_params* p);
 int exec_simonline(repet_ctx* c, const repet_params* p);
 int prepare_power_planes(repet_ctx* c, const Geo& g, int64_t T, int B);

@@ -120,7 +120,7 @@ static bool bits_median_enabled() {
 }
 
 // Sort every column of V and fill m's rank fields (bins [0, F-1); the lone Nyquist bin stays on the float kernel).
-int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count) {
+int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream, bool with_mark, int max_count, int phases) {
     const int n_cols = g.F - 1;
     const int64_t vs_pitch = round_up(g.T, 32);
     // (the bit-sliced selection reads the code planes only: no frame-major codes R then)
@@ -137,6 +137,7 @@ int run_rank_columns(repet_ctx* c, const Geo& g, MaskArgs* m, hipStream_t stream
     a.V = c->V.as<float>(); a.chan_stride = g.chan_stride; a.n_channels = g.C; a.T = g.T; a.FS = g.FS; a.n_cols = n_cols;
     a.R = bits ? nullptr : c->R.as<unsigned short>(); a.r_chan_stride = g.chan_stride; a.Vs = c->Vs.as<float>(); a.vs_pitch = vs_pitch;
     a.codes = c->rank_codes.as<unsigned short>();
+    a.phases = phases;
     if (bits) {
         a.n_planes = code_planes_for(g.T);
         HIP_TRY(c->code_planes.ensure((size_t)g.T * a.n_planes * 64 * sizeof(unsigned)));
@@ -187,6 +188,18 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
     if (with_seg) HIP_TRY(c->seg.ensure((size_t)T * 3 * seg_pitch * sizeof(float)));
     float* seg = with_seg ? c->seg.as<float>() : nullptr;
     bool seg_written = false;
+    // Experiment of round 6 (REPET_RANK_TRANSPOSE=early; measured: stage -12 us, step +13 us, profiles/r06_transpose_early_ab.txt -- off):
+    // the transpose that opens the column sort needs V only -- in line IN FRONT OF
+    // the Gram kernel (26 us alone) instead of squeezed in beside the first pass of the peak picking (55 us there), so that the sort
+    // itself is what the side stream starts with.
+    static const bool early_transpose = [] { const char* e = getenv("REPET_RANK_TRANSPOSE"); return e && e[0] == 'e'; }();
+    const int early_peaks = (int)std::min<int64_t>(p->sim_number, ceil_div(T, p->sim_distance_frames + 1));
+    const bool transposed_early = early_transpose && ranks_ahead;
+    if (transposed_early) {
+        MaskArgs m0 = mask_args(c, g, p->cutoff_bins);
+        RP_TRY(run_rank_columns(c, g, &m0, c->stream, false, early_peaks, 1));
+        mark(c, "columns_from_rows", (4.0 + 4.0) * (g.F - 1) * (double)g.T * g.C, 0);
+    }
     // The float64 norms of the unit rows (the first pass's float64 similarities divide by them: peaks.h) need the unit rows only:
     // they are computed on the side stream BESIDE the Gram kernel -- enqueued behind its launch, so the Gram's workgroups take the
     // CUs first and the 1 939 small workgroups of this kernel run where its second round leaves CUs idle (496 tiles on 256 CUs).
@@ -254,7 +267,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
         if (beside) {
             HIP_TRY(hipEventRecord(c->fork_event, c->stream));          // V is complete (so is S)
             HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
-            RP_TRY(run_rank_columns(c, g, &m, c->side_stream, false, max_peaks));
+            RP_TRY(run_rank_columns(c, g, &m, c->side_stream, false, max_peaks, transposed_early ? 2 : 0));
             HIP_TRY(hipEventRecord(c->join_event, c->side_stream));
         }
         const size_t scratch = local_maxima_scratch_bytes(T, (int)T, p->sim_distance_frames);
@@ -279,7 +292,7 @@ int exec_sim(repet_ctx* c, const repet_params* p) {
             mark(c, "peaks+rank_columns", 4.0 * T * T + 4.0 * K * T + (4.0 + 4.0 + 8.0 + 4.0 + 2.0 + 2.0 + 2.0) * (g.F - 1) * (double)g.T * g.C, 0);
         } else {
             mark(c, use_rank ? "local_maxima_level2" : "local_maxima", use_rank ? 0.0 : 4.0 * T * T + 4.0 * K * T, 0);
-            if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true, max_peaks));
+            if (use_rank) RP_TRY(run_rank_columns(c, g, &m, c->stream, true, max_peaks, transposed_early ? 2 : 0));
         }
         HIP_TRY(launch_mask_sim(m, c->idx.as<int32_t>(), KP, c->cnt.as<int32_t>(), 0, max_peaks, c->stream, c->side_stream,
                                 c->fork_event, c->join_event, 3, m.P != nullptr));

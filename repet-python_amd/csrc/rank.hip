@@ -481,13 +481,17 @@ static hipError_t launch_rank_n(const RankArgs& a, hipStream_t s, RankStepHook h
     const int64_t cols = (int64_t)a.n_channels * a.n_cols;
     // REPET_RANK_TILE=64: the 64-frame tiles of round 4 (A/B)
     static const bool tall = [] { const char* e = getenv("REPET_RANK_TILE"); return e && e[0] == '6'; }();
-    if (tall)
-        hipLaunchKernelGGL(columns_from_rows_kernel<64>, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
-                           dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(columns_from_rows_kernel<32>, dim3((unsigned)ceil_div(a.vs_pitch, 32), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
-                           dim3(256), 0, s, a);
-    if (hook) hook(user, 0);
+    const bool do_transpose = a.phases == 0 || (a.phases & 1), do_sort = a.phases == 0 || (a.phases & 2);
+    if (do_transpose) {
+        if (tall)
+            hipLaunchKernelGGL(columns_from_rows_kernel<64>, dim3((unsigned)ceil_div(a.vs_pitch, 64), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
+                               dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(columns_from_rows_kernel<32>, dim3((unsigned)ceil_div(a.vs_pitch, 32), (unsigned)(a.n_cols / 64), (unsigned)a.n_channels),
+                               dim3(256), 0, s, a);
+        if (hook) hook(user, 0);
+    }
+    if (!do_sort) return hipGetLastError();
     bool launched = false;
     if constexpr (kWideOk) {
         if (wide) { hipLaunchKernelGGL((rank_columns_kernel<LOG2N, true>), dim3((unsigned)cols), dim3(N / 32), lds, s, a); launched = true; }
